@@ -1,0 +1,82 @@
+"""Row a5 (MLL + gradient) has no reference code to pin against (it lives in gpytorch, absent).
+The oracle's closed form is checked against fp64 autograd of the dense Gaussian log-density,
+against the torch-CPU restatement used as cpu_baseline, and against this kernel's analytic
+identities.  CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_cpu_path as tp
+from oracle import volt_oracle as vo
+from volt_amd.synthetic import sde_batch
+
+
+def _problem(B, n, seed=2019):
+    x, F, vol = sde_batch(B, n, seed)
+    K = vo.volatility_kernel(np.repeat(x[None], B, 0)[..., None], vol[..., None])
+    y = np.log(F[:, 1:])
+    mean = np.stack([vo.ewma_mean(x, x, y[b], 25) for b in range(B)])
+    return x, vol, K, y, mean
+
+
+@pytest.mark.parametrize("n", [64, 200])
+def test_closed_form_vs_fp64_autograd(n):
+    _, _, K, y, mean = _problem(2, n)
+    for b in range(2):
+        raw = torch.tensor(1e-5, dtype=torch.float64, requires_grad=True)
+        m = torch.tensor(mean[b], dtype=torch.float64, requires_grad=True)
+        val = tp.mll_value_fp64(torch.tensor(K[b]), torch.tensor(y[b]), m, raw)
+        val.backward()
+        o = vo.mll_and_grads(K[b], y[b], mean[b], 1e-5)
+        assert abs(o["mll"] - val.item()) < 1e-10 * max(1, abs(val.item()))
+        assert abs(o["d_raw"] - raw.grad.item()) < 1e-9 * max(1, abs(raw.grad.item()))
+        np.testing.assert_allclose(o["d_mean"], m.grad.numpy(), rtol=1e-8, atol=1e-12)
+        assert abs(o["sigma2"] - 0.6932521) < 1e-6       # softplus(1e-5)+1e-4
+
+
+def test_torch_cpu_step_matches_oracle_fp64():
+    _, _, K, y, mean = _problem(3, 96)
+    raw = torch.full((3,), 1e-5, dtype=torch.float64, requires_grad=True)
+    mll, g = tp.mll_step(torch.tensor(K).double(), torch.tensor(y).double(),
+                         torch.tensor(mean).double(), raw)
+    o = vo.mll_and_grads(K, y, mean, 1e-5)
+    np.testing.assert_allclose(mll.numpy(), o["mll"], rtol=1e-11)
+    np.testing.assert_allclose(g.numpy(), o["d_raw"], rtol=1e-9)
+
+
+def test_analytic_cholesky_identity():
+    """K = C diag(d) C'  =>  chol(K)[i,j] = sqrt(d_j), K^-1 tridiagonal."""
+    x, vol, K, _, _ = _problem(1, 64)
+    V = vo.cumtrapz((vol[0] * vol[0]).astype(np.float64), x.astype(np.float64))
+    K64 = V[np.minimum.outer(np.arange(64), np.arange(64))]
+    L = np.linalg.cholesky(K64)
+    np.testing.assert_allclose(L, vo.analytic_cholesky(V), rtol=1e-9, atol=1e-14)
+    Kinv = np.linalg.inv(K64)
+    off = Kinv - np.triu(np.tril(Kinv, 1), -1)
+    assert np.abs(off).max() < 1e-6 * np.abs(np.diag(Kinv)).max()
+
+
+def test_one_step_conditional_identity():
+    """K_tr^-1 k_tr,te = e_last and pred_cov = 1/2 dx v_new^2."""
+    n = 50
+    x = np.arange(n + 1) / 252.0
+    rng = np.random.RandomState(1)
+    vol = rng.uniform(0.1, 0.4, n + 1)
+    K = vo.volatility_kernel(x, vol)
+    sol = np.linalg.solve(K[:n, :n], K[:n, n])
+    e = np.zeros(n)
+    e[-1] = 1
+    np.testing.assert_allclose(sol, e, atol=1e-8)
+    pc = K[n, n] - K[:n, n] @ sol
+    assert abs(pc - 0.5 * (1 / 252.0) * vol[-1] ** 2) < 1e-10
+
+
+def test_psd_safe_cholesky_jitter_loop():
+    a = np.ones((4, 4), dtype=np.float32)            # rank 1: fails without jitter
+    L, jit = vo.psd_safe_cholesky(a, jitter=1e-4)
+    assert jit == pytest.approx(1e-4)
+    np.testing.assert_allclose(L @ L.T, a + 1e-4 * np.eye(4), atol=1e-5)
+    with pytest.raises(np.linalg.LinAlgError):
+        vo.psd_safe_cholesky(-np.eye(3, dtype=np.float32), jitter=1e-4)
+    with pytest.raises(FloatingPointError):
+        vo.psd_safe_cholesky(np.full((2, 2), np.nan))
