@@ -1,0 +1,106 @@
+/* volt_hip.h -- C ABI of libvolt_hip.so: Volt's exact-GP hot path on MI355X (gfx950).
+ *
+ * This is the operator-level boundary of SURVEY.md 8(b).  The reference has no native layer:
+ * its hot path is a sequence of ATen calls issued from Python (file:line under the g-benton/Volt
+ * tree).  Each entry point below names the reference call site(s) it replaces.  A maintainer binds
+ * them with ctypes (INTEGRATION.md shows the stub); volt_amd/_lib.py is that binding.
+ *
+ * Conventions (all entry points):
+ *   - Plain pointers and sizes only.  Every pointer except `stream` is a DEVICE pointer owned by the
+ *     caller (e.g. torch `tensor.data_ptr()`).  The library never allocates, frees or retains
+ *     caller-visible memory; scratch comes from the caller via the *_workspace_bytes queries.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); work is
+ *     enqueued asynchronously and the call returns immediately.  Re-entrant across streams; no
+ *     mutable global state.
+ *   - Return value: 0 = enqueued; -k = argument k (1-based) is invalid; >0 = hipError_t of a
+ *     failed launch.  A matrix that is not positive definite is NOT an error return: LAPACK-style
+ *     `info[b]` (0, or the 1-based index of the first non-positive / NaN pivot) is written to a
+ *     caller buffer and the jitter-retry policy (gpytorch psd_safe_cholesky, used at
+ *     voltron/rollout_utils.py:35,46) stays in the host wrapper.
+ *   - Matrices are row-major fp32 (the reference is fp32 throughout; voltron/means/EWMA.py:37 even
+ *     forces FloatTensor) or fp64 where a *_f64 twin exists.  `ld` = leading dimension in
+ *     elements, `bs` = batch stride in elements.
+ *   - "Working" matrices (A, Y) have dimension Np = volt_padded_n(N) (next multiple of 128); the
+ *     padding is an identity block written by volt_prepare_*, so it contributes nothing to
+ *     log-determinants, solves or traces.
+ */
+#ifndef VOLT_HIP_H
+#define VOLT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOLT_TILE 128
+
+/* ---- introspection ------------------------------------------------------------------------ */
+int volt_abi_version(void);                 /* bumps when a signature changes */
+int volt_padded_n(int n);                   /* next multiple of VOLT_TILE */
+
+/* ---- a1: CumTrapz  (voltron/kernels/VolKernel.py:4-10) -------------------------------------
+ * V[b,i] = sum_{m<=i} w_m * y[b,m],  w = dx with first and last halved, dx = x[b,1]-x[b,0].
+ * If `square` != 0, y = vol*vol is formed first, as VolatilityKernel.forward does (:28).
+ * Bit-exact with the reference's CPU path: products in fp32, running sum in fp64, every prefix
+ * rounded to fp32 (that is what torch.cumsum does on fp32 CPU tensors).
+ * vol [B,N] (batch stride bs_vol), x [N] shared (bs_x = 0) or [B,N]; V [B,N] contiguous. */
+int volt_cumtrapz_f32(const float* vol, int64_t bs_vol, const float* x, int64_t bs_x,
+                      float* V, int B, int N, int square, void* stream);
+int volt_cumtrapz_f64(const double* vol, int64_t bs_vol, const double* x, int64_t bs_x,
+                      double* V, int B, int N, int square, void* stream);
+
+/* ---- a2: VolatilityKernel.forward gather  (voltron/kernels/VolKernel.py:30-33) --------------
+ * K[b,i,j] = V[b, min(i,j)], full square, row-major.  Replaces arange/meshgrid/minimum (int64
+ * [N,N] index rebuilt on the CPU every call) + advanced-index gather.  HBM-write bound. */
+int volt_fill_f32(const float* V, float* K, int B, int N, int64_t ldk, int64_t bsk, void* stream);
+int volt_fill_f64(const double* V, double* K, int B, int N, int64_t ldk, int64_t bsk, void* stream);
+
+/* ---- a5: GaussianLikelihood "K + sigma^2 I"  (gpytorch, called from train_utils.py:249) ------
+ * A[b] = tril-tiles(K[b]) + sigma2[b] I, padded to Np with an identity block.  sigma2 may be NULL
+ * (adds nothing: rollouts factor raw K, rollout_utils.py:35) and `jitter` is added on top of it
+ * (psd_safe_cholesky retry).  A [B,Np,Np] with ld = Np. */
+int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter,
+                     float* A, int B, int N, void* stream);
+
+/* ---- a5/a6: batched Cholesky  (torch.linalg.cholesky via gpytorch; psd_safe_cholesky at
+ * rollout_utils.py:35, VoltronGP.py:83, VoltMagpie.py:87) ------------------------------------
+ * In-place lower Cholesky of A [B,Np,Np] (left-looking, 128-wide panels, fp32 MFMA updates).
+ * Winv [B, Np/128, 128, 128] receives the inverses of the diagonal blocks (used by the solves).
+ * info [B] int32.  Diagonal tiles come back with their strict upper triangle zeroed; tiles above
+ * the diagonal are never touched. */
+int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream);
+
+/* ---- a5/a6: triangular solves with one right-hand side  (torch.cholesky_solve at
+ * rollout_utils.py:36,44; gpytorch inv_quad) ------------------------------------------------
+ * rhs/out [B,Np] contiguous (pad with zeros).  `scratch` [B,Np] floats.  lower: out = L^-1 rhs;
+ * lower_t: out = L^-T rhs.  rhs and out may alias. */
+int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out,
+                        float* scratch, int B, int Np, void* stream);
+int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, float* out,
+                          float* scratch, int B, int Np, void* stream);
+
+/* ---- a5: triangular inverse for the noise gradient  (replaces autograd cholesky_backward) ---
+ * Y = L^-T (upper triangular, row-major [B,Np,Np]); tr(K_s^-1) = ||Y||_F^2. */
+int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream);
+
+/* ---- a5: MLL + gradient  (ExactMarginalLogLikelihood + loss.backward(), train_utils.py:249-250)
+ * One "step" of SURVEY 8(d) with K resident:
+ *     A = K + sigma2 I -> potrf -> Y = L^-T -> z = Y'r, alpha = Y z
+ *     out[b,0] = mll   = -1/2 (z'z + logdet + N log 2pi) / N
+ *     out[b,1] = d mll / d sigma2 = 1/2 (alpha'alpha - tr K_s^-1) / N
+ *     out[b,2] = z'z   out[b,3] = logdet   out[b,4] = tr K_s^-1   out[b,5] = alpha'alpha
+ *     alpha[b,:] (= K_s^-1 r;  d mll / d mean = alpha / N)
+ * resid [B,N] = y - mean(x).  If `want_grad` == 0 the triangular inverse is skipped (forward
+ * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written.
+ * workspace: volt_mll_workspace_bytes(B,N,want_grad) bytes, 256-byte aligned. */
+size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
+int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid,
+                      const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
+                      int* info, void* workspace, int B, int N, int want_grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLT_HIP_H */

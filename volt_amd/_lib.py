@@ -1,0 +1,67 @@
+"""ctypes binding of libvolt_hip.so (include/volt_hip.h).  No fallback: if the library is missing
+or a call fails, this raises -- the product path never routes around the HIP kernels."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- load torch's libamdhip64 first so the library binds the same HIP runtime
+
+from .build import LIB
+
+_lib = None
+ABI_VERSION = 1
+
+_i32, _i64, _f32, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+_SIGS = {
+    "volt_abi_version": (C.c_int, []),
+    "volt_padded_n": (C.c_int, [_i32]),
+    "volt_cumtrapz_f32": (C.c_int, [_ptr, _i64, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr]),
+    "volt_cumtrapz_f64": (C.c_int, [_ptr, _i64, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr]),
+    "volt_fill_f32": (C.c_int, [_ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    "volt_fill_f64": (C.c_int, [_ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    "volt_prepare_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _f32, _ptr, _i32, _i32, _ptr]),
+    "volt_potrf_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_trsv_lower_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_trsv_lower_t_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_trtri_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_mll_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "volt_mll_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class VoltHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and type the library.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            raise VoltHipError(
+                f"{LIB} not found: build it with `python -m volt_amd.build` (hipcc, gfx950). "
+                "volt_amd has no CPU fallback.")
+        handle = C.CDLL(LIB)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)           # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.volt_abi_version() != ABI_VERSION:
+            raise VoltHipError("libvolt_hip.so ABI version mismatch: rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise VoltHipError(f"{what}: invalid argument #{-rc}")
+    raise VoltHipError(f"{what}: HIP error {rc}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

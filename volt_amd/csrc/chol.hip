@@ -1,0 +1,460 @@
+// Batched blocked Cholesky, triangular solves and triangular inverse.
+//   reference call sites: gpytorch MVN.log_prob -> torch.linalg.cholesky (via train_utils.py:249),
+//   psd_safe_cholesky / torch.cholesky_solve at voltron/rollout_utils.py:35,36,44.
+//
+// Layout: A [B,Np,Np] row-major fp32, Np a multiple of 128, lower triangle referenced.  All
+// matrices of the batch advance in lockstep, one launch per stage; a launch's grid is
+// (tiles of the stage) x B so the batch supplies the parallelism a single 4096^2 factorisation
+// lacks in its late panels.
+//
+// Left-looking by 128-wide block columns k = 0..n-1:
+//   P1  panel update   A[i,k] -= sum_{m<k} L[i,m] L[k,m]^T   (i >= k)   fp32 MFMA, K = 128 k
+//   P2  diagonal block L[k,k] = chol(A[k,k]),  W_k = L[k,k]^-1          one workgroup / matrix, LDS
+//   P3  panel solve    L[i,k] = A[i,k] W_k^T                 (i >  k)   fp32 MFMA, K = 128
+// Left-looking keeps the accumulator of a panel tile in registers across the whole K range, so
+// each tile of L is written once (N^2/2 words) instead of read-modify-written n times as in a
+// right-looking sweep; HBM traffic is the operand reads, N^3/(6*128) words per matrix.
+#include "common.h"
+#include "../../include/volt_hip.h"
+
+namespace volt {
+
+// ----------------------------------------------------------------------------- prepare
+// A = tril-tiles(K) + (sigma2 + jitter) I, identity in the padding.  Tile (ti,tj), tj <= ti.
+__global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ K, int64_t ldk, int64_t bsk,
+                                                      const float* __restrict__ sigma2, float jitter,
+                                                      float* __restrict__ A, int N, int Np) {
+    const int n = Np / TS;
+    // linear lower-triangular tile index -> (ti, tj)
+    int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    (void)n;
+    const int b = blockIdx.y;
+    const float add = (sigma2 ? sigma2[b] : 0.f) + jitter;
+    const float* Kb = K + (int64_t)b * bsk;
+    float* Ab = A + (int64_t)b * Np * Np;
+    const int cq = (threadIdx.x & 31) * 4;
+    const int r0 = threadIdx.x >> 5;
+    const bool vec_ok = ((ldk & 3) == 0) && ((bsk & 3) == 0) && (((uintptr_t)K & 15) == 0);
+#pragma unroll 4
+    for (int rr = r0; rr < TS; rr += 8) {
+        const int i = ti * TS + rr;
+        const int j = tj * TS + cq;
+        f32x4 v;
+        if (i < N && j + 3 < N && vec_ok) {
+            v = *reinterpret_cast<const f32x4*>(Kb + (int64_t)i * ldk + j);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (i < N && j + c < N) ? Kb[(int64_t)i * ldk + j + c] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (i == j + c) v[c] = (i < N) ? v[c] + add : 1.f;
+        *reinterpret_cast<f32x4*>(Ab + (int64_t)i * Np + j) = v;
+    }
+}
+
+// ----------------------------------------------------------------------------- P1
+// grid.x = (n-k) * B.  Tile t: rows of block (k+t), columns of block k.
+__global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict__ A, int Np, int k, int B) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    int t, b;
+    decode_tile_batch(Np / TS - k, B, t, b);
+    float* Ab = A + (int64_t)b * Np * Np;
+    const float* Arows = Ab + (int64_t)(k + t) * TS * Np;   // L[k+t, 0:k]
+    const float* Brows = Ab + (int64_t)k * TS * Np;         // L[k,   0:k]
+    f32x16 acc[4];
+    zero_acc(acc);
+    gemm_nt_128<0>(Arows, Np, Brows, Np, k * (TS / BK), acc, smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    float* C = Ab + (int64_t)(k + t) * TS * Np + (int64_t)k * TS;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                const int c = wc * 64 + tn * 32 + (lane & 31);
+                float* p = C + (int64_t)r * Np + c;
+                *p = *p - acc[tm * 2 + tn][q];
+            }
+}
+
+// ----------------------------------------------------------------------------- P2
+// One workgroup per matrix: unblocked right-looking Cholesky of the 128x128 diagonal block in
+// LDS, then its inverse by forward substitution on the identity.  Serial by nature (128 dependent
+// pivots); only B workgroups are alive, which is why the batch runs in lockstep.
+constexpr int DLD = TS + 16;   // (16 i + c) mod 32 banks: conflict-free for the 2-row x 16-col half-waves
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                         int* __restrict__ info, int Np, int k) {
+    __shared__ float sL[TS * DLD];
+    __shared__ float sW[TS * DLD];
+    __shared__ float vec[TS];
+    const int b = blockIdx.x;
+    const int n = Np / TS;
+    float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
+    float* W = Winv + ((int64_t)b * n + k) * TS * TS;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    // load (coalesced float4), build identity in sW
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(D + (int64_t)r * Np + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sL[r * DLD + c + q] = v[q];
+            sW[r * DLD + c + q] = (r == c + q) ? 1.f : 0.f;
+        }
+    }
+    __syncthreads();
+    int bad = 0;
+    for (int j = 0; j < TS; ++j) {
+        const float d = sL[j * DLD + j];
+        if (!(d > 0.f) && bad == 0) bad = j + 1;           // non-positive or NaN pivot
+        const float piv = sqrtf(d);
+        const float rinv = 1.f / piv;
+        __syncthreads();                                     // everyone has read the pivot
+        if (tid < TS) {
+            if (tid > j) {
+                const float v = sL[tid * DLD + j] * rinv;
+                sL[tid * DLD + j] = v;
+                vec[tid] = v;
+            } else if (tid == j) {
+                sL[j * DLD + j] = piv;
+            }
+        }
+        __syncthreads();
+        for (int i = j + 1 + ty; i < TS; i += 16) {
+            const float li = vec[i];
+            for (int c = j + 1 + tx; c <= i; c += 16) sL[i * DLD + c] -= li * vec[c];
+        }
+        // next iteration's pivot read is ordered by the barrier below
+        __syncthreads();
+    }
+    // W = L^-1: rows of W become final top to bottom.
+    for (int j = 0; j < TS; ++j) {
+        const float rinv = 1.f / sL[j * DLD + j];
+        if (tid <= j) {
+            const float v = sW[j * DLD + tid] * rinv;
+            sW[j * DLD + tid] = v;
+            vec[tid] = v;
+        }
+        __syncthreads();
+        for (int i = j + 1 + ty; i < TS; i += 16) {
+            const float lij = sL[i * DLD + j];
+            for (int c = tx; c <= j; c += 16) sW[i * DLD + c] -= lij * vec[c];
+        }
+        __syncthreads();
+    }
+    // write back L (strict upper zeroed) and W
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        f32x4 l, w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            l[q] = (c + q <= r) ? sL[r * DLD + c + q] : 0.f;
+            w[q] = (c + q <= r) ? sW[r * DLD + c + q] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(D + (int64_t)r * Np + c) = l;
+        *reinterpret_cast<f32x4*>(W + r * TS + c) = w;
+    }
+    if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
+}
+
+// ----------------------------------------------------------------------------- P3
+// grid.x = (n-k-1) * B.  L[i,k] = A[i,k] * W_k^T, in place (the tile is fully staged through LDS
+// before the epilogue stores).
+__global__ __launch_bounds__(256, 2) void potrf_trsm_kernel(float* __restrict__ A, const float* __restrict__ Winv,
+                                                           int Np, int k, int B) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    const int n = Np / TS;
+    int t, b;
+    decode_tile_batch(n - k - 1, B, t, b);
+    float* P = A + (int64_t)b * Np * Np + (int64_t)(k + 1 + t) * TS * Np + (int64_t)k * TS;
+    const float* W = Winv + ((int64_t)b * n + k) * TS * TS;
+    f32x16 acc[4];
+    zero_acc(acc);
+    gemm_nt_128<0>(P, Np, W, TS, TS / BK, acc, smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                const int c = wc * 64 + tn * 32 + (lane & 31);
+                P[(int64_t)r * Np + c] = acc[tm * 2 + tn][q];
+            }
+}
+
+// ----------------------------------------------------------------------------- trsv steps
+// 128x128 tile times vector helpers: the tile is staged in LDS with coalesced float4 loads.
+constexpr int VLD = TS + 1;
+
+__device__ __forceinline__ void load_tile_lds(const float* __restrict__ T, int64_t ld, float* s) {
+    for (int e = threadIdx.x; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(T + (int64_t)r * ld + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[r * VLD + c + q] = v[q];
+    }
+}
+
+// Forward step i: z_i = W_i racc_i ; racc[rows of block i+t] -= L[i+t, i] z_i  (t >= 1).
+// grid.x = (n-i) * B; every workgroup recomputes z_i (64 KB of W_i out of L2) so no workgroup
+// waits on another inside the launch.
+__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const float* __restrict__ A, const float* __restrict__ Winv,
+                                                            float* __restrict__ racc, float* __restrict__ z, int Np,
+                                                            int i, int B) {
+    __shared__ float s[TS * VLD];
+    __shared__ float v[TS], zi[TS];
+    const int n = Np / TS;
+    int t, b;
+    decode_tile_batch(n - i, B, t, b);
+    const float* Ab = A + (int64_t)b * Np * Np;
+    float* rb = racc + (int64_t)b * Np;
+    const int tid = threadIdx.x;
+    load_tile_lds(Winv + ((int64_t)b * n + i) * TS * TS, TS, s);
+    if (tid < TS) v[tid] = rb[i * TS + tid];
+    __syncthreads();
+    if (tid < TS) {
+        float a = 0.f;
+        for (int p = 0; p <= tid; ++p) a += s[tid * VLD + p] * v[p];
+        zi[tid] = a;
+        if (t == 0) z[(int64_t)b * Np + i * TS + tid] = a;
+    }
+    __syncthreads();
+    if (t == 0) return;
+    load_tile_lds(Ab + (int64_t)(i + t) * TS * Np + (int64_t)i * TS, Np, s);
+    __syncthreads();
+    if (tid < TS) {
+        float a = 0.f;
+        for (int p = 0; p < TS; ++p) a += s[tid * VLD + p] * zi[p];
+        rb[(i + t) * TS + tid] -= a;
+    }
+}
+
+// Backward step i (i = n-1 .. 0): a_i = W_i^T zacc_i ; zacc[block t] -= L[i,t]^T a_i  (t < i).
+// grid.x = (i+1) * B; tile index t == i is the one that writes a_i.
+__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const float* __restrict__ A, const float* __restrict__ Winv,
+                                                            float* __restrict__ zacc, float* __restrict__ out, int Np,
+                                                            int i, int B) {
+    __shared__ float s[TS * VLD];
+    __shared__ float v[TS], ai[TS];
+    const int n = Np / TS;
+    int t, b;
+    decode_tile_batch(i + 1, B, t, b);
+    const float* Ab = A + (int64_t)b * Np * Np;
+    float* zb = zacc + (int64_t)b * Np;
+    const int tid = threadIdx.x;
+    load_tile_lds(Winv + ((int64_t)b * n + i) * TS * TS, TS, s);
+    if (tid < TS) v[tid] = zb[i * TS + tid];
+    __syncthreads();
+    if (tid < TS) {
+        float a = 0.f;
+        for (int p = tid; p < TS; ++p) a += s[p * VLD + tid] * v[p];   // W^T: column tid
+        ai[tid] = a;
+        if (t == i) out[(int64_t)b * Np + i * TS + tid] = a;
+    }
+    __syncthreads();
+    if (t == i) return;
+    load_tile_lds(Ab + (int64_t)i * TS * Np + (int64_t)t * TS, Np, s);
+    __syncthreads();
+    if (tid < TS) {
+        float a = 0.f;
+        for (int p = 0; p < TS; ++p) a += s[p * VLD + tid] * ai[p];
+        zb[t * TS + tid] -= a;
+    }
+}
+
+// ----------------------------------------------------------------------------- trtri
+// Y = L^-T (upper, row-major).  Block row i of X = L^-1 is block column i of Y:
+//     X[i,j] = -W_i * T ,  T = sum_{m=j}^{i-1} L[i,m] X[m,j]      (j < i),     X[i,i] = W_i
+// Phase 1 (MFMA, K = 128 (i-j)):  T[r][c] = sum_m L[i-rows r, m] * Y[j-rows c, m]   -- both K-contiguous.
+// Phase 2 (MFMA, K = 128):        Y[j-rows c, i-cols r] = - sum_p T[p][c] * W_i[r][p]
+//   With the 1x4 wave layout a wave holds all 128 p for its 32 columns c, and the accumulator
+//   layout of T (lane = c, registers = p) is exactly the A-operand layout of phase 2, so T never
+//   leaves the register file; W_i is staged once in LDS.
+// grid.x = (i+1) * B (tile j = 0..i; j == i copies W_i^T).
+constexpr int WLD = TS + 4;    // 132-float rows: b128 reads of 16 rows land on 16 distinct slots
+
+__global__ __launch_bounds__(256) void trtri_row_kernel(const float* __restrict__ A, const float* __restrict__ Winv,
+                                                        float* __restrict__ Y, int Np, int i, int B) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];   // 73,728 B >= 128*132*4
+    const int n = Np / TS;
+    int j, b;
+    decode_tile_batch(i + 1, B, j, b);
+    const float* Ab = A + (int64_t)b * Np * Np;
+    float* Yb = Y + (int64_t)b * Np * Np;
+    const float* W = Winv + ((int64_t)b * n + i) * TS * TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    if (j == i) {
+        // diagonal tile: Y[i,i] = W_i^T (transposed through LDS so both sides stay coalesced)
+        for (int e = tid; e < TS * TS / 4; e += NT) {
+            const int r = e >> 5, c = (e & 31) * 4;
+            *reinterpret_cast<f32x4*>(smem + r * WLD + c) = *reinterpret_cast<const f32x4*>(W + r * TS + c);
+        }
+        __syncthreads();
+        float* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
+        for (int e = tid; e < TS * TS; e += NT) {
+            const int c = e >> 7, r = e & 127;          // Y row c, column r
+            Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
+        }
+        return;
+    }
+
+    // phase 1 uses the whole staging area; W_i is staged into the same LDS afterwards (the two do
+    // not fit side by side at 2 workgroups per CU).
+    f32x16 T[4];
+    zero_acc(T);
+    {
+        const float* Lrows = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;   // L[i, j*128 ...]
+        const float* Yrows = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;   // Y[j, j*128 ...]
+        gemm_nt_128<1>(Lrows, Np, Yrows, Np, (i - j) * (TS / BK), T, smem);
+    }
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        *reinterpret_cast<f32x4*>(smem + r * WLD + c) = *reinterpret_cast<const f32x4*>(W + r * TS + c);
+    }
+    __syncthreads();
+
+    // phase 2: out[c][r] for c in this wave's 32 columns, r in 4 blocks of 32.
+    f32x16 O[4];
+    zero_acc(O);
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {          // 32-row block of p held in T[tp]
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {         // registers 4g..4g+3 <-> p = tp*32 + 8g + 4*lh + (0..3)
+            const int p0 = tp * 32 + 8 * g + 4 * lh;
+            f32x4 w[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+                w[rb] = *reinterpret_cast<const f32x4*>(smem + (rb * 32 + l31) * WLD + p0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float a = T[tp][4 * g + m];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb)
+                    O[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[rb][m], O[rb], 0, 0, 0);
+            }
+        }
+    }
+    // O[rb] element (row = c_local, col = r_local): lane&31 = r, registers = c.
+    float* Yt = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = wave * 32 + accrow(q, lane);
+            const int r = rb * 32 + l31;
+            Yt[(int64_t)c * Np + r] = -O[rb][q];
+        }
+}
+
+}  // namespace volt
+
+using namespace volt;
+
+extern "C" {
+
+int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, int B,
+                     int N, void* stream) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!A) return -6;
+    if (B < 0) return -7;
+    if (N < 1) return -8;
+    if (B == 0) return 0;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    hipLaunchKernelGGL(prepare_kernel, dim3(n * (n + 1) / 2, B), dim3(256), 0, (hipStream_t)stream, K, ldk, bsk,
+                       sigma2, jitter, A, N, Np);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!info) return -3;
+    if (B < 0) return -4;
+    if (Np < TS || Np % TS) return -5;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = Np / TS;
+    hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < n; ++k) {
+        if (k > 0) hipLaunchKernelGGL(potrf_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(256), 0, s, A, Winv, info, Np, k);
+        if (k + 1 < n) hipLaunchKernelGGL(potrf_trsm_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+    }
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out, float* scratch, int B,
+                        int Np, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!rhs) return -3;
+    if (!out) return -4;
+    if (!scratch) return -5;
+    if (B < 0) return -6;
+    if (Np < TS || Np % TS) return -7;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = Np / TS;
+    hipError_t e = hipMemcpyAsync(scratch, rhs, sizeof(float) * (size_t)B * Np, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    for (int i = 0; i < n; ++i)
+        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3((n - i) * B), dim3(256), 0, s, A, Winv, scratch, out, Np, i, B);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, float* out, float* scratch, int B,
+                          int Np, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!rhs) return -3;
+    if (!out) return -4;
+    if (!scratch) return -5;
+    if (B < 0) return -6;
+    if (Np < TS || Np % TS) return -7;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = Np / TS;
+    hipError_t e = hipMemcpyAsync(scratch, rhs, sizeof(float) * (size_t)B * Np, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    for (int i = n - 1; i >= 0; --i)
+        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3((i + 1) * B), dim3(256), 0, s, A, Winv, scratch, out, Np, i, B);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!Y) return -3;
+    if (B < 0) return -4;
+    if (Np < TS || Np % TS) return -5;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = Np / TS;
+    for (int i = 0; i < n; ++i)
+        hipLaunchKernelGGL(trtri_row_kernel, dim3((i + 1) * B), dim3(256), 0, s, A, Winv, Y, Np, i, B);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// Shared device code for libvolt_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define VOLT_ABI_VERSION 1
+
+namespace volt {
+
+constexpr int TS = 128;        // tile edge of every blocked algorithm here
+constexpr int BK = 32;         // K-chunk staged through LDS per pipeline step
+constexpr int SLD = BK + 4;    // LDS row stride (floats): 144 B rows keep ds_read_b128 conflict-free
+constexpr int NT = 256;        // threads per workgroup (4 wave64)
+constexpr int STAGE_FLOATS = 2 * TS * SLD;             // one A tile + one B tile
+constexpr int GEMM_LDS_BYTES = 2 * STAGE_FLOATS * 4;   // double buffered: 73,728 B -> 2 WG / CU
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VOLT_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+// Row of a 32x32 MFMA accumulator element: reg q of lane l sits at (row, col) = (accrow(q,l), l&31).
+__device__ __forceinline__ int accrow(int q, int lane) { return (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5); }
+
+// XCD-aware decode of a 1-D grid into (tile, batch).  The dispatcher places workgroup w on XCD
+// w % 8 (observed, used for speed only): give every XCD whole matrices so the operand a panel's
+// tiles share (the k-th block row, or a diagonal inverse) is fetched into one L2, not eight.
+__device__ __forceinline__ void decode_tile_batch(int ntiles, int nbatch, int& tile, int& batch) {
+    const int w = blockIdx.x;
+    if ((nbatch & 7) == 0) {
+        const int xcd = w & 7, slot = w >> 3;
+        batch = (slot / ntiles) * 8 + xcd;
+        tile = slot % ntiles;
+    } else {
+        batch = w / ntiles;
+        tile = w % ntiles;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128x128 (x K) "NT" GEMM core on fp32 MFMA:  acc[r][c] += sum_k Arows[r][k] * Brows[c][k]
+// Both operands are row-major with K contiguous (rows of L / Y / W), which is the only product
+// shape the blocked Cholesky, the TRSM-by-inverse and the triangular inverse need.
+//
+// WL = 0: waves in a 2x2 grid, each owning 64x64 = acc[tm*2+tn] (32x32 sub-tiles).
+// WL = 1: waves side by side, wave w owning all 128 rows x 32 columns [32w,32w+32) = acc[tm].
+//
+// Pipeline: register-staged prefetch of chunk c+1 (8 x global_load_dwordx4 per thread) is issued
+// before the 64 MFMAs of chunk c and written to the other LDS buffer after them; one barrier per
+// chunk.  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads (lane = row) hit 16
+// distinct 16-byte slots per lane group.  Each b128 read feeds four v_mfma_f32_32x32x2_f32: lane
+// halves take k = 4*(lane>>5)+m, consistently for A and B, so the sum over k is complete.
+// ---------------------------------------------------------------------------------------------
+struct StageRegs {
+    f32x4 a[4], b[4];
+};
+
+__device__ __forceinline__ void stage_load(StageRegs& s, const float* __restrict__ A, int64_t lda,
+                                           const float* __restrict__ B, int64_t ldb, int k0) {
+    const int t = threadIdx.x;
+    const int row = t >> 3, cq = (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        s.a[p] = *reinterpret_cast<const f32x4*>(A + (int64_t)(row + 32 * p) * lda + k0 + cq);
+        s.b[p] = *reinterpret_cast<const f32x4*>(B + (int64_t)(row + 32 * p) * ldb + k0 + cq);
+    }
+}
+
+__device__ __forceinline__ void stage_store(const StageRegs& s, float* __restrict__ buf) {
+    const int t = threadIdx.x;
+    const int row = t >> 3, cq = (t & 7) * 4;
+    float* sA = buf;
+    float* sB = buf + TS * SLD;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<f32x4*>(sA + (row + 32 * p) * SLD + cq) = s.a[p];
+        *reinterpret_cast<f32x4*>(sB + (row + 32 * p) * SLD + cq) = s.b[p];
+    }
+}
+
+template <int WL>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ buf, f32x16 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* sA = buf;
+    const float* sB = buf + TS * SLD;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+        const int ko = kk * 8 + 4 * lh;
+        if (WL == 0) {
+            const int wr = wave >> 1, wc = wave & 1;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sA + (wr * 64 + l31) * SLD + ko);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sA + (wr * 64 + 32 + l31) * SLD + ko);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB + (wc * 64 + l31) * SLD + ko);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB + (wc * 64 + 32 + l31) * SLD + ko);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b1[m], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b0[m], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m], acc[3], 0, 0, 0);
+            }
+        } else {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB + (wave * 32 + l31) * SLD + ko);
+            f32x4 a[4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+                a[tm] = *reinterpret_cast<const f32x4*>(sA + (tm * 32 + l31) * SLD + ko);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][m], b0[m], acc[tm], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// acc += A[0:128, 0:32*nchunks] * B[0:128, 0:32*nchunks]^T ; smem = GEMM_LDS_BYTES, 16-B aligned.
+// Ends with a barrier: smem is free for reuse on return.
+template <int WL>
+__device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t lda,
+                                            const float* __restrict__ B, int64_t ldb, int nchunks,
+                                            f32x16 (&acc)[4], float* smem) {
+    if (nchunks <= 0) return;
+    StageRegs s;
+    stage_load(s, A, lda, B, ldb, 0);
+    stage_store(s, smem);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        float* cur = smem + (c & 1) * STAGE_FLOATS;
+        float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
+        const bool more = (c + 1 < nchunks);
+        if (more) stage_load(s, A, lda, B, ldb, (c + 1) * BK);
+        mma_chunk<WL>(cur, acc);
+        if (more) stage_store(s, nxt);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+}
+
+}  // namespace volt

@@ -1,0 +1,241 @@
+// Marginal log likelihood + analytic gradient.
+//   reference: loss = -mll(model(x), y); loss.backward()  -- voltron/train_utils.py:243-250,
+//   :130-139, voltron/models/Volt.py:133-146; arithmetic in gpytorch ExactMarginalLogLikelihood.
+// All O(N^2) passes here are HBM-bound streams over Y = L^-T (upper triangle only).
+#include "common.h"
+#include "../../include/volt_hip.h"
+#include <math.h>
+
+namespace volt {
+
+constexpr int VLD2 = TS + 1;
+
+__global__ void pad_resid_kernel(const float* __restrict__ resid, float* __restrict__ rpad, int N, int Np) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Np) rpad[(int64_t)b * Np + i] = (i < N) ? resid[(int64_t)b * N + i] : 0.f;
+}
+
+__device__ __forceinline__ void upper_tile(int t, int& jb, int& cb) {
+    // t enumerates (cb, jb <= cb) like a lower-triangular index with roles swapped
+    int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    cb = ti;
+    jb = t - ti * (ti + 1) / 2;
+}
+
+// R1: per upper tile (jb <= cb):  zpart[b][jb][cb*128 + c] = sum_r Y[jb*128+r][cb*128+c] * rvec[jb*128+r]
+//     frob[b][t] = sum over rows < N of Y^2.   Deterministic (no atomics).
+__global__ __launch_bounds__(256) void reduce_yt_r_kernel(const float* __restrict__ Y, const float* __restrict__ rpad,
+                                                          float* __restrict__ zpart, float* __restrict__ frob, int N,
+                                                          int Np) {
+    __shared__ float sz[256];
+    __shared__ float sf[256];
+    const int n = Np / TS;
+    const int t = blockIdx.x, b = blockIdx.y;
+    int jb, cb;
+    upper_tile(t, jb, cb);
+    const float* Yt = Y + (int64_t)b * Np * Np + (int64_t)jb * TS * Np + (int64_t)cb * TS;
+    const float* rv = rpad + (int64_t)b * Np + jb * TS;
+    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
+    float az = 0.f, af = 0.f;
+#pragma unroll 8
+    for (int r = half * 64; r < half * 64 + 64; ++r) {
+        const float y = Yt[(int64_t)r * Np + c];
+        az += y * rv[r];
+        if (jb * TS + r < N) af += y * y;
+    }
+    sz[threadIdx.x] = az;
+    sf[threadIdx.x] = af;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        zpart[((int64_t)b * n + jb) * Np + cb * TS + c] = sz[threadIdx.x] + sz[threadIdx.x + 128];
+        sf[threadIdx.x] += sf[threadIdx.x + 128];
+    }
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sf[threadIdx.x] += sf[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) frob[(int64_t)b * (n * (n + 1) / 2) + t] = sf[0];
+}
+
+// R2: z[c] = sum_{jb <= cb} zpart[jb][c]
+__global__ void sum_zpart_kernel(const float* __restrict__ zpart, float* __restrict__ z, int Np) {
+    const int n = Np / TS;
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Np) return;
+    const int cb = c / TS;
+    float a = 0.f;
+    for (int jb = 0; jb <= cb; ++jb) a += zpart[((int64_t)b * n + jb) * Np + c];
+    z[(int64_t)b * Np + c] = a;
+}
+
+// R3: alpha[jb rows] = sum_{cb >= jb} Y[jb, cb] z[cb]   (one workgroup per block row)
+__global__ __launch_bounds__(256) void y_times_z_kernel(const float* __restrict__ Y, const float* __restrict__ z,
+                                                        float* __restrict__ alpha, int Np, int B) {
+    __shared__ float s[TS * VLD2];
+    __shared__ float zv[TS];
+    const int n = Np / TS;
+    int jb, b;
+    decode_tile_batch(n, B, jb, b);
+    const float* Yb = Y + (int64_t)b * Np * Np + (int64_t)jb * TS * Np;
+    const int tid = threadIdx.x;
+    float a = 0.f;
+    for (int cb = jb; cb < n; ++cb) {
+        __syncthreads();
+        for (int e = tid; e < TS * TS / 4; e += NT) {
+            const int r = e >> 5, c = (e & 31) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Yb + (int64_t)r * Np + cb * TS + c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s[r * VLD2 + c + q] = v[q];
+        }
+        if (tid < TS) zv[tid] = z[(int64_t)b * Np + cb * TS + tid];
+        __syncthreads();
+        if (tid < TS) {
+            // diagonal tile is upper triangular: start at the diagonal
+            const int p0 = (cb == jb) ? tid : 0;
+            for (int p = p0; p < TS; ++p) a += s[tid * VLD2 + p] * zv[p];
+        }
+    }
+    if (tid < TS) alpha[(int64_t)b * Np + jb * TS + tid] = a;
+}
+
+// R4: scalars.  out[b, 0..7] = mll, dmll/dsigma2, quad, logdet, trinv, aa, sigma2-used, 0
+__global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restrict__ A, const float* __restrict__ z,
+                                                          const float* __restrict__ alpha_pad,
+                                                          const float* __restrict__ frob, const float* __restrict__ sigma2,
+                                                          float jitter, float* __restrict__ out,
+                                                          float* __restrict__ alpha_out, int N, int Np, int want_grad) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = Np / TS;
+    const float* Ab = A + (int64_t)b * Np * Np;
+    auto block_sum = [&](double v) -> double {
+        red[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double q = 0, ld = 0, aa = 0, tr = 0;
+    for (int i = tid; i < N; i += 256) {
+        const double zi = z[(int64_t)b * Np + i];
+        q += zi * zi;
+        ld += log((double)Ab[(int64_t)i * Np + i]);
+        if (want_grad) {
+            const float al = alpha_pad[(int64_t)b * Np + i];
+            aa += (double)al * al;
+            alpha_out[(int64_t)b * N + i] = al;
+        }
+    }
+    if (want_grad) {
+        const int nt = n * (n + 1) / 2;
+        for (int i = tid; i < nt; i += 256) tr += frob[(int64_t)b * nt + i];
+    }
+    q = block_sum(q);
+    ld = 2.0 * block_sum(ld);
+    aa = block_sum(aa);
+    tr = block_sum(tr);
+    if (tid == 0) {
+        const double LOG_2PI = 1.8378770664093453;
+        float* o = out + (int64_t)b * 8;
+        o[0] = (float)(-0.5 * (q + ld + N * LOG_2PI) / N);
+        o[2] = (float)q;
+        o[3] = (float)ld;
+        o[6] = (sigma2 ? sigma2[b] : 0.f) + jitter;
+        o[7] = 0.f;
+        if (want_grad) {
+            o[1] = (float)(0.5 * (aa - tr) / N);
+            o[4] = (float)tr;
+            o[5] = (float)aa;
+        }
+    }
+}
+
+struct MllWs {
+    float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob;
+    size_t bytes;
+};
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static MllWs carve(void* base, int B, int N, int want_grad) {
+    const size_t Np = (size_t)volt_padded_n(N), n = Np / TS;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += al256(floats * sizeof(float));
+        return p;
+    };
+    MllWs w;
+    w.A = take((size_t)B * Np * Np);
+    w.Winv = take((size_t)B * n * TS * TS);
+    w.rpad = take((size_t)B * Np);
+    w.z = take((size_t)B * Np);
+    w.scratch = take((size_t)B * Np);
+    w.apad = take((size_t)B * Np);
+    if (want_grad) {
+        w.Y = take((size_t)B * Np * Np);
+        w.zpart = take((size_t)B * n * Np);
+        w.frob = take((size_t)B * (n * (n + 1) / 2));
+    } else {
+        w.Y = w.zpart = w.frob = nullptr;
+    }
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace volt
+
+using namespace volt;
+
+extern "C" {
+
+size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {
+    if (B <= 0 || N <= 0) return 0;
+    return carve(nullptr, B, N, want_grad).bytes;
+}
+
+int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2, float jitter,
+                      float* out, float* alpha, int* info, void* workspace, int B, int N, int want_grad,
+                      void* stream) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!resid) return -4;
+    if (!out) return -7;
+    if (want_grad && !alpha) return -8;
+    if (!info) return -9;
+    if (!workspace || ((uintptr_t)workspace & 255)) return -10;
+    if (B < 0) return -11;
+    if (N < 1) return -12;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    MllWs w = carve(workspace, B, N, want_grad);
+    int rc;
+    hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
+    if ((rc = volt_prepare_f32(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
+    if ((rc = volt_potrf_f32(w.A, w.Winv, info, B, Np, stream))) return rc > 0 ? rc : -1;
+    if (want_grad) {
+        if ((rc = volt_trtri_f32(w.A, w.Winv, w.Y, B, Np, stream))) return rc > 0 ? rc : -1;
+        hipLaunchKernelGGL(reduce_yt_r_kernel, dim3(n * (n + 1) / 2, B), dim3(256), 0, s, w.Y, w.rpad, w.zpart, w.frob,
+                           N, Np);
+        hipLaunchKernelGGL(sum_zpart_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, w.zpart, w.z, Np);
+        hipLaunchKernelGGL(y_times_z_kernel, dim3(n * B), dim3(256), 0, s, w.Y, w.z, w.apad, Np, B);
+    } else {
+        if ((rc = volt_trsv_lower_f32(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
+    }
+    hipLaunchKernelGGL(mll_scalars_kernel, dim3(B), dim3(256), 0, s, w.A, w.z, w.apad, w.frob, sigma2, jitter, out,
+                       alpha, N, Np, want_grad);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

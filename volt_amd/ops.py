@@ -1,0 +1,159 @@
+"""Tensor-level wrappers over the C ABI (device pointers in, torch tensors out).
+
+Everything here requires CUDA(HIP) tensors; there is deliberately no CPU path.  PyTorch is used
+for device memory and streams only.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+TILE = 128
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VoltHipError(
+                "volt_amd ops need tensors on the MI355X (got a CPU tensor); there is no CPU fallback")
+
+
+def padded_n(n: int) -> int:
+    return (n + TILE - 1) // TILE * TILE
+
+
+def cumtrapz(y: torch.Tensor, x: torch.Tensor, square: bool = False) -> torch.Tensor:
+    """CumTrapz (voltron/kernels/VolKernel.py:4-10).  y [..., N]; x [N] or y-shaped."""
+    _need_gpu(y, x)
+    if y.dtype not in (torch.float32, torch.float64):
+        y = y.float()
+    x = x.to(y.dtype)
+    n = y.shape[-1]
+    if x.shape[-1] != n:
+        raise ValueError("x and y disagree on N")
+    yb = y.reshape(-1, n).contiguous()
+    B = yb.shape[0]
+    if x.ndim == 1:
+        xb, bsx = x.contiguous(), 0
+    else:
+        xb = x.expand(y.shape).reshape(-1, n).contiguous()
+        bsx = n
+    V = torch.empty_like(yb)
+    fn = _lib.lib().volt_cumtrapz_f32 if y.dtype == torch.float32 else _lib.lib().volt_cumtrapz_f64
+    _lib.check(fn(yb.data_ptr(), n, xb.data_ptr(), bsx, V.data_ptr(), B, n, int(square), _lib.stream_ptr()),
+               "volt_cumtrapz")
+    return V.reshape(y.shape)
+
+
+def fill(V: torch.Tensor) -> torch.Tensor:
+    """K[..., i, j] = V[..., min(i, j)] (voltron/kernels/VolKernel.py:30-33)."""
+    _need_gpu(V)
+    n = V.shape[-1]
+    Vb = V.reshape(-1, n).contiguous()
+    B = Vb.shape[0]
+    K = torch.empty(B, n, n, dtype=V.dtype, device=V.device)
+    fn = _lib.lib().volt_fill_f32 if V.dtype == torch.float32 else _lib.lib().volt_fill_f64
+    _lib.check(fn(Vb.data_ptr(), K.data_ptr(), B, n, n, n * n, _lib.stream_ptr()), "volt_fill")
+    return K.reshape(*V.shape[:-1], n, n)
+
+
+class CholeskyFactor:
+    """Result of `potrf`: padded factor A [B,Np,Np] (lower), inverse diagonal blocks, info [B]."""
+
+    def __init__(self, A, Winv, info, n):
+        self.A, self.Winv, self.info, self.n = A, Winv, info, n
+
+    @property
+    def L(self) -> torch.Tensor:
+        return torch.tril(self.A[:, : self.n, : self.n])
+
+
+def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0.0) -> CholeskyFactor:
+    """Batched Cholesky of K + (sigma2 + jitter) I.  K [B,N,N] fp32 (only the lower triangle is read)."""
+    _need_gpu(K, sigma2)
+    if K.dtype != torch.float32 or K.ndim != 3:
+        raise ValueError("potrf expects a [B,N,N] fp32 tensor")
+    if K.stride(-1) != 1:
+        K = K.contiguous()
+    B, n, _ = K.shape
+    Np = padded_n(n)
+    A = torch.empty(B, Np, Np, dtype=torch.float32, device=K.device)
+    Winv = torch.empty(B, Np // TILE, TILE, TILE, dtype=torch.float32, device=K.device)
+    info = torch.empty(B, dtype=torch.int32, device=K.device)
+    s2 = None
+    if sigma2 is not None:
+        s2 = sigma2.to(torch.float32).expand(B).contiguous()
+    L = _lib.lib()
+    st = _lib.stream_ptr()
+    _lib.check(L.volt_prepare_f32(K.data_ptr(), K.stride(1), K.stride(0), s2.data_ptr() if s2 is not None else None,
+                                  float(jitter), A.data_ptr(), B, n, st), "volt_prepare")
+    _lib.check(L.volt_potrf_f32(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
+    return CholeskyFactor(A, Winv, info, n)
+
+
+def _pad_rhs(f: CholeskyFactor, rhs: torch.Tensor) -> torch.Tensor:
+    B, Np = f.A.shape[0], f.A.shape[1]
+    out = torch.zeros(B, Np, dtype=torch.float32, device=f.A.device)
+    out[:, : f.n] = rhs.reshape(B, f.n)
+    return out
+
+
+def trsv(f: CholeskyFactor, rhs: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """L^-1 rhs (or L^-T rhs).  rhs [B,N] -> [B,N]."""
+    _need_gpu(rhs)
+    r = _pad_rhs(f, rhs)
+    out = torch.empty_like(r)
+    scratch = torch.empty_like(r)
+    B, Np = r.shape
+    fn = _lib.lib().volt_trsv_lower_t_f32 if transpose else _lib.lib().volt_trsv_lower_f32
+    _lib.check(fn(f.A.data_ptr(), f.Winv.data_ptr(), r.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, Np,
+                  _lib.stream_ptr()), "volt_trsv")
+    return out[:, : f.n]
+
+
+def cholesky_solve(f: CholeskyFactor, rhs: torch.Tensor) -> torch.Tensor:
+    """(L L^T)^-1 rhs for one right-hand side per matrix (torch.cholesky_solve, rollout_utils.py:36)."""
+    return trsv(f, trsv(f, rhs), transpose=True)
+
+
+def trtri(f: CholeskyFactor) -> torch.Tensor:
+    """Y = L^-T as an upper-triangular [B,N,N] tensor."""
+    B, Np = f.A.shape[0], f.A.shape[1]
+    Y = torch.empty(B, Np, Np, dtype=torch.float32, device=f.A.device)
+    _lib.check(_lib.lib().volt_trtri_f32(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()),
+               "volt_trtri")
+    return torch.triu(Y[:, : f.n, : f.n])
+
+
+class MllWorkspace:
+    """Caller-owned scratch for volt_mll_step_f32, reusable across steps of the same (B,N)."""
+
+    def __init__(self, B: int, N: int, want_grad: bool, device):
+        self.B, self.N, self.want_grad = B, N, bool(want_grad)
+        nbytes = _lib.lib().volt_mll_workspace_bytes(B, N, int(want_grad))
+        self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        self.ptr = (self.buf.data_ptr() + 255) // 256 * 256
+        self.out = torch.empty(B, 8, dtype=torch.float32, device=device)
+        self.alpha = torch.empty(B, N, dtype=torch.float32, device=device)
+        self.info = torch.empty(B, dtype=torch.int32, device=device)
+
+
+def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: MllWorkspace | None = None,
+             want_grad: bool = True, jitter: float = 0.0):
+    """One MLL(+grad) evaluation with K resident.  Returns (out [B,8], alpha [B,N], info [B]); see
+    include/volt_hip.h for the meaning of out's columns."""
+    _need_gpu(K, resid, sigma2)
+    if K.ndim != 3 or K.dtype != torch.float32:
+        raise ValueError("K must be [B,N,N] fp32")
+    B, n, _ = K.shape
+    if K.stride(-1) != 1:
+        K = K.contiguous()
+    resid = resid.reshape(B, n).to(torch.float32).contiguous()
+    s2 = sigma2.to(torch.float32).expand(B).contiguous()
+    if ws is None or ws.B != B or ws.N != n or ws.want_grad != bool(want_grad):
+        ws = MllWorkspace(B, n, want_grad, K.device)
+    _lib.check(_lib.lib().volt_mll_step_f32(K.data_ptr(), K.stride(1), K.stride(0), resid.data_ptr(), s2.data_ptr(),
+                                            float(jitter), ws.out.data_ptr(), ws.alpha.data_ptr(), ws.info.data_ptr(),
+                                            ws.ptr, B, n, int(want_grad), _lib.stream_ptr()), "volt_mll_step")
+    return ws.out, ws.alpha, ws.info
