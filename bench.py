@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- MLL+grad steps/s at N=4096, batch=64 per GPU (BASELINE.json metric), MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+
+A *step* is one pass of the training-loop body of voltron/train_utils.py:243-254 over a batch of
+independent series with K (train_cov) already resident: residual y - EWMA mean -> K + sigma^2 I
+-> blocked Cholesky -> L^-T -> MLL and its gradient wrt raw_noise -> Adam update of raw_noise ->
+(N>1) one RCCL all-reduce of the summed loss/grad scalars.  Series shard across ranks (weak
+scaling: 64 series per GPU), no data-path collective.
+
+Rank 0 prints ONE JSON line.  `value` = batch-of-64 steps per second summed over ranks, inputs
+resident in HBM.  `roofline` is for the dominant kernel (per-launch HIP events, live);
+`cpu_baseline` times the torch-CPU restatement of the gpytorch path on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_SERIES = 4096          # BASELINE.json metric: N = 4096
+BATCH = 64               # series per GPU
+EWMA_K = 25              # VoltMagpie default k (voltron/models/VoltMagpie.py:17)
+FP32_MFMA_PEAK_TF = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def kernel_class_flops(B: int, Np: int):
+    """Algorithmic flops of each kernel class over one factorisation (+ inverse) of B matrices."""
+    n, t3 = Np // 128, 2.0 * 128 ** 3
+    upd = sum((n - k) * k for k in range(1, n)) * t3            # P1: (n-k) tiles x K = 128 k
+    diag = n * (128 ** 3 / 3 + 128 ** 3 / 3)                     # P2: potrf + trtri of a 128 block
+    trsm = sum(n - k - 1 for k in range(n)) * t3 * 0.5           # P3: triangular W -> half the MACs count
+    tri = sum((i - j) + 0.5 for i in range(n) for j in range(i)) * t3   # phase 1 + triangular phase 2
+    return [B * upd, B * diag, B * trsm, B * tri]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=N_SERIES)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from volt_amd import _lib, ops
+    from volt_amd.synthetic import sde_batch
+
+    n, B = args.n, args.batch
+    x, F, vol = sde_batch(B, n, seed=2019, first=rank * B)          # this rank's shard of series
+    xd, vold = torch.tensor(x, device=dev), torch.tensor(vol, device=dev)
+    y = torch.log(torch.tensor(F[:, 1:], device=dev))
+
+    # ---- fill (timed separately): K is built once per model (VoltMagpie.py:46)
+    V = ops.cumtrapz(vold, xd, square=True)
+    K = ops.fill(V)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        K = ops.fill(V)
+    e1.record()
+    torch.cuda.synchronize()
+    fill_ms = e0.elapsed_time(e1) / 3
+    fill_gbs = B * n * n * 4 / (fill_ms * 1e-3) / 1e9
+
+    raw_noise = torch.full((B,), 1e-5, device=dev, requires_grad=True)   # train_utils.py:222
+    opt = torch.optim.Adam([raw_noise], lr=0.1)                            # train_utils.py:236-238
+    ws = ops.MllWorkspace(B, n, True, dev)
+    red = torch.zeros(2, device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        mean = ops.ewma(y, EWMA_K)[..., :-1]                    # EWMAMean.forward (EWMA.py:46-54)
+        resid = y - mean
+        with torch.no_grad():
+            sigma2 = torch.nn.functional.softplus(raw_noise) + 1e-4
+        out, alpha, info = ops.mll_step(K, resid, sigma2, ws, want_grad=True)
+        with torch.no_grad():
+            # loss = -mll ; d loss / d raw = -(d mll / d sigma2) * sigmoid(raw)
+            raw_noise.grad = -(out[:, 1] * torch.sigmoid(raw_noise))
+            red[0] = -out[:, 0].sum()
+            red[1] = raw_noise.grad.sum()
+        if dist is not None:
+            dist.all_reduce(red)                                 # the path's only collective
+        opt.step()
+        return out, info
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, info = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    bad = int((info != 0).sum().item())
+    loss = float(red[0].item()) / (B * world)
+
+    # ---- roofline leg: per-launch HIP events around each kernel class of one factor+inverse
+    roof = None
+    extra = {}
+    if rank == 0:
+        Np = ops.padded_n(n)
+        L = _lib.lib()
+        s2 = (torch.nn.functional.softplus(raw_noise.detach()) + 1e-4).contiguous()
+        A = torch.empty(B, Np, Np, device=dev)
+        Winv = torch.empty(B, Np // 128, 128, 128, device=dev)
+        Y = torch.empty(B, Np, Np, device=dev)
+        inf = torch.empty(B, dtype=torch.int32, device=dev)
+        ms = (ctypes.c_float * 4)()
+        cnt = (ctypes.c_int * 4)()
+        tot = np.zeros(4)
+        reps = 2
+        for _ in range(reps):
+            _lib.check(L.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n,
+                                          _lib.stream_ptr()), "prepare")
+            _lib.check(L.volt_profile_factor_f32(A.data_ptr(), Winv.data_ptr(), Y.data_ptr(), inf.data_ptr(), B, Np,
+                                                 _lib.stream_ptr(), ms, cnt), "profile")
+            tot += np.array(list(ms))
+        tot /= reps
+        names = ["potrf_update_kernel", "potrf_diag_kernel", "potrf_trsm_kernel", "trtri_row_kernel"]
+        flops = kernel_class_flops(B, Np)
+        dom = int(np.argmax(tot))
+        ach = flops[dom] / (tot[dom] * 1e-3) / 1e12
+        roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "launches": int(cnt[dom]), "avg_launch_ms": round(float(tot[dom] / max(1, cnt[dom])), 4)}
+        extra = {"kernel_ms": {nm: round(float(t), 3) for nm, t in zip(names, tot)},
+                 "kernel_tflops": {nm: round(f / (t * 1e-3) / 1e12, 2) for nm, f, t in zip(names, flops, tot)},
+                 "ms_per_cholesky": round(float(tot[:3].sum()) / B, 4),
+                 "cholesky_tflops": round(B * Np ** 3 / 3 / (tot[:3].sum() * 1e-3) / 1e12, 2),
+                 "fill_ms": round(fill_ms, 3), "fill_GBps": round(fill_gbs, 1),
+                 "fill_frac_of_hbm_peak": round(fill_gbs / HBM_PEAK_GBS, 4)}
+        del A, Winv, Y
+
+    # ---- CPU baseline leg (rank 0, N=1 only): torch-CPU restatement of the gpytorch path
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_cpu_path as tp
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        bs = 4 if n >= 4096 else 8
+        Kc = K[:bs].cpu()
+        yc = y[:bs].cpu()
+        mc = ops.ewma(y[:bs], EWMA_K)[..., :-1].cpu()
+        rawc = torch.full((bs,), 1e-5, requires_grad=True)
+        tp.mll_step(Kc, yc, mc, rawc)                    # warm-up
+        reps = 2
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            mll_c, g_c = tp.mll_step(Kc, yc, mc, rawc)
+        tc = (time.perf_counter() - t1) / reps
+        cpu = {"value": round(1.0 / (tc / bs * B), 5), "unit": "steps/s", "cores": cores, "kind": "port",
+               "sample": f"{bs} of {B} series x {reps} steps at N={n} (torch-CPU fp32 cholesky+autograd, "
+                         f"{tc:.2f} s per {bs}-series step), scaled x{B // bs} to the batch",
+               "note": "gpytorch absent -- baseline is a torch-only restatement (oracle/torch_cpu_path.py)"}
+
+    if rank == 0:
+        steps_per_s = world * args.steps / dt
+        line = {
+            "metric": "mll_grad_steps_per_s", "value": round(steps_per_s, 4),
+            "unit": f"steps/s (1 step = MLL+grad over {B} series of N={n})",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MLL+grad step, N={n}, batch={B} series per GPU, Volatility kernel + EWMA(k={EWMA_K}) mean",
+                       "series_total": B * world, "parallelism": f"series-sharded x{world}",
+                       "collective": "all_reduce(2 floats)/step" if world > 1 else "none"},
+            "step_tflops": round(world * B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
+            "loss": round(loss, 6), "not_pd": bad,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

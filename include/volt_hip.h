@@ -57,6 +57,14 @@ int volt_cumtrapz_f64(const double* vol, int64_t bs_vol, const double* x, int64_
 int volt_fill_f32(const float* V, float* K, int B, int N, int64_t ldk, int64_t bsk, void* stream);
 int volt_fill_f64(const double* V, double* K, int B, int N, int64_t ldk, int64_t bsk, void* stream);
 
+/* ---- a4: EWMA  (voltron/means/EWMA.py:20-37) --------------------------------------------------
+ * out[b,t] = sum_{j<k} w[j] * padded[b,t+j], padded = k copies of y[b,0] then y[b,:]; t = 0..N, so
+ * out is [B,N+1]: out[:, :-1] is the train mean, out[:, -1] the one-step-ahead mean.  The k taps
+ * `w` (device, fp32) are computed by the host exactly as the reference does (:21-24).  Replaces
+ * conv1d + the forced .type(torch.FloatTensor) host round trip (:37). */
+int volt_ewma_f32(const float* y, int64_t bs_y, const float* w, int k, float* out, int B, int N,
+                  void* stream);
+
 /* ---- a5: GaussianLikelihood "K + sigma^2 I"  (gpytorch, called from train_utils.py:249) ------
  * A[b] = tril-tiles(K[b]) + sigma2[b] I, padded to Np with an identity block.  sigma2 may be NULL
  * (adds nothing: rollouts factor raw K, rollout_utils.py:35) and `jitter` is added on top of it
@@ -84,6 +92,13 @@ int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, f
 /* ---- a5: triangular inverse for the noise gradient  (replaces autograd cholesky_backward) ---
  * Y = L^-T (upper triangular, row-major [B,Np,Np]); tr(K_s^-1) = ||Y||_F^2. */
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream);
+
+/* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
+ * Runs volt_potrf_f32 (and, if Y != NULL, volt_trtri_f32) with every launch bracketed by HIP events
+ * on `stream`, synchronises, and writes to HOST arrays the summed milliseconds and launch counts
+ * per kernel class: [0] potrf_update (P1), [1] potrf_diag (P2), [2] potrf_trsm (P3), [3] trtri_row. */
+int volt_profile_factor_f32(float* A, float* Winv, float* Y, int* info, int B, int Np, void* stream,
+                            float* ms_host /*[4]*/, int* launches_host /*[4]*/);
 
 /* ---- a5: MLL + gradient  (ExactMarginalLogLikelihood + loss.backward(), train_utils.py:249-250)
  * One "step" of SURVEY 8(d) with K resident:

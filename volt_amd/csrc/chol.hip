@@ -16,6 +16,7 @@
 // right-looking sweep; HBM traffic is the operand reads, N^3/(6*128) words per matrix.
 #include "common.h"
 #include "../../include/volt_hip.h"
+#include <vector>
 
 namespace volt {
 
@@ -365,6 +366,75 @@ __global__ __launch_bounds__(256) void trtri_row_kernel(const float* __restrict_
 
 using namespace volt;
 
+// Optional per-launch timing (bench only): every launch is bracketed by two events on the same
+// stream; the caller synchronises and sums the intervals per kernel class.
+struct LaunchTimer {
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    explicit LaunchTimer(hipStream_t st) : s(st) {}
+    void begin(int c) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, s);
+        ev.push_back(e);
+        cls.push_back(c);
+    }
+    void end() {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, s);
+        ev.push_back(e);
+    }
+    void collect(float* ms_by_class, int* n_by_class, int nclass) {
+        (void)hipStreamSynchronize(s);
+        for (int c = 0; c < nclass; ++c) { ms_by_class[c] = 0.f; n_by_class[c] = 0; }
+        for (size_t i = 0; i < cls.size(); ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+            ms_by_class[cls[i]] += ms;
+            n_by_class[cls[i]] += 1;
+        }
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+        cls.clear();
+    }
+};
+
+static int run_potrf(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, LaunchTimer* tm) {
+    const int n = Np / TS;
+    hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < n; ++k) {
+        if (k > 0) {
+            if (tm) tm->begin(0);
+            hipLaunchKernelGGL(potrf_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B);
+            if (tm) tm->end();
+        }
+        if (tm) tm->begin(1);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(256), 0, s, A, Winv, info, Np, k);
+        if (tm) tm->end();
+        if (k + 1 < n) {
+            if (tm) tm->begin(2);
+            hipLaunchKernelGGL(potrf_trsm_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+            if (tm) tm->end();
+        }
+    }
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np, hipStream_t s, LaunchTimer* tm) {
+    const int n = Np / TS;
+    for (int i = 0; i < n; ++i) {
+        if (tm) tm->begin(3);
+        hipLaunchKernelGGL(trtri_row_kernel, dim3((i + 1) * B), dim3(256), 0, s, A, Winv, Y, Np, i, B);
+        if (tm) tm->end();
+    }
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" {
 
 int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, int B,
@@ -389,16 +459,23 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
     if (B < 0) return -4;
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int n = Np / TS;
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
-    if (e != hipSuccess) return (int)e;
-    for (int k = 0; k < n; ++k) {
-        if (k > 0) hipLaunchKernelGGL(potrf_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B);
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(256), 0, s, A, Winv, info, Np, k);
-        if (k + 1 < n) hipLaunchKernelGGL(potrf_trsm_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
-    }
-    VOLT_LAUNCH_CHECK();
+    return run_potrf(A, Winv, info, B, Np, (hipStream_t)stream, nullptr);
+}
+
+int volt_profile_factor_f32(float* A, float* Winv, float* Y, int* info, int B, int Np, void* stream,
+                            float* ms_host, int* launches_host) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!info) return -4;
+    if (B < 1) return -5;
+    if (Np < TS || Np % TS) return -6;
+    if (!ms_host) return -8;
+    if (!launches_host) return -9;
+    LaunchTimer tm((hipStream_t)stream);
+    int rc = run_potrf(A, Winv, info, B, Np, (hipStream_t)stream, &tm);
+    if (rc) return rc;
+    if (Y && (rc = run_trtri(A, Winv, Y, B, Np, (hipStream_t)stream, &tm))) return rc;
+    tm.collect(ms_host, launches_host, 4);
     return 0;
 }
 
@@ -449,12 +526,7 @@ int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, v
     if (B < 0) return -4;
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int n = Np / TS;
-    for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(trtri_row_kernel, dim3((i + 1) * B), dim3(256), 0, s, A, Winv, Y, Np, i, B);
-    VOLT_LAUNCH_CHECK();
-    return 0;
+    return run_trtri(A, Winv, Y, B, Np, (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"

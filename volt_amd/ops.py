@@ -58,6 +58,26 @@ def fill(V: torch.Tensor) -> torch.Tensor:
     return K.reshape(*V.shape[:-1], n, n)
 
 
+def ewma_weights(k: int, device) -> torch.Tensor:
+    """The reference's taps, computed with the same torch expression (voltron/means/EWMA.py:21-24)."""
+    alpha = 2. / (k + 1)
+    wghts = alpha * (1 - alpha) ** (torch.arange(k - 1, -1, -1))
+    return (wghts / wghts.sum()).to(torch.float32).to(device)
+
+
+def ewma(y: torch.Tensor, k: int) -> torch.Tensor:
+    """EWMA(y, k) (voltron/means/EWMA.py:20-37): y [..., N] -> [..., N+1] fp32, on the device."""
+    _need_gpu(y)
+    n = y.shape[-1]
+    yb = y.to(torch.float32).reshape(-1, n).contiguous()
+    B = yb.shape[0]
+    w = ewma_weights(k, y.device)
+    out = torch.empty(B, n + 1, dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().volt_ewma_f32(yb.data_ptr(), n, w.data_ptr(), k, out.data_ptr(), B, n, _lib.stream_ptr()),
+               "volt_ewma")
+    return out.reshape(*y.shape[:-1], n + 1)
+
+
 class CholeskyFactor:
     """Result of `potrf`: padded factor A [B,Np,Np] (lower), inverse diagonal blocks, info [B]."""
 
