@@ -87,84 +87,164 @@ __global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict_
 }
 
 // ----------------------------------------------------------------------------- P2
-// One workgroup per matrix: unblocked right-looking Cholesky of the 128x128 diagonal block in
-// LDS, then its inverse by forward substitution on the identity.  Serial by nature (128 dependent
-// pivots); only B workgroups are alive, which is why the batch runs in lockstep.
-constexpr int DLD = TS + 16;   // (16 i + c) mod 32 banks: conflict-free for the 2-row x 16-col half-waves
-
+// One workgroup per matrix factors the 128x128 diagonal block and inverts it.  128 dependent pivots
+// make this a latency chain, so the block lives in REGISTERS: 16x16 threads, thread (ty,tx) owns the
+// 8x8 elements (ty+16*ii, tx+16*cc) (cyclic, so every thread stays busy as the active window
+// shrinks).  Per pivot: the 16 owners of column j publish it to a 512-byte LDS buffer (double
+// buffered -> one barrier per pivot), every thread reads its 8 row- and 8 column-entries with four
+// ds_read_b128 and applies the rank-1 update to the registers that are still active; which (ii,cc)
+// pairs are active is decided at compile time (the 16-pivot groups are unrolled), only the
+// group's own block row/column needs a lane mask.  Columns of L are kept in LDS (transposed,
+// lane-permuted) for the second phase, W = L^-1 by forward substitution with the same machinery.
+// LDS element order inside a 128-vector: index (i%16)*8 + i/16, i.e. a thread's 8 entries are contiguous.
 __global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                          int* __restrict__ info, int Np, int k) {
-    __shared__ float sL[TS * DLD];
-    __shared__ float sW[TS * DLD];
-    __shared__ float vec[TS];
+    __shared__ __attribute__((aligned(16))) float sLT[TS * TS];   // [j][perm(i)] = L[i][j]
+    __shared__ __attribute__((aligned(16))) float bc[2][TS];
+    __shared__ float sRinv[TS];
     const int b = blockIdx.x;
     const int n = Np / TS;
     float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     float* W = Winv + ((int64_t)b * n + k) * TS * TS;
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    // load (coalesced float4), build identity in sW
-    for (int e = tid; e < TS * TS / 4; e += NT) {
-        const int r = e >> 5, c = (e & 31) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(D + (int64_t)r * Np + c);
+
+    float a[8][8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            sL[r * DLD + c + q] = v[q];
-            sW[r * DLD + c + q] = (r == c + q) ? 1.f : 0.f;
-        }
-    }
-    __syncthreads();
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc)
+            a[ii][cc] = (ii >= cc) ? D[(int64_t)(ty + 16 * ii) * Np + tx + 16 * cc] : 0.f;
+
     int bad = 0;
-    for (int j = 0; j < TS; ++j) {
-        const float d = sL[j * DLD + j];
-        if (!(d > 0.f) && bad == 0) bad = j + 1;           // non-positive or NaN pivot
-        const float piv = sqrtf(d);
-        const float rinv = 1.f / piv;
-        __syncthreads();                                     // everyone has read the pivot
-        if (tid < TS) {
-            if (tid > j) {
-                const float v = sL[tid * DLD + j] * rinv;
-                sL[tid * DLD + j] = v;
-                vec[tid] = v;
-            } else if (tid == j) {
-                sL[j * DLD + j] = piv;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+#pragma clang loop unroll(disable)
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = jb * 16 + jj;
+            float* buf = bc[j & 1];
+            if (tx == jj) {
+                f32x4 lo, hi;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) lo[ii] = (ii >= jb) ? a[ii][jb] : 0.f;
+#pragma unroll
+                for (int ii = 4; ii < 8; ++ii) hi[ii - 4] = (ii >= jb) ? a[ii][jb] : 0.f;
+                *reinterpret_cast<f32x4*>(buf + ty * 8) = lo;
+                *reinterpret_cast<f32x4*>(buf + ty * 8 + 4) = hi;
+            }
+            __syncthreads();
+            const float d = buf[jj * 8 + jb];
+            if (!(d > 0.f) && bad == 0) bad = j + 1;            // non-positive or NaN pivot
+            const float piv = sqrtf(d);
+            const float rinv = 1.f / piv;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(buf + ty * 8);
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(buf + ty * 8 + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(buf + tx * 8);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(buf + tx * 8 + 4);
+            float li[8], lc[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                li[q] = r0[q] * rinv;
+                li[q + 4] = r1[q] * rinv;
+                lc[q] = c0[q] * rinv;
+                lc[q + 4] = c1[q] * rinv;
+            }
+#pragma unroll
+            for (int cc = jb; cc < 8; ++cc) {
+                const bool colact = (cc > jb) || (tx > jj);                   // c > j
+#pragma unroll
+                for (int ii = cc; ii < 8; ++ii) {
+                    const bool act = colact && ((ii > cc) || (ty >= tx));     // i >= c
+                    if (act) a[ii][cc] -= li[ii] * lc[cc];
+                }
+            }
+            if (tx == jj) {                                                   // column j is final
+                f32x4 lo, hi;
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    float v = 0.f;
+                    if (ii > jb) v = li[ii];
+                    else if (ii == jb) v = (ty > jj) ? li[ii] : ((ty == jj) ? piv : 0.f);
+                    if (ii >= jb) a[ii][jb] = v;
+                    if (ii < 4) lo[ii] = v; else hi[ii - 4] = v;
+                }
+                *reinterpret_cast<f32x4*>(sLT + j * TS + ty * 8) = lo;
+                *reinterpret_cast<f32x4*>(sLT + j * TS + ty * 8 + 4) = hi;
+                if (ty == jj) sRinv[j] = rinv;
             }
         }
-        __syncthreads();
-        for (int i = j + 1 + ty; i < TS; i += 16) {
-            const float li = vec[i];
-            for (int c = j + 1 + tx; c <= i; c += 16) sL[i * DLD + c] -= li * vec[c];
-        }
-        // next iteration's pivot read is ordered by the barrier below
-        __syncthreads();
     }
-    // W = L^-1: rows of W become final top to bottom.
-    for (int j = 0; j < TS; ++j) {
-        const float rinv = 1.f / sL[j * DLD + j];
-        if (tid <= j) {
-            const float v = sW[j * DLD + tid] * rinv;
-            sW[j * DLD + tid] = v;
-            vec[tid] = v;
-        }
-        __syncthreads();
-        for (int i = j + 1 + ty; i < TS; i += 16) {
-            const float lij = sL[i * DLD + j];
-            for (int c = tx; c <= j; c += 16) sW[i * DLD + c] -= lij * vec[c];
-        }
-        __syncthreads();
-    }
-    // write back L (strict upper zeroed) and W
-    for (int e = tid; e < TS * TS / 4; e += NT) {
-        const int r = e >> 5, c = (e & 31) * 4;
-        f32x4 l, w;
+    // L out (strict upper of the tile zeroed)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            l[q] = (c + q <= r) ? sL[r * DLD + c + q] : 0.f;
-            w[q] = (c + q <= r) ? sW[r * DLD + c + q] : 0.f;
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            float v = 0.f;
+            if (ii > cc) v = a[ii][cc];
+            else if (ii == cc) v = (ty >= tx) ? a[ii][cc] : 0.f;
+            D[(int64_t)(ty + 16 * ii) * Np + tx + 16 * cc] = v;
         }
-        *reinterpret_cast<f32x4*>(D + (int64_t)r * Np + c) = l;
-        *reinterpret_cast<f32x4*>(W + r * TS + c) = w;
+    __syncthreads();
+
+    // ---- W = L^-1: rows become final top to bottom -----------------------------------------
+    float w[8][8];
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) w[ii][cc] = (ii == cc && ty == tx) ? 1.f : 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+#pragma clang loop unroll(disable)
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = jb * 16 + jj;
+            float* buf = bc[j & 1];
+            if (ty == jj) {                                                   // owners of row j
+                const float rinv = sRinv[j];
+                f32x4 lo, hi;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    float v = 0.f;
+                    if (cc < jb) v = w[jb][cc] * rinv;
+                    else if (cc == jb) v = (tx <= jj) ? w[jb][cc] * rinv : 0.f;
+                    if (cc <= jb) w[jb][cc] = v;
+                    if (cc < 4) lo[cc] = v; else hi[cc - 4] = v;
+                }
+                *reinterpret_cast<f32x4*>(buf + tx * 8) = lo;
+                *reinterpret_cast<f32x4*>(buf + tx * 8 + 4) = hi;
+            }
+            __syncthreads();
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(sLT + j * TS + ty * 8);       // L[i][j], my rows
+            const f32x4 r1 = *reinterpret_cast<const f32x4*>(sLT + j * TS + ty * 8 + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(buf + tx * 8);               // W[j][c], my cols
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(buf + tx * 8 + 4);
+            float li[8], lc[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                li[q] = r0[q];
+                li[q + 4] = r1[q];
+                lc[q] = c0[q];
+                lc[q + 4] = c1[q];
+            }
+#pragma unroll
+            for (int ii = jb; ii < 8; ++ii) {
+                const bool rowact = (ii > jb) || (ty > jj);                   // i > j
+#pragma unroll
+                for (int cc = 0; cc <= jb; ++cc) {
+                    const bool act = rowact && ((cc < jb) || (tx <= jj));     // c <= j
+                    if (act) w[ii][cc] -= li[ii] * lc[cc];
+                }
+            }
+        }
     }
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            float v = 0.f;
+            if (ii > cc) v = w[ii][cc];
+            else if (ii == cc) v = (ty >= tx) ? w[ii][cc] : 0.f;
+            W[(ty + 16 * ii) * TS + tx + 16 * cc] = v;
+        }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
 }
 
