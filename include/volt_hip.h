@@ -100,6 +100,10 @@ int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, v
 int volt_profile_factor_f32(float* A, float* Winv, float* Y, int* info, int B, int Np, void* stream,
                             float* ms_host /*[4]*/, int* launches_host /*[4]*/);
 
+/* Tuning hook (scripts/tune_gemm.py): launches the P1 panel-update kernel of step k `reps` times in
+ * variant `var` on an already factored A; results are garbage, only the timing matters. */
+int volt_tune_update_f32(float* A, int B, int Np, int k, int var, int reps, void* stream);
+
 /* ---- a5: MLL + gradient  (ExactMarginalLogLikelihood + loss.backward(), train_utils.py:249-250)
  * One "step" of SURVEY 8(d) with K resident:
  *     A = K + sigma2 I -> potrf -> Y = L^-T -> z = Y'r, alpha = Y z

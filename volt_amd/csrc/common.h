@@ -49,9 +49,8 @@ __device__ __forceinline__ void decode_tile_batch(int ntiles, int nbatch, int& t
 // WL = 0: waves in a 2x2 grid, each owning 64x64 = acc[tm*2+tn] (32x32 sub-tiles).
 // WL = 1: waves side by side, wave w owning all 128 rows x 32 columns [32w,32w+32) = acc[tm].
 //
-// Pipeline: register-staged prefetch of chunk c+1 (8 x global_load_dwordx4 per thread) is issued
-// before the 64 MFMAs of chunk c and written to the other LDS buffer after them; one barrier per
-// chunk.  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads (lane = row) hit 16
+// Pipeline: register-staged prefetch (8 x global_load_dwordx4 per thread and chunk), double-buffered
+// LDS, one barrier per chunk.  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads (lane = row) hit 16
 // distinct 16-byte slots per lane group.  Each b128 read feeds four v_mfma_f32_32x32x2_f32: lane
 // halves take k = 4*(lane>>5)+m, consistently for A and B, so the sum over k is complete.
 // ---------------------------------------------------------------------------------------------
@@ -82,14 +81,14 @@ __device__ __forceinline__ void stage_store(const StageRegs& s, float* __restric
     }
 }
 
-template <int WL>
+template <int WL, int KK0 = 0, int KK1 = BK / 8>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ buf, f32x16 (&acc)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const float* sA = buf;
     const float* sB = buf + TS * SLD;
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
+    for (int kk = KK0; kk < KK1; ++kk) {
         const int ko = kk * 8 + 4 * lh;
         if (WL == 0) {
             const int wr = wave >> 1, wc = wave & 1;
@@ -122,22 +121,27 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ buf, f32x16 
 
 // acc += A[0:128, 0:32*nchunks] * B[0:128, 0:32*nchunks]^T ; smem = GEMM_LDS_BYTES, 16-B aligned.
 // Ends with a barrier: smem is free for reuse on return.
+// The staging traffic rides in the shadow of the MFMAs: the LDS write of chunk c+1 and the global
+// loads of chunk c+2 are issued half-way through the 64 MFMAs of chunk c (a 32x32x2 MFMA holds the
+// pipe for 64 cycles; an in-order wave can slip a dozen other instructions behind each), so the
+// only thing left at the per-chunk barrier is the barrier.
 template <int WL>
 __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t lda,
-                                            const float* __restrict__ B, int64_t ldb, int nchunks,
-                                            f32x16 (&acc)[4], float* smem) {
+                                               const float* __restrict__ B, int64_t ldb, int nchunks,
+                                               f32x16 (&acc)[4], float* smem) {
     if (nchunks <= 0) return;
     StageRegs s;
     stage_load(s, A, lda, B, ldb, 0);
     stage_store(s, smem);
+    if (nchunks > 1) stage_load(s, A, lda, B, ldb, BK);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         float* cur = smem + (c & 1) * STAGE_FLOATS;
         float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
-        const bool more = (c + 1 < nchunks);
-        if (more) stage_load(s, A, lda, B, ldb, (c + 1) * BK);
-        mma_chunk<WL>(cur, acc);
-        if (more) stage_store(s, nxt);
+        mma_chunk<WL, 0, BK / 16>(cur, acc);
+        if (c + 1 < nchunks) stage_store(s, nxt);
+        if (c + 2 < nchunks) stage_load(s, A, lda, B, ldb, (c + 2) * BK);
+        mma_chunk<WL, BK / 16, BK / 8>(cur, acc);
         __syncthreads();
     }
 }
