@@ -93,6 +93,23 @@ int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, f
  * Y = L^-T (upper triangular, row-major [B,Np,Np]); tr(K_s^-1) = ||Y||_F^2. */
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream);
 
+/* ---- a7/a8: sequential posterior rollouts  (voltron/rollout_utils.py:57-93 + :6-53) ----------
+ * Bordered-Cholesky engine: the host factors the shared train block once per series (volt_potrf)
+ * and passes rho = u'K^-1u, tau = u'K^-1 r_tr; this launch walks all H horizon steps for every
+ * sample path: dense per-sample factor rows in `scratch`, full forward substitution per step, EWMA-
+ * family mean of the appended point (mean_mode 0 ewma / 1 dewma / 2 tewma / 3 meanrevert, EWMA.py),
+ * optional mean reversion (:41-42), jitter ladder of psd_safe_cholesky(pred_cov, jitter) (:46).
+ * G series x S samples x H steps (H <= 256).  hist_* [G,k] are the last k values of the (padded)
+ * train series / its EMA / EMA(EMA); acc0 [G] the fp64 CumTrapz running sum through the last train
+ * point.  pred_vol, z, samples [G,S,H]; info [G,S] (0, or the 1-based step of a non-positive pivot). */
+size_t volt_rollout_scratch_bytes(int G, int S, int H);
+int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* acc0, const float* dx,
+                              const float* hist_y, const float* hist_e1, const float* hist_e2,
+                              const float* ema_prev, const float* mr_latent, const float* latent,
+                              const float* w, const float* pred_vol, const float* z, float* samples,
+                              float* scratch, int* info, int G, int S, int H, int k, int mean_mode,
+                              int use_theta, float theta, float mr_theta, float jitter, void* stream);
+
 /* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
  * Runs volt_potrf_f32 (and, if Y != NULL, volt_trtri_f32) with every launch bracketed by HIP events
  * on `stream`, synchronises, and writes to HOST arrays the summed milliseconds and launch counts

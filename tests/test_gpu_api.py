@@ -1,0 +1,268 @@
+"""The voltron-shaped Python surface (kernels / means / models / train_utils / rollout_utils) on the
+MI355X, checked against golden vectors produced by the reference's own code and against the oracle.
+Reads like the reference's call sites on purpose."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import volt_oracle as vo
+from volt_amd.synthetic import sde_batch, sde_series, rollout_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    assert torch.cuda.is_available()
+    import volt_amd
+    return volt_amd
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    return (t if dtype is None else t.to(dtype)).cuda()
+
+
+# ------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("tag", ["n7", "n64", "n257", "b3n50", "b2n130"])
+def test_volatility_kernel_class_golden(va, golden, tag):
+    from volt_amd.kernels import VolatilityKernel
+    g = golden("fill")
+    vol, x = dev(g[f"{tag}_vol"]), dev(g[f"{tag}_x"])
+    xx = x if vol.ndim == 1 else x.unsqueeze(0).repeat(vol.shape[0], 1)
+    kern = VolatilityKernel()
+    K = kern.forward(xx.unsqueeze(-1), vol.unsqueeze(-1))
+    assert np.array_equal(K.cpu().numpy(), g[f"{tag}_K"])
+    d = kern.forward(xx.unsqueeze(-1), vol.unsqueeze(-1), diag=True)
+    assert np.array_equal(d.cpu().numpy(), g[f"{tag}_diag"])
+    assert np.array_equal(kern(xx.unsqueeze(-1), vol.unsqueeze(-1)).evaluate().cpu().numpy(), g[f"{tag}_K"])
+
+
+# ------------------------------------------------------------------ means
+@pytest.mark.parametrize("tag,k", [("n60k5", 5), ("n60k25", 25), ("b3n40k7", 7), ("n300k100", 100)])
+def test_mean_classes_golden(va, golden, tag, k):
+    from volt_amd import means
+    g = golden("ewma")
+    y, x = dev(g[f"{tag}_y"]), dev(g[f"{tag}_x"])
+    np.testing.assert_allclose(means.EWMA(y, k).cpu().numpy(), g[f"{tag}_ewma"], rtol=2e-6)
+    n = x.shape[0]
+    for cname, cls in (("ewma", means.EWMAMean), ("dewma", means.DEWMAMean), ("tewma", means.TEWMAMean),
+                       ("meanrevert", means.MeanRevertingEMAMean)):
+        mod = cls(x, y, k)
+        for branch, xq in (("train", x), ("one", x[-1:] + 1 / 252.), ("other", x[: n // 2])):
+            out = mod(xq)
+            ref = g[f"{tag}_{cname}_{branch}"]
+            assert tuple(out.shape) == ref.shape, (cname, branch)
+            assert out.is_cuda
+            np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ MLL autograd
+def test_mll_autograd_matches_oracle(va):
+    from volt_amd.gp import ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal
+    B, n = 3, 320
+    x, F, vol = sde_batch(B, n)
+    K = vo.volatility_kernel(np.repeat(x[None], B, 0)[..., None], vol[..., None])
+    y = np.log(F[:, 1:])
+    lh = GaussianLikelihood(batch_shape=torch.Size([B])).cuda()
+    lh.raw_noise.data.fill_(1e-5)
+    mean = torch.full((B, n), 2.3, device="cuda", requires_grad=True)
+    mll = ExactMarginalLogLikelihood(lh, None)
+    val = mll(MultivariateNormal(mean, dev(K)), dev(y))
+    assert val.shape == (B,)
+    (-val.sum()).backward()
+    o = vo.mll_and_grads(K, y, np.full((B, n), 2.3, dtype=np.float32), 1e-5)
+    np.testing.assert_allclose(val.detach().cpu().numpy(), o["mll"], rtol=2e-5)
+    np.testing.assert_allclose(-lh.raw_noise.grad.cpu().numpy()[:, 0], o["d_raw"], rtol=1e-3)
+    gm = -mean.grad.cpu().numpy()
+    assert np.abs(gm - o["d_mean"]).max() <= 1e-4 * np.abs(o["d_mean"]).max()
+
+
+def test_mll_raises_on_non_pd(va):
+    from volt_amd.gp import ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal, NotPSDError
+    n = 130
+    K = -5 * torch.eye(n, device="cuda")
+    lh = GaussianLikelihood().cuda()
+    with pytest.raises(NotPSDError):
+        ExactMarginalLogLikelihood(lh, None)(MultivariateNormal(torch.zeros(n, device="cuda"), K),
+                                              torch.zeros(n, device="cuda"))
+
+
+# ------------------------------------------------------------------ training loops
+def _oracle_adam(K, y, mean, iters, lr=0.1):
+    raw = torch.tensor([1e-5], dtype=torch.float64, requires_grad=True)
+    opt = torch.optim.Adam([raw], lr=lr)
+    losses = []
+    for _ in range(iters):
+        opt.zero_grad()
+        o = vo.mll_and_grads(K, y, mean, float(raw))
+        losses.append(-float(o["mll"]))
+        raw.grad = torch.tensor([-o["d_raw"]], dtype=torch.float64)
+        opt.step()
+    return np.array(losses), float(raw)
+
+
+@pytest.mark.parametrize("mean_func", ["ewma", "dewma"])
+def test_train_volt_magpie_model_tracks_oracle(va, mean_func):
+    """The reference loop (train_utils.py:192-257) on the device vs the same Adam recursion driven by the
+    fp64 oracle: losses agree to 1e-4 over 12 iterations (sigma^2 moves from 0.69 to ~0.2)."""
+    from volt_amd.train_utils import TrainVoltMagpieModel
+    n, k, iters = 255, 20, 12
+    F, vol = sde_series(n, 2021)
+    train_x = torch.arange(n, device="cuda") / 252.
+    prices = dev(F)
+    model, lh = TrainVoltMagpieModel(train_x, prices[1:], None, None, dev(vol), train_iters=iters, k=k,
+                                     mean_func=mean_func)
+    x = (np.arange(n) / 252.).astype(np.float32)
+    K = vo.volatility_kernel(x, vol)
+    y = np.log(F[1:])
+    mfn = vo.ewma_mean if mean_func == "ewma" else vo.dewma_mean
+    losses, raw_end = _oracle_adam(K, y, mfn(x, x, y, k), iters)
+    assert abs(float(lh.raw_noise) - raw_end) < 2e-3 * max(1.0, abs(raw_end))
+    # last loss of the device loop, recomputed
+    from volt_amd.gp import ExactMarginalLogLikelihood
+    with torch.no_grad():
+        model.train()
+        last = -ExactMarginalLogLikelihood(lh, model)(model(train_x), prices[1:].log())
+    o = vo.mll_and_grads(K, y, mfn(x, x, y, k), float(lh.raw_noise))
+    assert abs(float(last) + float(o["mll"])) < 1e-4 * max(1.0, abs(float(o["mll"])))
+    # only the likelihood noise is trainable with an EWMA-family mean (train_utils.py:201)
+    flags = [p.requires_grad for p in model.parameters()]
+    assert flags[0] is True and not any(flags[1:])
+
+
+def test_train_data_model_loglinear(va):
+    from volt_amd.train_utils import TrainDataModel
+    n = 200
+    F, vol = sde_series(n, 7)
+    train_x = torch.arange(n, device="cuda") / 252.
+    model, lh = TrainDataModel(train_x, dev(F)[1:], None, None, dev(vol), train_iters=5)
+    assert model.mean_module.weights.grad is not None and model.mean_module.bias.grad is not None
+    assert torch.isfinite(lh.raw_noise).all()
+    assert model.train_cov.shape == (n, n)
+
+
+def test_batched_training_matches_per_series(va):
+    from volt_amd.train_utils import TrainVoltMagpieBatch, TrainVoltMagpieModel
+    B, n, iters = 3, 200, 6
+    x, F, vol = sde_batch(B, n)
+    tx = dev(x)
+    model, lh, losses = TrainVoltMagpieBatch(tx, dev(F[:, 1:]), dev(vol), train_iters=iters, k=10)
+    for b in range(B):
+        m1, l1 = TrainVoltMagpieModel(tx, dev(F[b, 1:]), None, None, dev(vol[b]), train_iters=iters, k=10)
+        assert abs(float(l1.raw_noise) - float(lh.raw_noise[b])) < 1e-4
+
+
+# ------------------------------------------------------------------ rollouts
+class _ConstMean(torch.nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+
+    def forward(self, x):
+        return torch.full((x.shape[0],), self.c, device=x.device)
+
+
+def test_generate_prediction_multipoint_golden(va, golden):
+    from volt_amd.kernels import VolatilityKernel
+    from volt_amd.rollout_utils import GeneratePrediction
+    g = golden("rollouts")
+
+    class M:
+        pass
+    m = M()
+    m.train_x = dev(g["gpm_train_x"])
+    m.train_y = dev(g["gpm_train_y"])[1:].log()
+    m.log_vol_path = dev(g["gpm_vol_path"]).log()
+    m.mean_module = _ConstMean(float(g["gpm_const"]))
+    m.covar_module = VolatilityKernel()
+    out = GeneratePrediction(m.train_x, dev(g["gpm_train_y"]), dev(g["gpm_test_x"]), dev(g["gpm_pred_vol"]), m,
+                             z=dev(g["gpm_z"]))
+    assert tuple(out.shape) == g["gpm_samples"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g["gpm_samples"], atol=2e-3, rtol=0)
+
+
+RO = [("ewma", "ewma"), ("ewma_theta", "ewma"), ("dewma", "dewma"), ("tewma", "tewma"), ("ewma_n120", "ewma")]
+
+
+def _golden_model(g, tag, mean):
+    from volt_amd import means
+    from volt_amd.gp import GaussianLikelihood
+    from volt_amd.models import VoltMagpie
+    tx, ty = dev(g[f"{tag}_train_x"]), dev(g[f"{tag}_train_y"])
+    k = int(g[f"{tag}_k"])
+    model = VoltMagpie(tx, ty[1:].log(), GaussianLikelihood().cuda(), dev(g[f"{tag}_vol_path"]), k=k)
+    cls = {"ewma": means.EWMAMean, "dewma": means.DEWMAMean, "tewma": means.TEWMAMean}[mean]
+    model.mean_module = cls(tx, ty[1:].log(), k)
+    return model, tx, ty
+
+
+@pytest.mark.parametrize("engine", ["dense", "bordered"])
+@pytest.mark.parametrize("tag,mean", RO)
+def test_rollouts_golden_pathwise(va, golden, tag, mean, engine):
+    """Reference Rollouts outputs (tests/golden/rollouts.npz) with the same pred_vol and N(0,1) draws.
+    Tolerance 2e-3 abs on log-prices (one-step predictive sd ~ 1e-2): the reference factors the
+    noise-free K in fp32, so its own outputs carry round-off of this size."""
+    from volt_amd.rollout_utils import Rollouts
+    g = golden("rollouts")
+    model, tx, ty = _golden_model(g, tag, mean)
+    theta = float(g[f"{tag}_theta"])
+    theta = None if np.isnan(theta) else theta
+    S, H = g[f"{tag}_z"].shape
+    out = Rollouts(tx, ty, dev(g[f"{tag}_test_x"]), model, nsample=S, theta=theta,
+                   pred_vol=dev(g[f"{tag}_pred_vol"]), z=dev(g[f"{tag}_z"]), engine=engine)
+    assert not out.is_cuda and tuple(out.shape) == (S, H)          # CPU result like the reference (:65)
+    np.testing.assert_allclose(out.numpy(), g[f"{tag}_samples"], atol=2e-3, rtol=0)
+    # the model is left mutated as the reference leaves it (:80-86)
+    n = tx.shape[0]
+    assert tuple(model.train_y.shape) == (S, n + H - 1) and tuple(model.log_vol_path.shape) == (S, n + H - 1)
+    assert tuple(model.train_x.shape) == (n + H - 1,)
+
+
+@pytest.mark.parametrize("mean_name", ["ewma", "dewma", "tewma", "meanrevert"])
+def test_bordered_vs_oracle_exact_conditional(va, mean_name):
+    """Against the fp64 exact conditional (last residual + mean + sqrt(1/2 dx v^2) z) driven by
+    the oracle's means, N = 399 (the reference's default ntrain), S = 16, H = 24."""
+    from volt_amd import means
+    from volt_amd.gp import GaussianLikelihood
+    from volt_amd.models import VoltMagpie
+    from volt_amd.rollout_utils import Rollouts
+    n, S, H, k = 399, 16, 24, 25
+    F, vol = sde_series(n, 11)
+    pv, z = rollout_inputs(vol[-1], S, H, seed=5)
+    tx = torch.arange(n, device="cuda") / 252.
+    test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
+    model = VoltMagpie(tx, dev(F)[1:].log(), GaussianLikelihood().cuda(), dev(vol), k=k)
+    cls = {"ewma": means.EWMAMean, "dewma": means.DEWMAMean, "tewma": means.TEWMAMean,
+           "meanrevert": means.MeanRevertingEMAMean}[mean_name]
+    model.mean_module = cls(tx, dev(F)[1:].log(), k)
+    out = Rollouts(tx, dev(F), test_x, copy.deepcopy(model), nsample=S, pred_vol=dev(pv), z=dev(z),
+                   engine="bordered").numpy()
+    # exact recursion in fp64
+    x = (np.arange(n) / 252.).astype(np.float32)
+    logy = np.log(F[1:]).astype(np.float32)
+    fn = {"ewma": vo.ewma_mean, "dewma": vo.dewma_mean, "tewma": vo.tewma_mean, "meanrevert": vo.meanrevert_mean}[mean_name]
+    lat = logy.mean(dtype=np.float32)
+    ref = np.zeros((S, H))
+    for s in range(S):
+        ys = logy.copy()
+        xs = x.copy()
+        for i in range(H):
+            kw = {"latent": lat} if mean_name == "meanrevert" else {}
+            m_all = fn(np.arange(len(ys) + 1), xs, ys, k, **kw) if False else None
+            full = {"ewma": vo.ewma(ys, k)}.get(mean_name)
+            if mean_name == "ewma":
+                mtr, mnew = full[:-1], full[-1]
+            else:
+                tr = fn(xs, xs, ys, k, **kw)
+                one = fn(np.array([0.0]), xs, ys, k, **kw)
+                mtr, mnew = tr, one[0]
+            resid_last = ys[-1] - mtr[-1]
+            sd = np.sqrt(0.5 * (1 / 252.) * float(pv[s, i]) ** 2)
+            ref[s, i] = resid_last + mnew + sd * z[s, i]
+            ys = np.append(ys, np.float32(ref[s, i]))
+            xs = np.append(xs, np.float32(xs[-1] + 1 / 252.))
+    # fp32 factor of the noise-free K (cond ~1e6 at N=399): a few 1e-4 on values ~2.3
+    np.testing.assert_allclose(out, ref, atol=1.5e-3, rtol=0)

@@ -1,0 +1,29 @@
+"""volt_amd -- MI355X-native implementation of Volt's exact-GP hot path (g-benton/Volt), exposing
+the reference's own ``voltron`` surface for that path (voltron/__init__.py:2-11):
+
+    from volt_amd.kernels import VolatilityKernel
+    from volt_amd.models import VoltronGP, VoltMagpie, BMGP
+    from volt_amd.rollout_utils import Rollouts, GeneratePrediction
+    from volt_amd.train_utils import TrainVoltMagpieModel, TrainDataModel
+
+``volt_amd.install_as_voltron()`` aliases the package as ``voltron`` so reference drivers import it
+unchanged.  Arithmetic runs in volt_amd/csrc/libvolt_hip.so (include/volt_hip.h); nothing here has a
+CPU fallback.
+"""
+__version__ = "0.1"
+
+from .kernels import BMKernel, VolatilityKernel            # noqa: F401
+from .models import BMGP, VoltronGP, VoltMagpie            # noqa: F401
+from .rollout_utils import Rollouts, GeneratePrediction    # noqa: F401
+
+
+def install_as_voltron():
+    """Register this package (and its hot-path submodules) under the name ``voltron``."""
+    import sys
+    from . import kernels, means, models, rollout_utils, train_utils
+    me = sys.modules[__name__]
+    sys.modules.setdefault("voltron", me)
+    for name, mod in (("kernels", kernels), ("means", means), ("models", models),
+                      ("rollout_utils", rollout_utils), ("train_utils", train_utils)):
+        sys.modules.setdefault("voltron." + name, mod)
+    return me

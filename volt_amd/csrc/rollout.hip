@@ -1,0 +1,262 @@
+// Sequential posterior rollouts, bordered-Cholesky engine (7 hard part 3).
+//   reference: voltron/rollout_utils.py:57-93 calling GeneratePrediction (:6-53) H times; every call
+//   re-fills and re-factors S matrices of size (N+idx)^2 from scratch.
+//
+// Structure used (and only this): the train block of every sample's matrix is the same
+// (train_stack_vol = log_vol_path.repeat(S,1), :72) and the cross block between the train points and
+// the appended points is sample-independent.  So per series the host factors K_NN once (HIP potrf)
+// and solves K_NN x = u once (fp64-refined, volt_amd/rollout_engine.py); with rho = u'x (= q'q,
+// q = L^-1 u) and tau = x'r_tr (= q'z_tr) every sample owns a small dense bordered problem of
+// dimension idx <= H:
+//     S_s   = C_s - rho 11'            (Schur complement of the appended points),  L_s = chol(S_s)
+//     w_s   = L_s^-1 (k*_s - rho 1),   z_s = L_s^-1 (r_s - tau 1)
+//     mean  = tau + w_s'z_s + m(x*),   var = k** - rho - w_s'w_s
+// The new row of L_s at step idx+1 is w_s of step idx (the new column of K_tr is the previous k*),
+// which is ordinary row-by-row Cholesky.  The per-sample triangular solve is done in full at every
+// step against the stored dense rows of L_s -- O(idx^2) words streamed per step, HBM-bound.
+//
+// One wave per sample (a sample's recursion is sequential in idx and in the substitution index);
+// 4 samples per workgroup, EWMA histories in LDS.  H <= 256: a lane owns entries lane + 64 t.
+#include "common.h"
+#include "../../include/volt_hip.h"
+
+namespace volt {
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// sum over the 64 lanes, result in every lane
+__device__ __forceinline__ float wave_sum(float x) {
+    x += dpp_f<0xB1>(x);     // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);     // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);    // row_half_mirror
+    x += dpp_f<0x140>(x);    // row_mirror      -> every lane of a 16-lane row holds the row sum
+    const int xi = __float_as_int(x);        // readlane is an integer builtin: bit-cast, do not convert
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+struct RolloutParams {
+    // per series g (G series), all device pointers
+    const float* rho;        // [G]   q'q
+    const float* tau;        // [G]   q'z_tr
+    const double* acc0;      // [G]   fp64 running CumTrapz sum through train point N-1 (full weights)
+    const float* dx;         // [G]   x[1]-x[0]
+    const float* hist_y;     // [G,k] padded train series tail  Y[N-k .. N-1]
+    const float* hist_e1;    // [G,k] EMA tail    ema[N-k .. N-1]     (dewma / tewma)
+    const float* hist_e2;    // [G,k] EMA(EMA) tail                    (tewma)
+    const float* ema_prev;   // [G]   plain ema[N-1]                    (meanrevert)
+    const float* mr_latent;  // [G]   latent mean of the mean module    (meanrevert)
+    const float* latent;     // [G]   Rollouts' latent_mean (theta != NULL) or unused
+    const float* w;          // [k]   EWMA taps
+    const float* pred_vol;   // [G,S,H]
+    const float* z;          // [G,S,H]
+    float* samples;          // [G,S,H]
+    float* Ls;               // [G,S,H,H] scratch: rows of the per-sample factor
+    int* info;               // [G,S] 0 or 1-based horizon step of the first non-positive pivot / variance
+    int G, S, H, k;
+    int mean_mode;           // 0 ewma, 1 dewma, 2 tewma, 3 meanrevert
+    int use_theta;
+    float theta, mr_theta, jitter;
+};
+
+__global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wave, g = blockIdx.y;
+    const int H = p.H, k = p.k;
+    const int hl = k + H;                                   // history length per level
+    float* hy = lds + (size_t)wave * 3 * hl;
+    float* he1 = hy + hl;
+    float* he2 = he1 + hl;
+    float* sw = lds + (size_t)4 * 3 * hl;                   // taps, shared by the 4 waves
+    for (int j = threadIdx.x; j < k; j += 256) sw[j] = p.w[j];
+    if (s < p.S) {
+        for (int j = lane; j < k; j += 64) {
+            hy[j] = p.hist_y[(size_t)g * k + j];
+            he1[j] = (p.mean_mode == 1 || p.mean_mode == 2) ? p.hist_e1[(size_t)g * k + j] : 0.f;
+            he2[j] = (p.mean_mode == 2) ? p.hist_e2[(size_t)g * k + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (s >= p.S) return;
+
+    const float rho = p.rho[g], tau = p.tau[g], dx = p.dx[g], hdx = dx * 0.5f;
+    const size_t row = ((size_t)g * p.S + s) * H;
+    const float* pv = p.pred_vol + row;
+    const float* zz = p.z + row;
+    float* out = p.samples + row;
+    float* Ls = p.Ls + row * H;
+    double acc = p.acc0[g];
+    float ema_prev = (p.mean_mode == 3) ? p.ema_prev[g] : 0.f;
+    int bad = 0;
+
+    float U[4] = {0.f, 0.f, 0.f, 0.f};      // U_s[N+a]  for a = lane + 64 t
+    float rd[4] = {0.f, 0.f, 0.f, 0.f};     // 1 / L_s[a][a]
+    float zs[4] = {0.f, 0.f, 0.f, 0.f};     // z_s[a]
+    float wv[4];
+
+    for (int idx = 0; idx < H; ++idx) {
+        // ---- w_s = L_s^-1 (U_s - rho): row-oriented forward substitution against stored rows ----
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wv[t] = U[t] - rho;
+        for (int a = 1; a < idx; ++a) {                      // row 0 has no off-diagonal part
+            const float* La = Ls + (size_t)a * H;
+            float part = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int b = lane + 64 * t;
+                if (b < a) part += La[b] * (wv[t] * rd[t]);  // w[b] = wv[b] * rd[b] for finished b
+            }
+            // every b < a is already final: entries of wv are only reduced by rows a' <= their index
+            const float dot = wave_sum(part);
+            const int ta = a >> 6;
+            if (lane == (a & 63)) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t == ta) wv[t] -= dot;
+            }
+        }
+        float ww = 0.f, wz = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int b = lane + 64 * t;
+            wv[t] = (b < idx) ? wv[t] * rd[t] : 0.f;         // now wv = w_s
+            ww += wv[t] * wv[t];
+            wz += wv[t] * zs[t];
+        }
+        ww = wave_sum(ww);
+        wz = wave_sum(wz);
+
+        // ---- mean of the new point: EWMA family on the stacked series (EWMA.py:20-37) ----------
+        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int j = lane; j < k; j += 64) {
+            const double wj = (double)sw[j];
+            a1 += wj * (double)hy[idx + j];
+            if (p.mean_mode == 1 || p.mean_mode == 2) a2 += wj * (double)he1[idx + j];
+            if (p.mean_mode == 2) a3 += wj * (double)he2[idx + j];
+        }
+        const float ma1 = (float)wave_sum_d(a1);
+        float mstar = ma1;
+        float e2new = 0.f;
+        if (p.mean_mode == 1 || p.mean_mode == 2) {
+            e2new = (float)wave_sum_d(a2);                   // EMA(EMA) at the new index
+            if (p.mean_mode == 1) mstar = 2.f * ma1 - e2new;
+            else mstar = 3.f * ma1 - 3.f * e2new + (float)wave_sum_d(a3);
+        } else if (p.mean_mode == 3) {
+            mstar = ma1 - p.mr_theta * (ema_prev - p.mr_latent[g]);
+        }
+
+        // ---- conditional and draw (rollout_utils.py:36-53) --------------------------------------
+        const float v = pv[idx];
+        const float v2 = v * v;
+        const float kss = (float)(acc + (double)__fmul_rn(hdx, v2));       // last CumTrapz weight halved
+        float pm = tau + wz + mstar;
+        if (p.use_theta) pm -= p.theta * (pm - p.latent[g]);
+        float pvar = kss - rho - ww;
+        if (!(pvar > 0.f)) {                                 // psd_safe_cholesky(pred_cov, jitter) ladder
+            float jit = p.jitter;
+            int tries = 0;
+            while (!(pvar + jit > 0.f) && tries < 2) { jit *= 10.f; ++tries; }
+            if (pvar + jit > 0.f) pvar += jit;
+            else { if (!bad) bad = idx + 1; pvar = 0.f; }
+        }
+        const float smp = sqrtf(pvar) * zz[idx] + pm;
+        if (lane == 0) out[idx] = smp;
+
+        // ---- append the point to the conditioning set --------------------------------------------
+        acc += (double)__fmul_rn(dx, v2);                    // full weight from now on
+        const float Unew = (float)acc;
+        float d2 = Unew - rho - ww;                          // next pivot of L_s
+        if (!(d2 > 0.f)) {
+            if (!bad) bad = idx + 1;
+            d2 = fmaxf(p.jitter, 1e-12f);
+        }
+        const float ell = sqrtf(d2), rell = 1.f / ell;
+        const float znew = ((smp - mstar) - tau - wz) * rell;
+        // row idx of L_s = [w_s, ell]
+        float* Lrow = Ls + (size_t)idx * H;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int b = lane + 64 * t;
+            if (b < idx) Lrow[b] = wv[t];
+            if (b == idx) {
+                Lrow[b] = ell;
+                U[t] = Unew;
+                rd[t] = rell;
+                zs[t] = znew;
+            }
+        }
+        if (lane == 0) {
+            hy[k + idx] = smp;
+            he1[k + idx] = ma1;
+            he2[k + idx] = e2new;
+        }
+        ema_prev = ma1;
+        __builtin_amdgcn_wave_barrier();
+        // make this wave's own LDS/global writes visible to its later reads
+        __threadfence_block();
+    }
+    if (lane == 0) p.info[(size_t)g * p.S + s] = bad;
+}
+
+}  // namespace volt
+
+extern "C" {
+
+size_t volt_rollout_scratch_bytes(int G, int S, int H) {
+    if (G <= 0 || S <= 0 || H <= 0) return 0;
+    return (size_t)G * S * H * H * sizeof(float);
+}
+
+int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* acc0, const float* dx,
+                              const float* hist_y, const float* hist_e1, const float* hist_e2, const float* ema_prev,
+                              const float* mr_latent, const float* latent, const float* w, const float* pred_vol,
+                              const float* z, float* samples, float* scratch, int* info, int G, int S, int H, int k,
+                              int mean_mode, int use_theta, float theta, float mr_theta, float jitter, void* stream) {
+    using namespace volt;
+    if (!rho) return -1;
+    if (!tau) return -2;
+    if (!acc0) return -3;
+    if (!dx) return -4;
+    if (!hist_y) return -5;
+    if (!w) return -11;
+    if (!pred_vol) return -12;
+    if (!z) return -13;
+    if (!samples) return -14;
+    if (!scratch) return -15;
+    if (!info) return -16;
+    if (G < 0) return -17;
+    if (S < 0) return -18;
+    if (H < 1 || H > 256) return -19;
+    if (k < 1 || k > 2048) return -20;
+    if (mean_mode < 0 || mean_mode > 3) return -21;
+    if ((mean_mode == 1 || mean_mode == 2) && !hist_e1) return -6;
+    if (mean_mode == 2 && !hist_e2) return -7;
+    if (mean_mode == 3 && (!ema_prev || !mr_latent)) return -8;
+    if (use_theta && !latent) return -10;
+    if (G == 0 || S == 0) return 0;
+    RolloutParams p{rho, tau, acc0, dx, hist_y, hist_e1, hist_e2, ema_prev, mr_latent, latent, w, pred_vol, z,
+                    samples, scratch, info, G, S, H, k, mean_mode, use_theta, theta, mr_theta, jitter};
+    const size_t lds = ((size_t)4 * 3 * (k + H) + k) * sizeof(float);
+    if (lds > 160 * 1024) return -20;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_bordered_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(rollout_bordered_kernel, dim3((S + 3) / 4, G), dim3(256), lds, (hipStream_t)stream, p);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

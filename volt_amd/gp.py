@@ -1,0 +1,319 @@
+"""Minimal stand-ins for the four gpytorch types the hot path touches, backed by the HIP library.
+
+The reference's call sites are unchanged:
+
+    likelihood = GaussianLikelihood()                               # train_utils.py:100,195
+    mll = ExactMarginalLogLikelihood(likelihood, model)             # train_utils.py:127,240
+    output = model(train_x)                                         # ExactGP.__call__ -> forward
+    loss = -mll(output, train_y); loss.backward()                   # train_utils.py:249-250
+
+gpytorch itself is third-party and absent from /root/reference; what is restated here (from its
+published behaviour, gpytorch >= 1.0.1 per setup.py:19) is only the plumbing: parameter names and
+registration order (the reference freezes parameters *positionally*, train_utils.py:226-227), the
+``softplus + 1e-4`` noise constraint, input unsqueezing in ``ExactGP.__call__`` and the
+``psd_safe_cholesky`` jitter policy.  The arithmetic -- K + sigma^2 I, Cholesky, solves, log-det,
+gradient -- runs in libvolt_hip.so through one ``torch.autograd.Function``; there is no CPU path.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+class NotPSDError(RuntimeError):
+    pass
+
+
+class NanError(RuntimeError):
+    pass
+
+
+class NumericalWarning(RuntimeWarning):
+    pass
+
+
+# ------------------------------------------------------------------------------------ modules
+class Module(nn.Module):
+    pass
+
+
+class Kernel(Module):
+    """gpytorch.kernels.Kernel stand-in: ``kernel(x1, x2)`` calls ``forward`` and wraps the result
+    so that ``.evaluate()`` (rollout_utils.py:26) works."""
+    has_lengthscale = False
+
+    def __init__(self, **kwargs):
+        super().__init__()
+
+    def __call__(self, *args, **kwargs):
+        return _Evaluated(self.forward(*args, **kwargs))
+
+
+class _Evaluated:
+    """Already-dense "lazy tensor"."""
+
+    def __init__(self, t):
+        self.tensor = t
+
+    def evaluate(self):
+        return self.tensor
+
+    def to_dense(self):
+        return self.tensor
+
+    def detach(self):
+        return self.tensor.detach()
+
+    @property
+    def shape(self):
+        return self.tensor.shape
+
+
+def _dense(c):
+    return c.evaluate() if isinstance(c, _Evaluated) else c
+
+
+class Mean(Module):
+    def __call__(self, x):
+        res = self.forward(x)
+        return res
+
+
+class ConstantMean(Mean):
+    def __init__(self, batch_shape=torch.Size(), **kwargs):
+        super().__init__()
+        self.batch_shape = batch_shape
+        self.register_parameter("constant", nn.Parameter(torch.zeros(*batch_shape, 1)))
+
+    def forward(self, x):
+        if x.shape[:-2] == self.batch_shape:
+            return self.constant.expand(x.shape[:-1])
+        return self.constant.expand(*x.shape[:-1]) if x.ndim > 1 else self.constant.expand(x.shape)
+
+
+class LinearMean(Mean):
+    def __init__(self, input_size, batch_shape=torch.Size(), bias=True):
+        super().__init__()
+        self.register_parameter("weights", nn.Parameter(torch.randn(*batch_shape, input_size, 1)))
+        if bias:
+            self.register_parameter("bias", nn.Parameter(torch.randn(*batch_shape, 1)))
+        else:
+            self.bias = None
+
+    def forward(self, x):
+        if x.ndim == 1:
+            x = x.unsqueeze(-1)
+        res = x.matmul(self.weights).squeeze(-1)
+        if self.bias is not None:
+            res = res + self.bias
+        return res
+
+
+class MultivariateNormal:
+    """gpytorch.distributions.MultivariateNormal stand-in (VoltMagpie.py:127)."""
+
+    def __init__(self, mean, covariance_matrix):
+        self.loc = mean
+        self._covar = covariance_matrix
+
+    @property
+    def mean(self):
+        return self.loc
+
+    @property
+    def covariance_matrix(self):
+        return _dense(self._covar)
+
+    @property
+    def lazy_covariance_matrix(self):
+        return self._covar if isinstance(self._covar, _Evaluated) else _Evaluated(self._covar)
+
+    @property
+    def variance(self):
+        return torch.diagonal(self.covariance_matrix, dim1=-2, dim2=-1)
+
+    def rsample(self, sample_shape=torch.Size(), base_samples=None):
+        cov = self.covariance_matrix
+        L = psd_safe_cholesky(cov)
+        shape = torch.Size(sample_shape) + self.loc.shape
+        if base_samples is None:
+            base_samples = torch.randn(shape, dtype=self.loc.dtype, device=self.loc.device)
+        return self.loc + (L @ base_samples.unsqueeze(-1)).squeeze(-1)
+
+    def sample(self, sample_shape=torch.Size(), base_samples=None):
+        with torch.no_grad():
+            return self.rsample(sample_shape, base_samples)
+
+
+# --------------------------------------------------------------------------------- likelihood
+class _NoiseCovar(Module):
+    def __init__(self, batch_shape):
+        super().__init__()
+        self.register_parameter("raw_noise", nn.Parameter(torch.zeros(*batch_shape, 1)))
+
+
+class GaussianLikelihood(Module):
+    """noise = softplus(raw_noise) + 1e-4  (gpytorch default GreaterThan(1e-4) constraint).
+    ``likelihood.raw_noise.data = torch.tensor([1e-5])`` (train_utils.py:222) => noise ~= 0.6933."""
+    NOISE_FLOOR = 1e-4
+
+    def __init__(self, batch_shape=torch.Size(), **kwargs):
+        super().__init__()
+        self.noise_covar = _NoiseCovar(batch_shape)
+
+    @property
+    def raw_noise(self):
+        return self.noise_covar.raw_noise
+
+    @raw_noise.setter
+    def raw_noise(self, value):
+        self.noise_covar.raw_noise = value
+
+    @property
+    def noise(self):
+        return F.softplus(self.noise_covar.raw_noise) + self.NOISE_FLOOR
+
+    @noise.setter
+    def noise(self, value):
+        value = torch.as_tensor(value, dtype=self.raw_noise.dtype, device=self.raw_noise.device)
+        v = (value - self.NOISE_FLOOR).clamp_min(1e-12).expand_as(self.raw_noise)
+        with torch.no_grad():
+            self.noise_covar.raw_noise.copy_(v + torch.log(-torch.expm1(-v)))    # inverse softplus
+
+    def forward(self, function_dist):
+        """p(y|f): add the noise to the diagonal (dense; used outside the fused MLL only)."""
+        cov = function_dist.covariance_matrix
+        n = cov.shape[-1]
+        noise = self.noise.reshape(*self.noise.shape[:-1], 1, 1)
+        return MultivariateNormal(function_dist.mean, cov + noise * torch.eye(n, dtype=cov.dtype, device=cov.device))
+
+
+
+# -------------------------------------------------------------------------------------- model
+class ExactGP(Module):
+    """gpytorch.models.ExactGP stand-in.  Registers ``likelihood`` first (so it is parameter 0 for
+    the positional grad_flags of train_utils.py:226), stores 1-D inputs as [N,1] and passes
+    unsqueezed inputs to ``forward`` exactly like gpytorch does."""
+
+    def __init__(self, train_inputs, train_targets, likelihood):
+        super().__init__()
+        self.likelihood = likelihood
+        if train_inputs is not None and torch.is_tensor(train_inputs):
+            train_inputs = (train_inputs,)
+        self.train_inputs = None if train_inputs is None else tuple(
+            t.unsqueeze(-1) if t.ndimension() == 1 else t for t in train_inputs)
+        self.train_targets = train_targets
+
+    def __call__(self, *args, **kwargs):
+        inputs = [a.unsqueeze(-1) if torch.is_tensor(a) and a.ndimension() == 1 else a for a in args]
+        if self.training:
+            return self.forward(*inputs, **kwargs)
+        return self.posterior_call(*inputs, **kwargs)
+
+    def posterior_call(self, *inputs, **kwargs):
+        raise NotImplementedError(
+            f"{type(self).__name__}: eval-mode model(x) (generic gpytorch posterior) is outside the accelerated path; "
+            "use GeneratePrediction / Rollouts (voltron/rollout_utils.py) which this package does implement")
+
+
+# --------------------------------------------------------------------------------------- MLL
+class _ExactMLL(torch.autograd.Function):
+    """mll[b] = log N(y_b; m_b, K_b + s2_b I) / N  with analytic backward:
+    d/d s2 = 1/2 (a'a - tr K_s^-1)/N,  d/d m = a/N,  d/d y = -a/N,  a = K_s^-1 (y - m)."""
+
+    @staticmethod
+    def forward(ctx, K, mean, noise, target, holder):
+        if K.requires_grad:
+            raise NotImplementedError("the volatility covariance has no trainable parameters on this path "
+                                      "(train_cov is detached, VoltMagpie.py:46); K.requires_grad is unsupported")
+        B, n = mean.shape
+        need_grad = any(ctx.needs_input_grad[1:4])
+        ws = holder.workspace(B, n, need_grad, K.device)
+        resid = (target - mean).to(torch.float32)
+        jitter = 0.0
+        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter)
+        bad = int((info != 0).sum().item())
+        if bad:
+            if torch.isnan(K).any() or torch.isnan(resid).any():
+                raise NanError("cholesky: NaN in the covariance or the residual")
+            raise NotPSDError(f"K + sigma^2 I not positive definite for {bad} of {B} series "
+                              f"(first failing pivot {int(info[info != 0][0].item())})")
+        ctx.n = n
+        if need_grad:
+            ctx.save_for_backward(out[:, 1].clone(), alpha.clone())
+        return out[:, 0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dsig, alpha = ctx.saved_tensors
+        gm = g.unsqueeze(-1) * alpha / ctx.n
+        return None, gm, g * dsig, -gm, None
+
+
+class ExactMarginalLogLikelihood(Module):
+    """gpytorch.mlls.ExactMarginalLogLikelihood stand-in: ``mll(model(x), y)`` returns the marginal
+    log likelihood divided by the number of data points (a scalar, or [T] for a batched model)."""
+
+    def __init__(self, likelihood, model):
+        super().__init__()
+        # plain attributes: gpytorch registers both as submodules, but nobody iterates mll.parameters()
+        object.__setattr__(self, "likelihood", likelihood)
+        object.__setattr__(self, "model", model)
+        self._ws = None
+
+    def workspace(self, B, n, want_grad, device):
+        ws = self._ws
+        if ws is None or ws.B != B or ws.N != n or ws.want_grad != bool(want_grad) or ws.buf.device != device:
+            self._ws = ws = ops.MllWorkspace(B, n, want_grad, device)
+        return ws
+
+    def forward(self, function_dist, target):
+        mean = function_dist.mean
+        K = function_dist.covariance_matrix
+        batched = mean.ndim > 1
+        n = mean.shape[-1]
+        mean2, K3, t2 = mean.reshape(-1, n), K.reshape(-1, n, n), target.reshape(-1, n)
+        if not K3.is_cuda:
+            raise ops._lib.VoltHipError("ExactMarginalLogLikelihood: tensors must live on the MI355X; no CPU fallback")
+        noise = self.likelihood.noise.reshape(-1)
+        noise = noise.expand(mean2.shape[0]) if noise.numel() == 1 else noise
+        res = _ExactMLL.apply(K3, mean2.to(torch.float32), noise.to(torch.float32), t2.to(torch.float32), self)
+        return res.reshape(mean.shape[:-1]) if batched else res.reshape(())
+
+
+# -------------------------------------------------------------------------- psd_safe_cholesky
+def psd_safe_cholesky(A, upper=False, out=None, jitter=None, max_tries=3):
+    """gpytorch.utils.cholesky.psd_safe_cholesky on the HIP potrf: try once; on a non-positive
+    pivot add jitter * 10^i (i = 0..max_tries-1; default 1e-6 fp32 / 1e-8 fp64) to the diagonal and
+    retry, warning like gpytorch; raise NanError / NotPSDError otherwise.  Returns dense L."""
+    f, _ = _safe_factor(A, jitter, max_tries)
+    L = f.L.reshape(A.shape)
+    return L.transpose(-1, -2) if upper else L
+
+
+def _safe_factor(A, jitter=None, max_tries=3):
+    n = A.shape[-1]
+    A3 = A.reshape(-1, n, n).to(torch.float32)
+    f = ops.potrf(A3)
+    if not bool((f.info != 0).any().item()):
+        return f, 0.0
+    if torch.isnan(A3).any():
+        raise NanError(f"cholesky_cpu: {int(torch.isnan(A3).sum())} of {A3.numel()} elements of the {tuple(A.shape)} tensor are NaN.")
+    if jitter is None:
+        jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
+    for i in range(max_tries):
+        jitter_new = jitter * (10 ** i)
+        f = ops.potrf(A3, jitter=jitter_new)
+        if not bool((f.info != 0).any().item()):
+            warnings.warn(f"A not p.d., added jitter of {jitter_new:.1e} to the diagonal", NumericalWarning)
+            return f, jitter_new
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitter_new:.1e}.")
+
+
+LOG_2PI = math.log(2 * math.pi)

@@ -1,0 +1,46 @@
+"""Volatility kernel -- drop-in for voltron/kernels/VolKernel.py, arithmetic in libvolt_hip.so.
+
+    K[..., i, j] = V[..., min(i, j)],   V = CumTrapz(vol_path**2, x)
+
+Reference quirks kept on purpose (hard part 5): the second positional argument of
+``forward`` is the *volatility path*, not a second set of inputs; CumTrapz halves the first AND
+last weight and takes dx = x[1]-x[0] (uniform grid assumed); inputs of trailing size 1 are
+``squeeze()``d.  What is not kept: the int64 [N,N] index the reference rebuilds on the CPU on
+every call (VolKernel.py:30-32) -- the fill kernel computes min(i,j) in registers.
+"""
+import torch
+
+from .. import ops
+from ..gp import Kernel
+
+
+def CumTrapz(y, x):
+    """voltron/kernels/VolKernel.py:4-10 (bit-exact with its CPU result)."""
+    return ops.cumtrapz(y, x, square=False)
+
+
+class VolatilityKernel(Kernel):
+    has_lengthscale = False
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+    def forward(self, x, vol_path, diag=False, **params):
+        if x.shape[-1] == 1:
+            x = x.squeeze()                      # VolKernel.py:19-22 (squeeze() drops every unit dim)
+        if vol_path.shape[-1] == 1:
+            vol_path = vol_path.squeeze()
+
+        last_dim_is_batch = params.get("last_dim_is_batch", False)
+        if last_dim_is_batch:
+            vol_path = vol_path.transpose(-1, -2)
+
+        vol_int = ops.cumtrapz(vol_path, x, square=True)          # CumTrapz(vol_path * vol_path, x), :28
+        if diag:
+            if last_dim_is_batch:
+                raise NotImplementedError("diag with last_dim_is_batch (reference marks this branch 'TODO: check this')")
+            return vol_int                                        # diagonal of V[min(i,j)] is V, :39-40
+        res = ops.fill(vol_int)                                   # :30-33
+        if last_dim_is_batch:
+            res = res.permute(1, 2, 0)                            # :35-37, mirrored as written
+        return res

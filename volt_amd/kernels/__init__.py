@@ -1,0 +1,2 @@
+from .BMKernel import BMKernel                       # voltron/kernels/__init__.py:1-5 (hot-path subset)
+from .VolKernel import VolatilityKernel, CumTrapz

@@ -1,0 +1,45 @@
+"""Brownian-motion GP over the log-volatility path -- voltron/models/BMGP.py:9-28.
+
+SURVEY 8(f) row 1: it supplies ``pred_vol`` at voltron/rollout_utils.py:66 through
+``model.vol_model(test_x).sample(...)``.  Training-mode call -> prior MVN (for an MLL); eval-mode
+call -> exact-GP posterior at the test points, computed with the same HIP Cholesky / triangular
+inverse as the data model (K_s^-1 = Y Y^T, Y = L^-T) plus two plain library matmuls.
+The botorch-based MultitaskBMGP (:30-56) is out of scope.
+"""
+import torch
+
+from .. import ops
+from ..gp import ExactGP, MultivariateNormal, _safe_factor
+from ..kernels.BMKernel import BMKernel
+
+
+class BMGP(ExactGP):
+    def __init__(self, train_x, train_y, likelihood, kernel="bm"):
+        super().__init__(train_x, train_y, likelihood)
+        if kernel != "bm":
+            raise NotImplementedError("only the Brownian-motion kernel is provided (FBMKernel is out of scope)")
+        self.covar_module = BMKernel().to(train_x.device)
+        self.scaling = (train_x[1] - train_x[0])
+
+    def mean_module(self, x):
+        return -0.5 * self.covar_module.vol.pow(2.0) * x.squeeze()        # BMGP.py:20-21
+
+    def forward(self, x):
+        return MultivariateNormal(self.mean_module(x), self.covar_module(x))
+
+    def posterior_call(self, x):
+        with torch.no_grad():
+            xt = self.train_inputs[0]
+            y = self.train_targets
+            n = xt.shape[0]
+            Ktt = self.covar_module.forward(xt, xt)
+            noise = self.likelihood.noise.reshape(-1)[:1]
+            A = (Ktt + noise * torch.eye(n, device=xt.device)).unsqueeze(0)
+            f, _ = _safe_factor(A)
+            Y = ops.trtri(f)[0]                                           # L^-T
+            Kst = self.covar_module.forward(x, xt)                        # [H,N]
+            G = Kst @ Y                                                    # K_*t L^-T
+            r = (y - self.mean_module(xt)).to(torch.float32)
+            mean = self.mean_module(x) + G @ (Y.t() @ r)
+            cov = self.covar_module.forward(x, x) - G @ G.t()
+            return MultivariateNormal(mean, cov)

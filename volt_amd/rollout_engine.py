@@ -1,0 +1,167 @@
+"""Host side of the bordered rollout engine (csrc/rollout.hip, DESIGN.md "Rollouts").
+
+Per series, once:  U = CumTrapz weights with the LAST train weight un-halved (the halving moves to
+the test point, VolKernel.py:8-9 applied to the stacked path of rollout_utils.py:17-20), K_NN =
+fill(U), L = potrf(K_NN) with the psd_safe_cholesky jitter policy (:35), q = L^-1 u, z_tr = L^-1
+r_tr, rho = q'q, tau = q'z_tr.  Then ONE kernel launch walks all H horizon steps for every sample.
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from . import _lib, ops
+from .gp import NumericalWarning, _safe_factor
+from .means import DEWMAMean, EWMAMean, MeanRevertingEMAMean, TEWMAMean
+
+_MODES = {EWMAMean: 0, DEWMAMean: 1, TEWMAMean: 2, MeanRevertingEMAMean: 3}
+
+
+def _tail(series: torch.Tensor, k: int) -> torch.Tensor:
+    """Last k entries of `series` left-padded with its first value (the conv padding of EWMA.py:27-28)."""
+    n = series.shape[-1]
+    if n >= k:
+        return series[..., n - k:].contiguous()
+    pad = series[..., :1].expand(*series.shape[:-1], k - n)
+    return torch.cat((pad, series), -1).contiguous()
+
+
+def _refined_solve(K, fct, rhs, jitter_used=0.0, iters=30, tol=1e-12):
+    """x = (K + jitter I)^-1 rhs to fp64 accuracy: conjugate gradients in fp64 on the device,
+    preconditioned by the fp32 HIP Cholesky factor (two triangular solves per iteration; the fp64
+    K p products are plain library matmuls).  With the factor as preconditioner the spectrum of the
+    preconditioned operator is clustered at 1 even when cond(K) eps_32 > 1, so a handful of
+    iterations suffice where plain iterative refinement would stall."""
+    Kd = K.double()
+    b = rhs.double()
+
+    def matvec(v):
+        out = torch.matmul(Kd, v.unsqueeze(-1)).squeeze(-1)
+        return out + jitter_used * v if jitter_used else out
+
+    def prec(r):
+        scale = r.abs().amax(-1, keepdim=True).clamp_min(1e-300)        # keep fp32 solves in range
+        return ops.cholesky_solve(fct, (r / scale).float()).double() * scale
+
+    x = prec(b)
+    r = b - matvec(x)
+    zv = prec(r)
+    pdir = zv.clone()
+    rz = (r * zv).sum(-1, keepdim=True)
+    bnorm = b.norm(dim=-1, keepdim=True).clamp_min(1e-300)
+    for _ in range(iters):
+        if bool(((r.norm(dim=-1, keepdim=True) / bnorm) < tol).all()):
+            break
+        Ap = matvec(pdir)
+        alpha = rz / (pdir * Ap).sum(-1, keepdim=True)
+        x = x + alpha * pdir
+        r = r - alpha * Ap
+        zv = prec(r)
+        rz_new = (r * zv).sum(-1, keepdim=True)
+        pdir = zv + (rz_new / rz) * pdir
+        rz = rz_new
+    return x
+
+
+def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode, k, latent_mean=None, theta=None,
+                   mr_theta=0.5, mr_latent=None, jitter=1e-4):
+    """Batched engine entry.  train_x [N]; log_y, log_vol_path [G,N]; test_x [H]; pred_vol, z [G,S,H].
+    Returns (samples [G,S,H] on the device, info [G,S])."""
+    dev = train_x.device
+    G, N = log_y.shape
+    S, H = pred_vol.shape[-2:]
+    f32 = torch.float32
+    vol = log_vol_path.exp().to(f32)
+    x = train_x.to(f32)
+    dx = (x[1] - x[0]).reshape(1).expand(G).contiguous()
+    # U: CumTrapz over [train, first test point] keeps full weight on train point N-1
+    xe = torch.cat((x, test_x[:1].to(f32)))
+    U = ops.cumtrapz(torch.cat((vol, vol[:, -1:]), -1), xe, square=True)[:, :N].contiguous()
+    wts = torch.full((N,), 1.0, device=dev, dtype=f32) * (x[1] - x[0])
+    wts[0] *= 0.5
+    acc0 = (wts * (vol * vol)).double().sum(-1).contiguous()                  # fp64 running sum through N-1
+    K = ops.fill(U)
+    fct, used = _safe_factor(K, jitter)                                        # psd_safe_cholesky(K_tr, 1e-4), :35
+    # train residuals with the model's mean family
+    w = ops.ewma_weights(k, dev)
+    ema = ops.ewma(log_y, k)                                                   # [G,N+1]
+    hist_e1 = hist_e2 = ema_prev = mrl = None
+    if mean_mode == 0:
+        m_tr = ema[:, :-1]
+    elif mean_mode == 1:
+        ee = ops.ewma(ema, k)[:, :-1]                                          # [G,N+1]
+        m_tr = (2 * ema - ee)[:, :-1]
+        hist_e1, hist_e2 = _tail(ema[:, :-1], k), None
+    elif mean_mode == 2:
+        ee = ops.ewma(ema, k)[:, :-1]
+        eee = ops.ewma(ee, k)[:, :-1]
+        m_tr = (3 * ema - 3 * ee + eee)[:, :-1]
+        hist_e1, hist_e2 = _tail(ema[:, :-1], k), _tail(ee[:, :-1], k)
+    elif mean_mode == 3:
+        mrl = (log_y.mean(-1) if mr_latent is None else mr_latent.reshape(-1).expand(G)).to(f32).contiguous()
+        em = ema.clone()
+        em[:, 1:] -= mr_theta * (ema[:, :-1] - mrl[:, None])
+        m_tr = em[:, :-1]
+        ema_prev = ema[:, N - 1].contiguous()
+    else:
+        raise ValueError("mean_mode")
+    r_tr = (log_y.to(f32) - m_tr).contiguous()
+    # rho = u'K^-1 u and tau = u'K^-1 r_tr enter every sample's Schur complement C_s - rho 11', whose
+    # entries are ~dx vol^2 while rho ~ V[N-1]: they must be accurate far beyond fp32 round-off times
+    # cond(K_NN) (1e6 at N=400, 1e8 at N=4096).  One K^-1 u solve, refined in fp64.
+    xu = _refined_solve(K, fct, U, used)
+    rho = (U.double() * xu).sum(-1).to(f32).contiguous()
+    tau = (r_tr.double() * xu).sum(-1).to(f32).contiguous()
+    hist_y = _tail(log_y.to(f32), k)
+
+    samples = torch.empty(G, S, H, dtype=f32, device=dev)
+    info = torch.empty(G, S, dtype=torch.int32, device=dev)
+    nbytes = _lib.lib().volt_rollout_scratch_bytes(G, S, H)
+    scratch = torch.empty(nbytes // 4, dtype=f32, device=dev)
+    lat = None
+    if theta is not None:
+        lat = torch.as_tensor(latent_mean, dtype=f32, device=dev).reshape(-1).expand(G).contiguous()
+    pv = pred_vol.to(f32).contiguous()
+    zz = z.to(f32).contiguous()
+
+    def P(t):
+        return None if t is None else t.data_ptr()
+    _lib.check(_lib.lib().volt_rollout_bordered_f32(
+        P(rho), P(tau), P(acc0), P(dx), P(hist_y), P(hist_e1), P(hist_e2), P(ema_prev), P(mrl), P(lat), P(w),
+        P(pv), P(zz), P(samples), P(scratch), P(info), G, S, H, k, mean_mode, int(theta is not None),
+        float(theta or 0.0), float(mr_theta), float(jitter), _lib.stream_ptr()), "volt_rollout_bordered")
+    return samples, info
+
+
+def rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean, theta):
+    """Rollouts(..., engine="bordered"): same inputs / outputs / model mutation as rollout_utils.Rollouts."""
+    mm = model.mean_module
+    if type(mm) not in _MODES:
+        raise NotImplementedError(f"bordered rollouts support the EWMA mean family, got {type(mm).__name__}; "
+                                  "use engine='dense'")
+    S, H = pred_vol.shape
+    if z is None:
+        z = torch.randn(S, H, device=train_x.device)
+    if model.log_vol_path.ndim != 1:
+        raise NotImplementedError("Rollouts expects an unbatched model (rollout_utils.py:71-72 repeats its state)")
+    log_y = train_y[1:].log()
+    kw = {}
+    if isinstance(mm, MeanRevertingEMAMean):
+        kw = dict(mr_theta=mm.theta, mr_latent=mm.latent_mean)
+    samples, info = rollout_series(train_x, log_y.unsqueeze(0), model.log_vol_path.unsqueeze(0), test_x,
+                                   pred_vol.unsqueeze(0), z.unsqueeze(0), _MODES[type(mm)], mm.k,
+                                   latent_mean, theta, **kw)
+    bad = info[0] != 0
+    if bool(bad.any()):
+        warnings.warn(f"rollouts: {int(bad.sum())} of {S} sample paths hit a non-positive pivot "
+                      f"(first at horizon step {int(info[0][bad].min())}); jitter was applied", NumericalWarning)
+    samples = samples[0]
+    # leave the model in the state the reference leaves it in (rollout_utils.py:80-86, last idx = H-1)
+    if H > 1:
+        stack_y = torch.cat((log_y.repeat(S, 1), samples[:, :H - 1]), -1)
+        stack_vol = torch.cat((model.log_vol_path.repeat(S, 1), pred_vol[:, :H - 1].log()), -1)
+        rolling_x = torch.cat((train_x, test_x[:H - 1]))
+        mm.train_y, mm.train_x = stack_y, rolling_x
+        model.train_x, model.train_y, model.log_vol_path = rolling_x, stack_y, stack_vol
+    return samples.cpu()

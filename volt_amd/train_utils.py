@@ -1,0 +1,143 @@
+"""Training loops of the exact-GP data model -- drop-in for the two ★ loops of
+voltron/train_utils.py (TrainDataModel :98-144, TrainVoltMagpieModel :192-257).
+
+The loop bodies are the reference's, statement for statement: ``optimizer.zero_grad(); output =
+voltron(train_x); loss = -mll(output, y); loss.backward(); optimizer.step()``.  What changes is
+what runs underneath: ``mll`` is volt_amd.gp.ExactMarginalLogLikelihood, one fused HIP step with
+an analytic backward.  LearnGPCV / TrainVolModel / TrainBasicModel (variational ELBO, BM-kernel
+GP, Matern/SM baselines) are outside the accelerated path.
+
+``TrainVoltMagpieBatch`` is an addition for the multi-series case the reference only loops over
+in Python (experiments/stocks/ForecastGenerator.py:27-41): B independent series in one batched
+step, optionally sharded over ranks with one all-reduce of the summed loss.
+"""
+import torch
+
+from . import gp
+from .gp import ExactMarginalLogLikelihood, GaussianLikelihood
+from .means import LogLinearMean, EWMAMean, DEWMAMean, TEWMAMean, MeanRevertingEMAMean
+from .models import VoltronGP, VoltMagpie
+
+
+def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False):
+    voltron_lh = GaussianLikelihood().to(train_x.device)
+    voltron = VoltronGP(train_x, train_y.log(), voltron_lh, vol_path)
+    voltron.mean_module = LogLinearMean(1).to(train_x.device)
+    voltron.mean_module.initialize_from_data(train_x, train_y.log())
+    voltron.likelihood.raw_noise.data = torch.tensor([1e-5]).to(train_x.device)
+    voltron.vol_lh = vol_lh
+    voltron.vol_model = vol_model
+
+    grad_flags = [True, True, True, False, False, False]
+
+    for idx, p in enumerate(voltron.parameters()):
+        p.requires_grad = grad_flags[idx]
+
+    voltron.train()
+    voltron_lh.train()
+
+    optimizer = torch.optim.Adam([{'params': voltron.parameters()}], lr=0.1)
+    mll = ExactMarginalLogLikelihood(voltron_lh, voltron)
+
+    print_every = 50
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        output = voltron(train_x)
+        loss = -mll(output, train_y.log())
+        loss.backward()
+        if printing:
+            if i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
+        optimizer.step()
+
+    return voltron, voltron_lh
+
+
+def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, k=25,
+                         theta=0.5, mean_func="ewma"):
+    voltron_lh = GaussianLikelihood().to(train_x.device)
+    voltron = VoltMagpie(train_x, train_y.log(), voltron_lh, vol_path, k=k).to(train_x.device)
+
+    if mean_func.lower() in ["ewma", "dewma", "tewma", "meanrevert"]:
+        # default voltmagpie is an ewma mean so we don't need to redefine anything
+        grad_flags = [True, False, False, False]
+
+        if mean_func.lower() == "dewma":
+            voltron.mean_module = DEWMAMean(train_x, train_y.log(), k).to(train_x.device)
+        elif mean_func.lower() == 'tewma':
+            voltron.mean_module = TEWMAMean(train_x, train_y.log(), k).to(train_x.device)
+        elif mean_func.lower() == 'meanrevert':
+            voltron.mean_module = MeanRevertingEMAMean(train_x, train_y.log(), k, theta).to(train_x.device)
+
+    elif mean_func.lower() == 'constant':
+        voltron.mean_module = gp.ConstantMean().to(train_x.device)
+        grad_flags = [True, True, False, False, False]
+    elif mean_func.lower() == 'loglinear':
+        voltron.mean_module = LogLinearMean(1).to(train_x.device)
+        voltron.mean_module.initialize_from_data(train_x, train_y.log())
+        grad_flags = [True, True, True, False, False, False]
+    elif mean_func.lower() == 'linear':
+        voltron.mean_module = gp.LinearMean(1).to(train_x.device)
+        grad_flags = [True, True, True, False, False, False]
+
+    voltron.likelihood.raw_noise.data = torch.tensor([1e-5]).to(train_x.device)
+    if vol_lh is not None:
+        voltron.vol_lh = vol_lh.to(train_x.device)
+    if vol_model is not None:
+        voltron.vol_model = vol_model.to(train_x.device)
+
+    for idx, p in enumerate(voltron.parameters()):
+        p.requires_grad = grad_flags[idx]
+
+    voltron.train()
+    voltron_lh.train()
+
+    optimizer = torch.optim.Adam([{'params': voltron.parameters()}], lr=0.1)
+    mll = ExactMarginalLogLikelihood(voltron_lh, voltron)
+
+    print_every = 50
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        output = voltron(train_x)
+        loss = -mll(output, train_y.log())
+        loss.backward()
+        if printing:
+            if i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
+        optimizer.step()
+
+    return voltron, voltron_lh
+
+
+def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, printing=False, process_group=None,
+                         shared_noise=False):
+    """B independent series in one batched model (train_y [B,N] raw prices[1:], vol_path [B,N]).
+    Per-series raw_noise by default (each series is its own GP, as in the reference's Python loop over
+    tickers); ``shared_noise`` ties one likelihood across series AND ranks, whose gradient is then
+    all-reduced.  Returns (model, likelihood, last per-series losses)."""
+    from . import distributed as vdist
+    B = train_y.shape[0]
+    lh = GaussianLikelihood(batch_shape=torch.Size() if shared_noise else torch.Size([B])).to(train_x.device)
+    model = VoltMagpie(train_x, train_y.log(), lh, vol_path, k=k).to(train_x.device)
+    lh.raw_noise.data.fill_(1e-5)
+    for p in model.parameters():
+        p.requires_grad = False
+    lh.raw_noise.requires_grad = True
+    model.train()
+    optimizer = torch.optim.Adam([lh.raw_noise], lr=0.1)
+    mll = ExactMarginalLogLikelihood(lh, model)
+    losses = None
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        output = model(train_x)
+        losses = -mll(output, train_y.log())
+        loss = losses.sum()
+        loss.backward()
+        total = vdist.all_reduce_scalars(torch.stack([loss.detach(), torch.tensor(float(B), device=loss.device)]),
+                                         process_group)
+        if shared_noise:
+            vdist.all_reduce_(lh.raw_noise.grad, process_group)
+        if printing and i % 50 == 0:
+            print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, (total[0] / total[1]).item()))
+        optimizer.step()
+    return model, lh, losses.detach()
