@@ -111,10 +111,14 @@ int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* 
                               int use_theta, float theta, float mr_theta, float jitter, void* stream);
 
 /* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
- * Runs volt_potrf_f32 (and, if Y != NULL, volt_trtri_f32) with every launch bracketed by HIP events
- * on `stream`, synchronises, and writes to HOST arrays the summed milliseconds and launch counts
- * per kernel class: [0] potrf_update (P1), [1] potrf_diag (P2), [2] potrf_trsm (P3), [3] trtri_row. */
-int volt_profile_factor_f32(float* A, float* Winv, float* Y, int* info, int B, int Np, void* stream,
+ * Runs exactly the factorisation of volt_mll_step_f32 (block column 0 copied from K, the rest read from
+ * K inside the panel update; with Y != NULL also the triangular inverse, co-launched with the diagonal
+ * blocks) with every launch bracketed by HIP events on `stream`, synchronises, and writes to HOST
+ * arrays the summed milliseconds and launch counts per kernel class:
+ *   [0] potrf_update (P1)   [1] diag_trtri (P2(k) + trtri row k-1 in one grid)   [2] potrf_trsm (P3)
+ *   [3] trtri row n-1 alone. */
+int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A,
+                            float* Winv, float* Y, int* info, int B, int N, void* stream,
                             float* ms_host /*[4]*/, int* launches_host /*[4]*/);
 
 /* Tuning hook (scripts/tune_gemm.py): launches the P1 panel-update kernel of step k `reps` times in

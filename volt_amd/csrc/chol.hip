@@ -24,15 +24,19 @@ namespace volt {
 // A = tril-tiles(K) + (sigma2 + jitter) I, identity in the padding.  Tile (ti,tj), tj <= ti.
 __global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ K, int64_t ldk, int64_t bsk,
                                                       const float* __restrict__ sigma2, float jitter,
-                                                      float* __restrict__ A, int N, int Np) {
-    const int n = Np / TS;
-    // linear lower-triangular tile index -> (ti, tj)
+                                                      float* __restrict__ A, int N, int Np, int col0_only) {
+    // linear lower-triangular tile index -> (ti, tj); col0_only: just the first block column
     int t = blockIdx.x;
-    int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    const int tj = t - ti * (ti + 1) / 2;
-    (void)n;
+    int ti, tj;
+    if (col0_only) {
+        ti = t;
+        tj = 0;
+    } else {
+        ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    }
     const int b = blockIdx.y;
     const float add = (sigma2 ? sigma2[b] : 0.f) + jitter;
     const float* Kb = K + (int64_t)b * bsk;
@@ -62,8 +66,19 @@ __global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ 
 // grid.x = (n-k) * B.  Tile t: rows of block (k+t), columns of block k.
 // The C tile is loaded into registers BEFORE the K loop (its 64 KB per workgroup would otherwise
 // be an un-overlapped read-modify-write at the end: measured 51 -> 83 TF/s at k = 1, 115 -> 125 at
-// k = 16) and only stored in the epilogue.
-__global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict__ A, int Np, int k, int B) {
+// k = 16) and only stored in the epilogue.  FROMK: the C tile comes straight from the caller's
+// K (+ sigma2/jitter on the diagonal, identity in the padding) instead of a prepared copy in A, which
+// removes the K -> A copy pass for every block column but the first.
+struct KSource {
+    const float* K;
+    int64_t ldk, bsk;
+    const float* sigma2;
+    float jitter;
+    int N;
+};
+
+template <bool FROMK>
+__global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict__ A, int Np, int k, int B, KSource src) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     int t, b;
     decode_tile_batch(Np / TS - k, B, t, b);
@@ -75,6 +90,8 @@ __global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict_
     float* C = Ab + (int64_t)(k + t) * TS * Np + (int64_t)k * TS;
     f32x16 acc[4], cpre[4];
     zero_acc(acc);
+    const float add = FROMK ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
+    const float* Kb = FROMK ? src.K + (int64_t)b * src.bsk : nullptr;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -83,7 +100,14 @@ __global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict_
             for (int q = 0; q < 16; ++q) {
                 const int r = wr * 64 + tm * 32 + accrow(q, lane);
                 const int c = wc * 64 + tn * 32 + (lane & 31);
-                cpre[tm * 2 + tn][q] = C[(int64_t)r * Np + c];
+                if (FROMK) {
+                    const int gi = (k + t) * TS + r, gj = k * TS + c;
+                    float v = (gi < src.N && gj < src.N) ? Kb[(int64_t)gi * src.ldk + gj] : 0.f;
+                    if (gi == gj) v = (gi < src.N) ? v + add : 1.f;
+                    cpre[tm * 2 + tn][q] = v;
+                } else {
+                    cpre[tm * 2 + tn][q] = C[(int64_t)r * Np + c];
+                }
             }
     gemm_nt_128<0>(Arows, Np, Brows, Np, k * (TS / BK), acc, smem);
 #pragma unroll
@@ -109,12 +133,13 @@ __global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict_
 // group's own block row/column needs a lane mask.  Columns of L are kept in LDS (transposed,
 // lane-permuted) for the second phase, W = L^-1 by forward substitution with the same machinery.
 // LDS element order inside a 128-vector: index (i%16)*8 + i/16, i.e. a thread's 8 entries are contiguous.
-__global__ __launch_bounds__(256) void potrf_diag_kernel(float* __restrict__ A, float* __restrict__ Winv,
-                                                         int* __restrict__ info, int Np, int k) {
-    __shared__ __attribute__((aligned(16))) float sLT[TS * TS];   // [j][perm(i)] = L[i][j]
-    __shared__ __attribute__((aligned(16))) float bc[2][TS];
-    __shared__ float sRinv[TS];
-    const int b = blockIdx.x;
+constexpr int DIAG_LDS_FLOATS = TS * TS + 2 * TS + TS;          // 67,072 B, fits the GEMM staging area
+
+__device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
+                                          int Np, int k, int b, float* smem) {
+    float* sLT = smem;                                   // [j][perm(i)] = L[i][j]
+    float (*bc)[TS] = reinterpret_cast<float (*)[TS]>(smem + TS * TS);
+    float* sRinv = smem + TS * TS + 2 * TS;
     const int n = Np / TS;
     float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     float* W = Winv + ((int64_t)b * n + k) * TS * TS;
@@ -379,17 +404,26 @@ __global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const float* __restr
 // grid.x = (i+1) * B (tile j = 0..i; j == i copies W_i^T).
 constexpr int WLD = TS + 4;    // 132-float rows: b128 reads of 16 rows land on 16 distinct slots
 
-__global__ __launch_bounds__(256) void trtri_row_kernel(const float* __restrict__ A, const float* __restrict__ Winv,
-                                                        float* __restrict__ Y, int Np, int i, int B) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];   // 73,728 B >= 128*132*4
+// Optional reductions fused into the trtri epilogue (the MLL step needs z = Y'r and ||Y||_F^2; doing
+// them here saves a full pass over Y): zpart[b][j][i*128 + r] = sum_c Y[j*128+c][i*128+r] rvec[j*128+c],
+// frob[b][tile(j,i)] = sum of squares over rows < N.  Deterministic, no atomics.
+struct TriReduce {
+    const float* rpad;   // [B,Np] residual, zero padded; nullptr = no reductions
+    float* zpart;        // [B,n,Np]
+    float* frob;         // [B,n(n+1)/2]
+    int N;
+};
+
+__device__ __forceinline__ void trtri_body(const float* __restrict__ A, const float* __restrict__ Winv,
+                                           float* __restrict__ Y, int Np, int i, int j, int b, TriReduce red,
+                                           float* smem) {
     const int n = Np / TS;
-    int j, b;
-    decode_tile_batch(i + 1, B, j, b);
     const float* Ab = A + (int64_t)b * Np * Np;
     float* Yb = Y + (int64_t)b * Np * Np;
     const float* W = Winv + ((int64_t)b * n + i) * TS * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
+    const int tile_id = i * (i + 1) / 2 + j;             // upper-tile enumeration (cb = i, jb = j)
 
     if (j == i) {
         // diagonal tile: Y[i,i] = W_i^T (transposed through LDS so both sides stay coalesced)
@@ -403,36 +437,92 @@ __global__ __launch_bounds__(256) void trtri_row_kernel(const float* __restrict_
             const int c = e >> 7, r = e & 127;          // Y row c, column r
             Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
         }
+        if (red.rpad) {
+            float* sred = smem + TS * WLD;               // 128 floats behind the W image
+            float fz = 0.f, ff = 0.f;
+            if (tid < TS) {
+                const float* rv = red.rpad + (int64_t)b * Np + i * TS;
+                for (int c = 0; c <= tid; ++c) {         // column r = tid of Y: entries W[r][c], c <= r
+                    const float y = smem[tid * WLD + c];
+                    fz += y * rv[c];
+                    if (i * TS + c < red.N) ff += y * y;
+                }
+                red.zpart[((int64_t)b * n + i) * Np + i * TS + tid] = fz;
+                sred[tid] = ff;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const float tot = wave_sum_f(sred[tid] + sred[tid + 64]);
+                if (tid == 0) red.frob[(int64_t)b * (n * (n + 1) / 2) + tile_id] = tot;
+            }
+        }
         return;
     }
 
-    // phase 1 uses the whole staging area; W_i is staged into the same LDS afterwards (the two do
-    // not fit side by side at 2 workgroups per CU).
-    f32x16 T[4];
+    // One software pipeline over n1 + 4 chunks: chunks [0,n1) are phase 1 (A = L rows of block i, B = Y
+    // rows of block j, both at K offset 32c), chunks [n1,n1+4) are phase 2, whose B tile is W_i[:, 32tp..]
+    // and whose A operand is T itself, straight out of the accumulator registers -- so W_i streams
+    // through the same double-buffered LDS stage as everything else and there is no staging bubble
+    // between the phases.
+    const int n1 = (i - j) * (TS / BK);
+    const float* Lrows = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;   // L[i, j*128 ...]
+    const float* Yrows = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;   // Y[j, j*128 ...]
+    f32x16 T[4], O[4];
     zero_acc(T);
-    {
-        const float* Lrows = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;   // L[i, j*128 ...]
-        const float* Yrows = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;   // Y[j, j*128 ...]
-        gemm_nt_128<1>(Lrows, Np, Yrows, Np, (i - j) * (TS / BK), T, smem);
-    }
-    for (int e = tid; e < TS * TS / 4; e += NT) {
-        const int r = e >> 5, c = (e & 31) * 4;
-        *reinterpret_cast<f32x4*>(smem + r * WLD + c) = *reinterpret_cast<const f32x4*>(W + r * TS + c);
-    }
-    __syncthreads();
-
-    // phase 2: out[c][r] for c in this wave's 32 columns, r in 4 blocks of 32.
-    f32x16 O[4];
     zero_acc(O);
+    StageRegs sr;
+    const int srow = tid >> 3, scq = (tid & 7) * 4;
+    auto load_chunk = [&](int c) {
+        if (c < n1) {
+            stage_load(sr, Lrows, Np, Yrows, Np, c * BK);
+        } else {
+            const int p0 = (c - n1) * BK;
 #pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {          // 32-row block of p held in T[tp]
+            for (int p = 0; p < 4; ++p)
+                sr.b[p] = *reinterpret_cast<const f32x4*>(W + (srow + 32 * p) * TS + p0 + scq);
+        }
+    };
+    auto store_chunk = [&](int c, float* buf) {
+        if (c < n1) {
+            stage_store(sr, buf);
+        } else {
+            float* sB = buf + TS * SLD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {         // registers 4g..4g+3 <-> p = tp*32 + 8g + 4*lh + (0..3)
-            const int p0 = tp * 32 + 8 * g + 4 * lh;
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(sB + (srow + 32 * p) * SLD + scq) = sr.b[p];
+        }
+    };
+    const int nall = n1 + 4;
+    load_chunk(0);
+    store_chunk(0, smem);
+    load_chunk(1);
+    __syncthreads();
+    int c = 0;
+    for (; c < n1; ++c) {
+        float* cur = smem + (c & 1) * STAGE_FLOATS;
+        float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
+        mma_chunk<1, 0, BK / 16>(cur, T);
+        store_chunk(c + 1, nxt);                    // c + 1 <= n1 < nall always exists
+        if (c + 2 < nall) load_chunk(c + 2);
+        mma_chunk<1, BK / 16, BK / 8>(cur, T);
+        __syncthreads();
+    }
+    // phase 2: out[cc][r] for cc in this wave's 32 columns, r in 4 blocks of 32.
+    // registers 4g..4g+3 of T[tp] <-> p = tp*32 + 8g + 4*lh + (0..3); B fragment = W[r][p] from the stage.
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp, ++c) {
+        float* cur = smem + (c & 1) * STAGE_FLOATS;
+        float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
+        const float* sB = cur + TS * SLD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g == 2) {
+                if (c + 1 < nall) store_chunk(c + 1, nxt);
+                if (c + 2 < nall) load_chunk(c + 2);
+            }
             f32x4 w[4];
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb)
-                w[rb] = *reinterpret_cast<const f32x4*>(smem + (rb * 32 + l31) * WLD + p0);
+                w[rb] = *reinterpret_cast<const f32x4*>(sB + (rb * 32 + l31) * SLD + 8 * g + 4 * lh);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float a = T[tp][4 * g + m];
@@ -441,8 +531,9 @@ __global__ __launch_bounds__(256) void trtri_row_kernel(const float* __restrict_
                     O[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[rb][m], O[rb], 0, 0, 0);
             }
         }
+        __syncthreads();
     }
-    // O[rb] element (row = c_local, col = r_local): lane&31 = r, registers = c.
+    // O[rb] element (row = c_local, col = r_local): lane&31 = r, registers = c.  Y = -O.
     float* Yt = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
@@ -452,6 +543,55 @@ __global__ __launch_bounds__(256) void trtri_row_kernel(const float* __restrict_
             const int r = rb * 32 + l31;
             Yt[(int64_t)c * Np + r] = -O[rb][q];
         }
+    if (red.rpad) {
+        // rows of this block row are all < N (only block row n-1 is padded, and that is a diagonal tile)
+        const float* rv = red.rpad + (int64_t)b * Np + j * TS + wave * 32;
+        float rvq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rvq[q] = rv[accrow(q, lane)];
+        __syncthreads();                                  // everyone is done reading W from smem
+        float* sz = smem;                                 // [4 waves][128]
+        float ff = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            float cz = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float y = -O[rb][q];
+                cz += y * rvq[q];
+                ff += y * y;
+            }
+            cz += __shfl_xor(cz, 32);                     // the two lane halves hold different rows of column r
+            if (lh == 0) sz[wave * TS + rb * 32 + l31] = cz;
+        }
+        ff = wave_sum_f(ff);
+        if (lane == 0) sz[4 * TS + wave] = ff;
+        __syncthreads();
+        if (tid < TS)
+            red.zpart[((int64_t)b * n + j) * Np + i * TS + tid] =
+                (sz[tid] + sz[TS + tid]) + (sz[2 * TS + tid] + sz[3 * TS + tid]);
+        if (tid == 0)
+            red.frob[(int64_t)b * (n * (n + 1) / 2) + tile_id] = (sz[4 * TS] + sz[4 * TS + 1]) + (sz[4 * TS + 2] + sz[4 * TS + 3]);
+    }
+}
+
+// Fused launch: workgroups [0, nd) factor + invert diagonal block k_diag of their matrix (a 90 us
+// latency chain on only B of the 256 CUs), the rest compute the tiles of trtri row i_tri, which is
+// independent work.  Either part may be absent (k_diag < 0 / i_tri < 0).
+__global__ __launch_bounds__(256, 2) void diag_trtri_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                           float* __restrict__ Y, int* __restrict__ info, int Np,
+                                                           int k_diag, int i_tri, int B, TriReduce red) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    static_assert(DIAG_LDS_FLOATS <= 2 * STAGE_FLOATS, "diag block must fit the staging area");
+    static_assert(TS * WLD + TS <= 2 * STAGE_FLOATS, "W image + reduction scratch must fit");
+    const int nd = (k_diag >= 0) ? B : 0;
+    if ((int)blockIdx.x < nd) {
+        diag_body(A, Winv, info, Np, k_diag, blockIdx.x, smem);
+        return;
+    }
+    int j, b;
+    decode_tile_batch((int)blockIdx.x - nd, i_tri + 1, B, j, b);
+    trtri_body(A, Winv, Y, Np, i_tri, j, b, red, smem);
 }
 
 }  // namespace volt
@@ -493,18 +633,35 @@ struct LaunchTimer {
     }
 };
 
-static int run_potrf(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, LaunchTimer* tm) {
+// One factorisation (+ optional inverse) of the whole batch.  Launch sequence per block column k:
+//     P1(k)  ->  [ P2(k)  U  trtri row k-1 ]  ->  P3(k)        and finally trtri row n-1.
+// Timer classes: 0 = potrf_update (P1), 1 = diag_trtri (fused P2 + trtri row), 2 = potrf_trsm (P3),
+//                3 = trtri_row alone (the last row; every row when called through volt_trtri_f32).
+struct FactorOpts {
+    KSource src;            // src.K != nullptr: block columns >= 1 take their C tiles straight from K
+    float* Y;               // nullptr: no triangular inverse
+    TriReduce red;          // red.rpad != nullptr: fuse z-partials and Frobenius partials into trtri
+};
+
+static int run_factor(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o,
+                      LaunchTimer* tm) {
     const int n = Np / TS;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
+    const TriReduce nored{nullptr, nullptr, nullptr, 0};
     for (int k = 0; k < n; ++k) {
         if (k > 0) {
             if (tm) tm->begin(0);
-            hipLaunchKernelGGL(potrf_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B);
+            if (o.src.K)
+                hipLaunchKernelGGL(potrf_update_kernel<true>, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, o.src);
+            else
+                hipLaunchKernelGGL(potrf_update_kernel<false>, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, o.src);
             if (tm) tm->end();
         }
+        const int itri = (o.Y && k > 0) ? k - 1 : -1;
         if (tm) tm->begin(1);
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(B), dim3(256), 0, s, A, Winv, info, Np, k);
+        hipLaunchKernelGGL(diag_trtri_kernel, dim3(B + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, s, A, Winv,
+                           o.Y, info, Np, k, itri, B, o.Y ? o.red : nored);
         if (tm) tm->end();
         if (k + 1 < n) {
             if (tm) tm->begin(2);
@@ -512,18 +669,42 @@ static int run_potrf(float* A, float* Winv, int* info, int B, int Np, hipStream_
             if (tm) tm->end();
         }
     }
+    if (o.Y) {
+        if (tm) tm->begin(3);
+        hipLaunchKernelGGL(diag_trtri_kernel, dim3(n * B), dim3(256), 0, s, A, Winv, o.Y, info, Np, -1, n - 1, B, o.red);
+        if (tm) tm->end();
+    }
     VOLT_LAUNCH_CHECK();
     return 0;
 }
 
 static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np, hipStream_t s, LaunchTimer* tm) {
     const int n = Np / TS;
+    const TriReduce nored{nullptr, nullptr, nullptr, 0};
     for (int i = 0; i < n; ++i) {
         if (tm) tm->begin(3);
-        hipLaunchKernelGGL(trtri_row_kernel, dim3((i + 1) * B), dim3(256), 0, s, A, Winv, Y, Np, i, B);
+        hipLaunchKernelGGL(diag_trtri_kernel, dim3((i + 1) * B), dim3(256), 0, s, const_cast<float*>(A),
+                           const_cast<float*>(Winv), Y, nullptr, Np, -1, i, B, nored);
         if (tm) tm->end();
     }
     VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+// used by mll.hip
+int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
+                         float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
+                         void* stream, float* ms_host, int* launches_host) {
+    const int Np = volt_padded_n(N), n = Np / TS;
+    hipStream_t s = (hipStream_t)stream;
+    // block column 0 (no panel update there) is copied; the others are read from K inside P1
+    hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}};
+    if (!ms_host) return run_factor(A, Winv, info, B, Np, s, o, nullptr);
+    LaunchTimer tm(s);
+    const int rc = run_factor(A, Winv, info, B, Np, s, o, &tm);
+    if (rc) return rc;
+    tm.collect(ms_host, launches_host, 4);
     return 0;
 }
 
@@ -539,7 +720,7 @@ int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
     if (B == 0) return 0;
     const int Np = volt_padded_n(N), n = Np / TS;
     hipLaunchKernelGGL(prepare_kernel, dim3(n * (n + 1) / 2, B), dim3(256), 0, (hipStream_t)stream, K, ldk, bsk,
-                       sigma2, jitter, A, N, Np);
+                       sigma2, jitter, A, N, Np, 0);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
@@ -552,8 +733,9 @@ int volt_tune_update_f32(float* A, int B, int Np, int k, int var, int reps, void
     if (k < 1 || k >= n) return -4;
     if (var != 0) return -5;
     hipStream_t s = (hipStream_t)stream;
+    const KSource none{nullptr, 0, 0, nullptr, 0.f, 0};
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(potrf_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B);
+        hipLaunchKernelGGL(potrf_update_kernel<false>, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, none);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
@@ -565,24 +747,23 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
     if (B < 0) return -4;
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
-    return run_potrf(A, Winv, info, B, Np, (hipStream_t)stream, nullptr);
+    FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}};
+    return run_factor(A, Winv, info, B, Np, (hipStream_t)stream, o, nullptr);
 }
 
-int volt_profile_factor_f32(float* A, float* Winv, float* Y, int* info, int B, int Np, void* stream,
-                            float* ms_host, int* launches_host) {
-    if (!A) return -1;
-    if (!Winv) return -2;
-    if (!info) return -4;
-    if (B < 1) return -5;
-    if (Np < TS || Np % TS) return -6;
-    if (!ms_host) return -8;
-    if (!launches_host) return -9;
-    LaunchTimer tm((hipStream_t)stream);
-    int rc = run_potrf(A, Winv, info, B, Np, (hipStream_t)stream, &tm);
-    if (rc) return rc;
-    if (Y && (rc = run_trtri(A, Winv, Y, B, Np, (hipStream_t)stream, &tm))) return rc;
-    tm.collect(ms_host, launches_host, 4);
-    return 0;
+int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv,
+                            float* Y, int* info, int B, int N, void* stream, float* ms_host, int* launches_host) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!A) return -5;
+    if (!Winv) return -6;
+    if (!info) return -8;
+    if (B < 1) return -9;
+    if (N < 1) return -10;
+    if (!ms_host) return -12;
+    if (!launches_host) return -13;
+    return volt_internal_factor(K, ldk, bsk, sigma2, 0.f, A, Winv, Y, info, nullptr, nullptr, nullptr, B, N, stream,
+                                ms_host, launches_host);
 }
 
 int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out, float* scratch, int B,

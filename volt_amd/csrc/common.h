@@ -29,8 +29,7 @@ __device__ __forceinline__ int accrow(int q, int lane) { return (q & 3) + 8 * (q
 // XCD-aware decode of a 1-D grid into (tile, batch).  The dispatcher places workgroup w on XCD
 // w % 8 (observed, used for speed only): give every XCD whole matrices so the operand a panel's
 // tiles share (the k-th block row, or a diagonal inverse) is fetched into one L2, not eight.
-__device__ __forceinline__ void decode_tile_batch(int ntiles, int nbatch, int& tile, int& batch) {
-    const int w = blockIdx.x;
+__device__ __forceinline__ void decode_tile_batch(int w, int ntiles, int nbatch, int& tile, int& batch) {
     if ((nbatch & 7) == 0) {
         const int xcd = w & 7, slot = w >> 3;
         batch = (slot / ntiles) * 8 + xcd;
@@ -39,6 +38,10 @@ __device__ __forceinline__ void decode_tile_batch(int ntiles, int nbatch, int& t
         batch = w / ntiles;
         tile = w % ntiles;
     }
+}
+
+__device__ __forceinline__ void decode_tile_batch(int ntiles, int nbatch, int& tile, int& batch) {
+    decode_tile_batch((int)blockIdx.x, ntiles, nbatch, tile, batch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -144,6 +147,24 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
         mma_chunk<WL, BK / 16, BK / 8>(cur, acc);
         __syncthreads();
     }
+}
+
+// sum over the 64 lanes (DPP inside 16-lane rows, then four readlanes), result in every lane
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f(float x) {
+    x = dpp_add<0xB1>(x);     // quad_perm [1,0,3,2]
+    x = dpp_add<0x4E>(x);     // quad_perm [2,3,0,1]
+    x = dpp_add<0x141>(x);    // row_half_mirror
+    x = dpp_add<0x140>(x);    // row_mirror: every lane of a 16-lane row now holds the row sum
+    const int xi = __float_as_int(x);       // readlane is an integer builtin: bit-cast, never convert
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {

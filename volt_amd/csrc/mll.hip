@@ -25,42 +25,6 @@ __device__ __forceinline__ void upper_tile(int t, int& jb, int& cb) {
     jb = t - ti * (ti + 1) / 2;
 }
 
-// R1: per upper tile (jb <= cb):  zpart[b][jb][cb*128 + c] = sum_r Y[jb*128+r][cb*128+c] * rvec[jb*128+r]
-//     frob[b][t] = sum over rows < N of Y^2.   Deterministic (no atomics).
-__global__ __launch_bounds__(256) void reduce_yt_r_kernel(const float* __restrict__ Y, const float* __restrict__ rpad,
-                                                          float* __restrict__ zpart, float* __restrict__ frob, int N,
-                                                          int Np) {
-    __shared__ float sz[256];
-    __shared__ float sf[256];
-    const int n = Np / TS;
-    const int t = blockIdx.x, b = blockIdx.y;
-    int jb, cb;
-    upper_tile(t, jb, cb);
-    const float* Yt = Y + (int64_t)b * Np * Np + (int64_t)jb * TS * Np + (int64_t)cb * TS;
-    const float* rv = rpad + (int64_t)b * Np + jb * TS;
-    const int c = threadIdx.x & 127, half = threadIdx.x >> 7;
-    float az = 0.f, af = 0.f;
-#pragma unroll 8
-    for (int r = half * 64; r < half * 64 + 64; ++r) {
-        const float y = Yt[(int64_t)r * Np + c];
-        az += y * rv[r];
-        if (jb * TS + r < N) af += y * y;
-    }
-    sz[threadIdx.x] = az;
-    sf[threadIdx.x] = af;
-    __syncthreads();
-    if (threadIdx.x < 128) {
-        zpart[((int64_t)b * n + jb) * Np + cb * TS + c] = sz[threadIdx.x] + sz[threadIdx.x + 128];
-        sf[threadIdx.x] += sf[threadIdx.x + 128];
-    }
-    __syncthreads();
-    for (int s = 64; s > 0; s >>= 1) {
-        if (threadIdx.x < s) sf[threadIdx.x] += sf[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) frob[(int64_t)b * (n * (n + 1) / 2) + t] = sf[0];
-}
-
 // R2: z[c] = sum_{jb <= cb} zpart[jb][c]
 __global__ void sum_zpart_kernel(const float* __restrict__ zpart, float* __restrict__ z, int Np) {
     const int n = Np / TS;
@@ -73,34 +37,33 @@ __global__ void sum_zpart_kernel(const float* __restrict__ zpart, float* __restr
     z[(int64_t)b * Np + c] = a;
 }
 
-// R3: alpha[jb rows] = sum_{cb >= jb} Y[jb, cb] z[cb]   (one workgroup per block row)
+// R3: alpha = Y z, Y upper triangular: alpha[j] = sum_{c >= j} Y[j][c] z[c].  Pure HBM stream over the
+// upper half of Y: a wave owns one row at a time, lanes read float4 (1 KiB contiguous per wave and
+// pass), z comes from L1/L2; 4 rows are kept in flight per wave for memory-level parallelism.
+// grid = (Np/16) * B workgroups of 4 waves; a workgroup covers 16 consecutive rows.
 __global__ __launch_bounds__(256) void y_times_z_kernel(const float* __restrict__ Y, const float* __restrict__ z,
                                                         float* __restrict__ alpha, int Np, int B) {
-    __shared__ float s[TS * VLD2];
-    __shared__ float zv[TS];
-    const int n = Np / TS;
-    int jb, b;
-    decode_tile_batch(n, B, jb, b);
-    const float* Yb = Y + (int64_t)b * Np * Np + (int64_t)jb * TS * Np;
-    const int tid = threadIdx.x;
-    float a = 0.f;
-    for (int cb = jb; cb < n; ++cb) {
-        __syncthreads();
-        for (int e = tid; e < TS * TS / 4; e += NT) {
-            const int r = e >> 5, c = (e & 31) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(Yb + (int64_t)r * Np + cb * TS + c);
+    int rb, b;
+    decode_tile_batch(Np / 16, B, rb, b);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = rb * 16 + wave * 4;                       // this wave's 4 rows
+    const float* Yb = Y + (int64_t)b * Np * Np;
+    const float* zb = z + (int64_t)b * Np;
+    const int cstart = (j0 / TS) * TS;                       // tiles left of the diagonal tile are not stored
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = cstart + lane * 4; c < Np; c += 256) {
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(zb + c);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) s[r * VLD2 + c + q] = v[q];
-        }
-        if (tid < TS) zv[tid] = z[(int64_t)b * Np + cb * TS + tid];
-        __syncthreads();
-        if (tid < TS) {
-            // diagonal tile is upper triangular: start at the diagonal
-            const int p0 = (cb == jb) ? tid : 0;
-            for (int p = p0; p < TS; ++p) a += s[tid * VLD2 + p] * zv[p];
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(Yb + (int64_t)(j0 + r) * Np + c);
+            acc[r] += (y[0] * zv[0] + y[1] * zv[1]) + (y[2] * zv[2] + y[3] * zv[3]);
         }
     }
-    if (tid < TS) alpha[(int64_t)b * Np + jb * TS + tid] = a;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float tot = wave_sum_f(acc[r]);
+        if (lane == 0) alpha[(int64_t)b * Np + j0 + r] = tot;
+    }
 }
 
 // R4: scalars.  out[b, 0..7] = mll, dmll/dsigma2, quad, logdet, trinv, aa, sigma2-used, 0
@@ -196,6 +159,10 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
 
 using namespace volt;
 
+int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
+                         float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
+                         void* stream, float* ms_host, int* launches_host);
+
 extern "C" {
 
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {
@@ -221,14 +188,12 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
-    if ((rc = volt_prepare_f32(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
-    if ((rc = volt_potrf_f32(w.A, w.Winv, info, B, Np, stream))) return rc > 0 ? rc : -1;
+    if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
+                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, nullptr, nullptr)))
+        return rc > 0 ? rc : -1;
     if (want_grad) {
-        if ((rc = volt_trtri_f32(w.A, w.Winv, w.Y, B, Np, stream))) return rc > 0 ? rc : -1;
-        hipLaunchKernelGGL(reduce_yt_r_kernel, dim3(n * (n + 1) / 2, B), dim3(256), 0, s, w.Y, w.rpad, w.zpart, w.frob,
-                           N, Np);
         hipLaunchKernelGGL(sum_zpart_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, w.zpart, w.z, Np);
-        hipLaunchKernelGGL(y_times_z_kernel, dim3(n * B), dim3(256), 0, s, w.Y, w.z, w.apad, Np, B);
+        hipLaunchKernelGGL(y_times_z_kernel, dim3((Np / 16) * B), dim3(256), 0, s, w.Y, w.z, w.apad, Np, B);
     } else {
         if ((rc = volt_trsv_lower_f32(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
     }

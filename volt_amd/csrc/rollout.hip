@@ -22,25 +22,6 @@
 
 namespace volt {
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
-}
-
-// sum over the 64 lanes, result in every lane
-__device__ __forceinline__ float wave_sum(float x) {
-    x += dpp_f<0xB1>(x);     // quad_perm [1,0,3,2]
-    x += dpp_f<0x4E>(x);     // quad_perm [2,3,0,1]
-    x += dpp_f<0x141>(x);    // row_half_mirror
-    x += dpp_f<0x140>(x);    // row_mirror      -> every lane of a 16-lane row holds the row sum
-    const int xi = __float_as_int(x);        // readlane is an integer builtin: bit-cast, do not convert
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(xi, 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(xi, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
 __device__ __forceinline__ double wave_sum_d(double x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -120,7 +101,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
                 if (b < a) part += La[b] * (wv[t] * rd[t]);  // w[b] = wv[b] * rd[b] for finished b
             }
             // every b < a is already final: entries of wv are only reduced by rows a' <= their index
-            const float dot = wave_sum(part);
+            const float dot = wave_sum_f(part);
             const int ta = a >> 6;
             if (lane == (a & 63)) {
 #pragma unroll
@@ -136,8 +117,8 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
             ww += wv[t] * wv[t];
             wz += wv[t] * zs[t];
         }
-        ww = wave_sum(ww);
-        wz = wave_sum(wz);
+        ww = wave_sum_f(ww);
+        wz = wave_sum_f(wz);
 
         // ---- mean of the new point: EWMA family on the stacked series (EWMA.py:20-37) ----------
         double a1 = 0.0, a2 = 0.0, a3 = 0.0;
