@@ -156,8 +156,15 @@ def main():
         flops = kernel_class_flops(B, Np)
         dom = int(np.argmax(tot))
         ach = flops[dom] / (tot[dom] * 1e-3) / 1e12
+        traffic = None
+        try:      # HBM bytes per launch from the PMC passes (scripts/pmc.sh + scripts/pmc_traffic.py), same workload only
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pj["config"] == {"n": n, "batch": B}:
+                traffic = round(pj["kernels"][names[dom].split("(")[0]]["bytes_per_launch"])
+        except Exception:
+            traffic = None
         roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
                 "launches": int(cnt[dom]), "avg_launch_ms": round(float(tot[dom] / max(1, cnt[dom])), 4)}
         extra = {"kernel_ms": {nm: round(float(t), 3) for nm, t in zip(names, tot)},
                  "kernel_tflops": {nm: round(f / (t * 1e-3) / 1e12, 2) for nm, f, t in zip(names, flops, tot)},

@@ -1,0 +1,31 @@
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of scripts/pmc.sh into profiles/pmc_traffic.json, which
+bench.py attaches to its roofline object when the workload matches.
+
+Correction (MI355X_MICROARCH.md, HBM section): both counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so reads are doubled.
+WRITE_SIZE was calibrated here on fill_kernel (known 4*N^2*B bytes): exact.
+usage: python scripts/pmc_traffic.py gpurun_out/pmc_<tag> <n> <batch> <passes_per_run>
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root, n, batch, runs = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+agg = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
+for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("volt::", "").replace("void ", "").split("<")[0]
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        cnt[k][row["Counter_Name"]] += 1
+out = {"config": {"n": n, "batch": batch}, "source": root, "correction": "read bytes = 2 * FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
+       "kernels": {}}
+for k, a in agg.items():
+    if "FETCH_SIZE" not in a or "WRITE_SIZE" not in a:
+        continue
+    launches = cnt[k]["FETCH_SIZE"]
+    rd, wr = 2 * a["FETCH_SIZE"] * 1024, a["WRITE_SIZE"] * 1024
+    out["kernels"][k] = {"launches_profiled": launches, "read_bytes_per_launch": rd / launches,
+                         "write_bytes_per_launch": wr / launches, "bytes_per_launch": (rd + wr) / launches,
+                         "bytes_per_factorisation": (rd + wr) / runs}
+json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
