@@ -7,7 +7,7 @@ from volt_amd import _lib, ops
 from volt_amd.synthetic import sde_batch
 
 B, n = 64, 4096
-variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,2".split(","))]
+variants = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0".split(","))]
 ks = [1, 4, 16, 28]
 x, F, vol = sde_batch(B, n)
 K = ops.fill(ops.cumtrapz(torch.tensor(vol).cuda(), torch.tensor(x).cuda(), square=True))

@@ -92,22 +92,46 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         // ---- w_s = L_s^-1 (U_s - rho): row-oriented forward substitution against stored rows ----
 #pragma unroll
         for (int t = 0; t < 4; ++t) wv[t] = U[t] - rho;
-        for (int a = 1; a < idx; ++a) {                      // row 0 has no off-diagonal part
-            const float* La = Ls + (size_t)a * H;
-            float part = 0.f;
+        // Rows are streamed in groups of 4 with the next group's loads issued before the current
+        // group is consumed: the substitution itself is a dependent chain (row a needs w[a-1]), but the
+        // addresses are not, so 8 rows per wave stay in flight and the stream runs at memory bandwidth
+        // instead of one memory latency per row.
+        float cur[4][4], nxt[4][4];
+        auto load_rows = [&](float (&dst)[4][4], int a0) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int b = lane + 64 * t;
-                if (b < a) part += La[b] * (wv[t] * rd[t]);  // w[b] = wv[b] * rd[b] for finished b
-            }
-            // every b < a is already final: entries of wv are only reduced by rows a' <= their index
-            const float dot = wave_sum_f(part);
-            const int ta = a >> 6;
-            if (lane == (a & 63)) {
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + r;
+                const float* La = Ls + (size_t)a * H;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (t == ta) wv[t] -= dot;
+                for (int t = 0; t < 4; ++t) {
+                    const int b = lane + 64 * t;
+                    dst[r][t] = (a < idx && b < a) ? La[b] : 0.f;
+                }
             }
+        };
+        load_rows(cur, 1);                                   // row 0 has no off-diagonal part
+        for (int a0 = 1; a0 < idx; a0 += 4) {
+            load_rows(nxt, a0 + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = a0 + r;
+                if (a < idx) {                               // wave-uniform
+                    float part = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) part += cur[r][t] * (wv[t] * rd[t]);   // zero beyond b < a
+                    const float dot = wave_sum_f(part);
+                    const int ta = a >> 6;
+                    if (lane == (a & 63)) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+                            if (t == ta) wv[t] -= dot;
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) cur[r][t] = nxt[r][t];
         }
         float ww = 0.f, wz = 0.f;
 #pragma unroll
