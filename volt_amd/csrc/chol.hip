@@ -16,6 +16,8 @@
 // right-looking sweep; HBM traffic is the operand reads, N^3/(6*128) words per matrix.
 #include "common.h"
 #include "../../include/volt_hip.h"
+#include <mutex>
+#include <stdlib.h>
 #include <vector>
 
 namespace volt {
@@ -643,37 +645,142 @@ struct FactorOpts {
     TriReduce red;          // red.rpad != nullptr: fuse z-partials and Frobenius partials into trtri
 };
 
+// Everything one group of matrices needs: the batch is cut into contiguous groups that run the same
+// launch sequence on different streams (see run_factor_groups).
+struct Group {
+    float* A;
+    float* Winv;
+    int* info;
+    FactorOpts o;
+    int B;
+    hipStream_t s;
+};
+
+static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
+    const int n = Np / TS, B = g.B;
+    const TriReduce nored{nullptr, nullptr, nullptr, 0};
+    if (k > 0) {
+        if (tm) tm->begin(0);
+        if (g.o.src.K)
+            hipLaunchKernelGGL(potrf_update_kernel<true>, dim3((n - k) * B), dim3(256), 0, g.s, g.A, Np, k, B, g.o.src);
+        else
+            hipLaunchKernelGGL(potrf_update_kernel<false>, dim3((n - k) * B), dim3(256), 0, g.s, g.A, Np, k, B, g.o.src);
+        if (tm) tm->end();
+    }
+    const int itri = (g.o.Y && k > 0) ? k - 1 : -1;
+    if (tm) tm->begin(1);
+    hipLaunchKernelGGL(diag_trtri_kernel, dim3(B + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s, g.A, g.Winv,
+                       g.o.Y, g.info, Np, k, itri, B, g.o.Y ? g.o.red : nored);
+    if (tm) tm->end();
+    if (k + 1 < n) {
+        if (tm) tm->begin(2);
+        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((n - k - 1) * B), dim3(256), 0, g.s, g.A, g.Winv, Np, k, B);
+        if (tm) tm->end();
+    }
+    if (k + 1 == n && g.o.Y) {
+        if (tm) tm->begin(3);
+        hipLaunchKernelGGL(diag_trtri_kernel, dim3(n * B), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, -1, n - 1,
+                           B, g.o.red);
+        if (tm) tm->end();
+    }
+}
+
 static int run_factor(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o,
                       LaunchTimer* tm) {
     const int n = Np / TS;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
-    const TriReduce nored{nullptr, nullptr, nullptr, 0};
-    for (int k = 0; k < n; ++k) {
-        if (k > 0) {
-            if (tm) tm->begin(0);
-            if (o.src.K)
-                hipLaunchKernelGGL(potrf_update_kernel<true>, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, o.src);
-            else
-                hipLaunchKernelGGL(potrf_update_kernel<false>, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, o.src);
-            if (tm) tm->end();
+    const Group g{A, Winv, info, o, B, s};
+    for (int k = 0; k < n; ++k) enqueue_step(g, Np, k, tm);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- stage barriers vs. asynchrony ------------------------------------------------------------------
+// With the whole batch in lockstep every launch ends in a tail: (n-k)*B tiles rarely fill a whole number of
+// rounds of the 512 resident workgroups (measured: P1 at k = 23 runs 576 tiles = 1.125 rounds at 77 TF/s,
+// k = 24 = 1.0 rounds at 131), and the next stage cannot start before the tail has drained.  A list-
+// scheduling model of the measured tile times puts this at 32.4 ms per step against 26.8 ms for perfect
+// packing.  Cutting the batch into G groups that run the SAME launch sequence on G streams, started a
+// little apart, lets one group's tail overlap another group's next stage (model: 28.6 ms at G = 4).
+// The streams are created once per device (library-lifetime, like a BLAS handle); a call forks from and
+// joins back into the caller's stream with events, so the caller still sees ordinary stream semantics.
+__global__ void delay_kernel(long long cycles) {
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+constexpr int MAX_GROUPS = 8;
+struct StreamPool {
+    hipStream_t aux[MAX_GROUPS - 1];
+    bool ok = false;
+};
+static StreamPool* stream_pool() {
+    static StreamPool pools[16];
+    static std::once_flag once[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::call_once(once[dev], [dev]() {
+        bool ok = true;
+        for (int i = 0; i < MAX_GROUPS - 1; ++i)
+            ok = ok && hipStreamCreateWithFlags(&pools[dev].aux[i], hipStreamNonBlocking) == hipSuccess;
+        pools[dev].ok = ok;
+    });
+    return pools[dev].ok ? &pools[dev] : nullptr;
+}
+
+static int pick_groups(int B) {
+    int want = 4;
+    if (const char* e = getenv("VOLT_GROUPS")) want = atoi(e);
+    if (want < 1) want = 1;
+    if (want > MAX_GROUPS) want = MAX_GROUPS;
+    while (want > 1 && (B % want != 0 || B / want < 8)) want >>= 1;   // keep whole-XCD groups of >= 8 matrices
+    return want;
+}
+
+static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o) {
+    const int n = Np / TS;
+    const int G = pick_groups(B);
+    StreamPool* pool = G > 1 ? stream_pool() : nullptr;
+    if (G == 1 || !pool) return run_factor(A, Winv, info, B, Np, s, o, nullptr);
+    hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
+    if (e != hipSuccess) return (int)e;
+    const int Bg = B / G;
+    const int64_t mat = (int64_t)Np * Np;
+    Group grp[MAX_GROUPS];
+    hipEvent_t fork, join[MAX_GROUPS];
+    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return (int)e;
+    (void)hipEventRecord(fork, s);
+    long long skew = 0;                                    // optional start skew between groups (measured: no effect)
+    if (const char* ev = getenv("VOLT_GROUP_SKEW_US")) skew = (long long)(atof(ev) * 2400.0);
+    for (int g = 0; g < G; ++g) {
+        FactorOpts og = o;
+        const int b0 = g * Bg;
+        if (og.src.K) {
+            og.src.K += (int64_t)b0 * og.src.bsk;
+            if (og.src.sigma2) og.src.sigma2 += b0;
         }
-        const int itri = (o.Y && k > 0) ? k - 1 : -1;
-        if (tm) tm->begin(1);
-        hipLaunchKernelGGL(diag_trtri_kernel, dim3(B + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, s, A, Winv,
-                           o.Y, info, Np, k, itri, B, o.Y ? o.red : nored);
-        if (tm) tm->end();
-        if (k + 1 < n) {
-            if (tm) tm->begin(2);
-            hipLaunchKernelGGL(potrf_trsm_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
-            if (tm) tm->end();
+        if (og.Y) og.Y += b0 * mat;
+        if (og.red.rpad) {
+            og.red.rpad += (int64_t)b0 * Np;
+            og.red.zpart += (int64_t)b0 * n * Np;
+            og.red.frob += (int64_t)b0 * (n * (n + 1) / 2);
+        }
+        grp[g] = Group{A + b0 * mat, Winv + (int64_t)b0 * n * TS * TS, info + b0, og, Bg, g == 0 ? s : pool->aux[g - 1]};
+        if (g > 0) {
+            (void)hipStreamWaitEvent(grp[g].s, fork, 0);
+            if (skew > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, grp[g].s, skew * g);
         }
     }
-    if (o.Y) {
-        if (tm) tm->begin(3);
-        hipLaunchKernelGGL(diag_trtri_kernel, dim3(n * B), dim3(256), 0, s, A, Winv, o.Y, info, Np, -1, n - 1, B, o.red);
-        if (tm) tm->end();
+    for (int k = 0; k < n; ++k)
+        for (int g = 0; g < G; ++g) enqueue_step(grp[g], Np, k, nullptr);
+    for (int g = 1; g < G; ++g) {
+        if ((e = hipEventCreateWithFlags(&join[g], hipEventDisableTiming)) != hipSuccess) return (int)e;
+        (void)hipEventRecord(join[g], grp[g].s);
+        (void)hipStreamWaitEvent(s, join[g], 0);
+        (void)hipEventDestroy(join[g]);
     }
+    (void)hipEventDestroy(fork);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
@@ -700,7 +807,7 @@ int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* 
     // block column 0 (no panel update there) is copied; the others are read from K inside P1
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
     FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}};
-    if (!ms_host) return run_factor(A, Winv, info, B, Np, s, o, nullptr);
+    if (!ms_host) return run_factor_groups(A, Winv, info, B, Np, s, o);
     LaunchTimer tm(s);
     const int rc = run_factor(A, Winv, info, B, Np, s, o, &tm);
     if (rc) return rc;

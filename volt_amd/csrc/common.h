@@ -84,6 +84,36 @@ __device__ __forceinline__ void stage_store(const StageRegs& s, float* __restric
     }
 }
 
+// Buffer-addressed staging: one 128-bit resource per operand (wave-uniform), four per-lane byte
+// offsets computed once, the K offset in an SGPR -- no 64-bit VALU address arithmetic per chunk.
+struct StageAddr {
+    __amdgpu_buffer_rsrc_t ra, rb;
+    int va[4], vb[4];
+};
+
+__device__ __forceinline__ StageAddr stage_addr(const float* A, int64_t lda, const float* B, int64_t ldb) {
+    StageAddr sa;
+    sa.ra = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+    sa.rb = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
+    const int t = threadIdx.x;
+    const int row = t >> 3, cq = (t & 7) * 4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        sa.va[p] = (int)(((int64_t)(row + 32 * p) * lda + cq) * 4);
+        sa.vb[p] = (int)(((int64_t)(row + 32 * p) * ldb + cq) * 4);
+    }
+    return sa;
+}
+
+__device__ __forceinline__ void stage_load_buf(StageRegs& s, const StageAddr& sa, int k0) {
+    const int so = __builtin_amdgcn_readfirstlane(k0 * 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        s.a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sa.ra, sa.va[p], so, 0));
+        s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sa.rb, sa.vb[p], so, 0));
+    }
+}
+
 template <int WL, int KK0 = 0, int KK1 = BK / 8>
 __device__ __forceinline__ void mma_chunk(const float* __restrict__ buf, f32x16 (&acc)[4]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,16 +164,17 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
                                                f32x16 (&acc)[4], float* smem) {
     if (nchunks <= 0) return;
     StageRegs s;
-    stage_load(s, A, lda, B, ldb, 0);
+    const StageAddr sa = stage_addr(A, lda, B, ldb);
+    stage_load_buf(s, sa, 0);
     stage_store(s, smem);
-    if (nchunks > 1) stage_load(s, A, lda, B, ldb, BK);
+    if (nchunks > 1) stage_load_buf(s, sa, BK);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         float* cur = smem + (c & 1) * STAGE_FLOATS;
         float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
         mma_chunk<WL, 0, BK / 16>(cur, acc);
         if (c + 1 < nchunks) stage_store(s, nxt);
-        if (c + 2 < nchunks) stage_load(s, A, lda, B, ldb, (c + 2) * BK);
+        if (c + 2 < nchunks) stage_load_buf(s, sa, (c + 2) * BK);
         mma_chunk<WL, BK / 16, BK / 8>(cur, acc);
         __syncthreads();
     }
