@@ -266,3 +266,38 @@ def test_bordered_vs_oracle_exact_conditional(va, mean_name):
             xs = np.append(xs, np.float32(xs[-1] + 1 / 252.))
     # fp32 factor of the noise-free K (cond ~1e6 at N=399): a few 1e-4 on values ~2.3
     np.testing.assert_allclose(out, ref, atol=1.5e-3, rtol=0)
+
+
+# ------------------------------------------------------------------ next row (f)1: vol-path forecaster
+def test_train_vol_model_gradients_match_fp64_autograd(va):
+    """BMGP + exact MLL (train_utils.py:69-95): d mll / d raw_vol and d / d raw_noise from the HIP step vs
+    fp64 autograd of the dense formula, then a short training run stays finite and decreases the loss."""
+    from volt_amd.gp import ExactMarginalLogLikelihood
+    from volt_amd.train_utils import TrainVolModel
+    n = 200
+    F, vol = sde_series(n, 13)
+    tx = torch.arange(n, device="cuda") / 252. + 1 / 252.
+    model, lh = TrainVolModel(tx, dev(vol), train_iters=0)
+    model.train()
+    mll = ExactMarginalLogLikelihood(lh, model)
+    loss = -mll(model(tx), dev(vol).log())
+    loss.backward()
+    g_vol, g_noise = float(model.covar_module.raw_vol.grad), float(lh.raw_noise.grad)
+    # fp64 reference
+    x = tx.double().cpu()
+    y = torch.tensor(np.log(vol), dtype=torch.float64)
+    raw_vol = torch.tensor([float(model.covar_module.raw_vol)], dtype=torch.float64, requires_grad=True)
+    raw_noise = torch.tensor([float(lh.raw_noise)], dtype=torch.float64, requires_grad=True)
+    v = torch.sigmoid(raw_vol)
+    K = v * torch.minimum(x[:, None], x[None, :]) + (torch.nn.functional.softplus(raw_noise) + 1e-4) * torch.eye(n, dtype=torch.float64)
+    mean = -0.5 * v ** 2 * x
+    ref = -torch.distributions.MultivariateNormal(mean, covariance_matrix=K).log_prob(y) / n
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-5 * max(1, abs(float(ref)))
+    assert abs(g_vol - float(raw_vol.grad)) < 2e-3 * max(abs(float(raw_vol.grad)), 1e-3)
+    assert abs(g_noise - float(raw_noise.grad)) < 2e-3 * max(abs(float(raw_noise.grad)), 1e-3)
+    model2, lh2 = TrainVolModel(tx, dev(vol), train_iters=25)
+    with torch.no_grad():
+        model2.train()
+        end = -ExactMarginalLogLikelihood(lh2, model2)(model2(tx), dev(vol).log())
+    assert torch.isfinite(end) and float(end) < float(loss)

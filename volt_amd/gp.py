@@ -75,6 +75,36 @@ class _Evaluated:
         return self.tensor.shape
 
 
+class _ScaledDense(_Evaluated):
+    """K = scale * base with a trainable scalar `scale` and a constant dense `base` (BMKernel: vol *
+    min(x, x')).  Keeping the factorisation lets the MLL return d mll / d scale from the quantities
+    the fused step already has (see _ExactMLL.backward) instead of a dense d mll / d K."""
+
+    def __init__(self, scale, base):
+        self.scale, self.base = scale, base
+
+    @property
+    def tensor(self):
+        return self.scale * self.base
+
+    @tensor.setter
+    def tensor(self, v):
+        raise AttributeError("read-only")
+
+    def evaluate(self):
+        return self.scale * self.base
+
+    def to_dense(self):
+        return self.evaluate()
+
+    def detach(self):
+        return (self.scale * self.base).detach()
+
+    @property
+    def shape(self):
+        return self.base.shape
+
+
 def _dense(c):
     return c.evaluate() if isinstance(c, _Evaluated) else c
 
@@ -228,12 +258,12 @@ class _ExactMLL(torch.autograd.Function):
     d/d s2 = 1/2 (a'a - tr K_s^-1)/N,  d/d m = a/N,  d/d y = -a/N,  a = K_s^-1 (y - m)."""
 
     @staticmethod
-    def forward(ctx, K, mean, noise, target, holder):
+    def forward(ctx, K, mean, noise, target, holder, scale=None):
         if K.requires_grad:
             raise NotImplementedError("the volatility covariance has no trainable parameters on this path "
                                       "(train_cov is detached, VoltMagpie.py:46); K.requires_grad is unsupported")
         B, n = mean.shape
-        need_grad = any(ctx.needs_input_grad[1:4])
+        need_grad = any(ctx.needs_input_grad[1:4]) or (scale is not None and ctx.needs_input_grad[5])
         ws = holder.workspace(B, n, need_grad, K.device)
         resid = (target - mean).to(torch.float32)
         jitter = 0.0
@@ -245,15 +275,25 @@ class _ExactMLL(torch.autograd.Function):
             raise NotPSDError(f"K + sigma^2 I not positive definite for {bad} of {B} series "
                               f"(first failing pivot {int(info[info != 0][0].item())})")
         ctx.n = n
+        ctx.has_scale = scale is not None
         if need_grad:
-            ctx.save_for_backward(out[:, 1].clone(), alpha.clone())
+            extra = (out[:, 2:6].clone(), noise.detach().clone(), scale.detach().clone()) if scale is not None else ()
+            ctx.save_for_backward(out[:, 1].clone(), alpha.clone(), *extra)
         return out[:, 0].clone()
 
     @staticmethod
     def backward(ctx, g):
-        dsig, alpha = ctx.saved_tensors
+        dsig, alpha = ctx.saved_tensors[:2]
         gm = g.unsqueeze(-1) * alpha / ctx.n
-        return None, gm, g * dsig, -gm, None
+        gscale = None
+        if ctx.has_scale:
+            # K = c M  =>  a'Ma = (r'a - s2 a'a)/c  and  tr(K_s^-1 M) = (N - s2 tr K_s^-1)/c
+            q, noise, c = ctx.saved_tensors[2:]
+            quad, tr, aa = q[:, 0], q[:, 2], q[:, 3]
+            gscale = (g * 0.5 * ((quad - noise * aa) - (ctx.n - noise * tr)) / (ctx.n * c.reshape(-1))).reshape(c.shape)
+            if gscale.shape != c.shape:
+                gscale = gscale.sum().reshape(c.shape)
+        return None, gm, g * dsig, -gm, None, gscale
 
 
 class ExactMarginalLogLikelihood(Module):
@@ -275,7 +315,13 @@ class ExactMarginalLogLikelihood(Module):
 
     def forward(self, function_dist, target):
         mean = function_dist.mean
-        K = function_dist.covariance_matrix
+        lazy = function_dist.lazy_covariance_matrix
+        scale = None
+        if isinstance(lazy, _ScaledDense):
+            scale = lazy.scale
+            K = lazy.scale.detach() * lazy.base
+        else:
+            K = function_dist.covariance_matrix
         batched = mean.ndim > 1
         n = mean.shape[-1]
         mean2, K3, t2 = mean.reshape(-1, n), K.reshape(-1, n, n), target.reshape(-1, n)
@@ -283,7 +329,7 @@ class ExactMarginalLogLikelihood(Module):
             raise ops._lib.VoltHipError("ExactMarginalLogLikelihood: tensors must live on the MI355X; no CPU fallback")
         noise = self.likelihood.noise.reshape(-1)
         noise = noise.expand(mean2.shape[0]) if noise.numel() == 1 else noise
-        res = _ExactMLL.apply(K3, mean2.to(torch.float32), noise.to(torch.float32), t2.to(torch.float32), self)
+        res = _ExactMLL.apply(K3, mean2.to(torch.float32), noise.to(torch.float32), t2.to(torch.float32), self, scale)
         return res.reshape(mean.shape[:-1]) if batched else res.reshape(())
 
 

@@ -4,7 +4,7 @@ gpytorch's Interval(0., 1.).  Elementwise, kept in torch; the factorisations it 
 import torch
 from torch import nn
 
-from ..gp import Kernel
+from ..gp import Kernel, _ScaledDense
 
 
 class BMKernel(Kernel):
@@ -48,4 +48,10 @@ class BMKernel(Kernel):
         return cov
 
     def __call__(self, x1, x2=None, **kwargs):
-        return super().__call__(x1, x2, **kwargs)
+        """Lazy form: keeps K = vol * min(x1, x2) factored so an exact MLL can differentiate wrt vol."""
+        if kwargs.get("diag", False) or self.batch_shape != torch.Size():
+            return super().__call__(x1, x2, **kwargs)
+        x2 = x1 if x2 is None else x2
+        a = x1[:, 0] if x1.ndim > 1 else x1
+        b = x2[:, 0] if x2.ndim > 1 else x2
+        return _ScaledDense(self.vol, torch.minimum(a.unsqueeze(-1), b.unsqueeze(-2)))

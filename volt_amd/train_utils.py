@@ -19,6 +19,33 @@ from .means import LogLinearMean, EWMAMean, DEWMAMean, TEWMAMean, MeanRevertingE
 from .models import VoltronGP, VoltMagpie
 
 
+def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm"):
+    """voltron/train_utils.py:69-95 -- SURVEY 8(f) row 1: the Brownian-motion GP over log-vol that later
+    supplies pred_vol to Rollouts.  Same loop; the MLL and its gradient wrt the kernel's `vol` and the
+    noise run on the HIP path (K = vol * min(x,x') keeps d mll / d vol in closed form, gp._ExactMLL).
+    Quirk kept: `vol_lh.noise.data = ...` (:71) assigns to a temporary in the reference and changes
+    nothing, so the noise starts at softplus(0) + 1e-4."""
+    from .models import BMGP
+    vol_lh = GaussianLikelihood().to(train_x.device)
+    vol_lh.noise.data = torch.tensor([1e-2])          # no-op, as in the reference
+    vol_model = BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device)
+
+    optimizer = torch.optim.Adam([{'params': vol_model.parameters()}], lr=0.01)
+    mll = ExactMarginalLogLikelihood(vol_lh, vol_model)
+
+    print_every = 50
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        output = vol_model(train_x)
+        loss = -mll(output, vol_path.log())
+        loss.backward()
+        if printing:
+            if i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
+        optimizer.step()
+    return vol_model, vol_lh
+
+
 def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False):
     voltron_lh = GaussianLikelihood().to(train_x.device)
     voltron = VoltronGP(train_x, train_y.log(), voltron_lh, vol_path)
