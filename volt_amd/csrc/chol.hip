@@ -472,19 +472,25 @@ __device__ __forceinline__ void trtri_body(const float* __restrict__ A, const fl
     f32x16 T[4], O[4];
     zero_acc(T);
     zero_acc(O);
-    StageRegs sr;
+    // Two register stage sets (loads issued two chunks ahead of their LDS write), buffer-addressed.
+    StageRegs sr0, sr1;
     const int srow = tid >> 3, scq = (tid & 7) * 4;
-    auto load_chunk = [&](int c) {
+    const StageAddr sa = stage_addr(Lrows, Np, Yrows, Np);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, TS * TS * 4, 0x00020000);
+    int vw[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) vw[p] = ((srow + 32 * p) * TS + scq) * 4;
+    auto load_chunk = [&](StageRegs& sr, int c) {
         if (c < n1) {
-            stage_load(sr, Lrows, Np, Yrows, Np, c * BK);
+            stage_load_buf(sr, sa, c * BK);
         } else {
-            const int p0 = (c - n1) * BK;
+            const int so = __builtin_amdgcn_readfirstlane((c - n1) * BK * 4);
 #pragma unroll
             for (int p = 0; p < 4; ++p)
-                sr.b[p] = *reinterpret_cast<const f32x4*>(W + (srow + 32 * p) * TS + p0 + scq);
+                sr.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vw[p], so, 0));
         }
     };
-    auto store_chunk = [&](int c, float* buf) {
+    auto store_chunk = [&](const StageRegs& sr, int c, float* buf) {
         if (c < n1) {
             stage_store(sr, buf);
         } else {
@@ -493,48 +499,71 @@ __device__ __forceinline__ void trtri_body(const float* __restrict__ A, const fl
             for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(sB + (srow + 32 * p) * SLD + scq) = sr.b[p];
         }
     };
-    const int nall = n1 + 4;
-    load_chunk(0);
-    store_chunk(0, smem);
-    load_chunk(1);
+    const int nall = n1 + 4;                                // >= 5
+    load_chunk(sr0, 0);
+    store_chunk(sr0, 0, smem);
+    load_chunk(sr0, 1);                                     // even-numbered stores use sr1, odd use sr0
+    load_chunk(sr1, 2);
     __syncthreads();
+    // chunk c lives in buffer c & 1; at its mid-point chunk c+1 is written (from sr0 if c is even, else
+    // sr1) and chunk c+3 is requested into the same set.
+#define VOLT_TRI_STAGE(C)                                                            \
+    {                                                                                \
+        float* nxt_ = smem + (((C) + 1) & 1) * STAGE_FLOATS;                         \
+        if (((C) & 1) == 0) {                                                        \
+            if ((C) + 1 < nall) store_chunk(sr0, (C) + 1, nxt_);                     \
+            if ((C) + 3 < nall) load_chunk(sr0, (C) + 3);                            \
+        } else {                                                                     \
+            if ((C) + 1 < nall) store_chunk(sr1, (C) + 1, nxt_);                     \
+            if ((C) + 3 < nall) load_chunk(sr1, (C) + 3);                            \
+        }                                                                            \
+    }
     int c = 0;
-    for (; c < n1; ++c) {
-        float* cur = smem + (c & 1) * STAGE_FLOATS;
-        float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
-        mma_chunk<1, 0, BK / 16>(cur, T);
-        store_chunk(c + 1, nxt);                    // c + 1 <= n1 < nall always exists
-        if (c + 2 < nall) load_chunk(c + 2);
-        mma_chunk<1, BK / 16, BK / 8>(cur, T);
+    for (; c + 1 < n1; c += 2) {                            // phase 1, two chunks per trip (static set names)
+        mma_chunk<1, 0, BK / 16>(smem, T);
+        VOLT_TRI_STAGE(c)
+        mma_chunk<1, BK / 16, BK / 8>(smem, T);
+        __syncthreads();
+        mma_chunk<1, 0, BK / 16>(smem + STAGE_FLOATS, T);
+        VOLT_TRI_STAGE(c + 1)
+        mma_chunk<1, BK / 16, BK / 8>(smem + STAGE_FLOATS, T);
         __syncthreads();
     }
+    // n1 is a multiple of 4 (128-wide blocks of 32-wide chunks), so phase 1 always ends on an even chunk
     // phase 2: out[cc][r] for cc in this wave's 32 columns, r in 4 blocks of 32.
     // registers 4g..4g+3 of T[tp] <-> p = tp*32 + 8g + 4*lh + (0..3); B fragment = W[r][p] from the stage.
 #pragma unroll
-    for (int tp = 0; tp < 4; ++tp, ++c) {
-        float* cur = smem + (c & 1) * STAGE_FLOATS;
-        float* nxt = smem + ((c + 1) & 1) * STAGE_FLOATS;
-        const float* sB = cur + TS * SLD;
+    for (int tp = 0; tp < 4; ++tp) {
+        const int cc = n1 + tp;                             // parity of cc == parity of tp
+        const float* sB = smem + (tp & 1) * STAGE_FLOATS + TS * SLD;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (g == 2) {
-                if (c + 1 < nall) store_chunk(c + 1, nxt);
-                if (c + 2 < nall) load_chunk(c + 2);
+                float* nxt_ = smem + ((tp + 1) & 1) * STAGE_FLOATS;
+                if ((tp & 1) == 0) {
+                    if (cc + 1 < nall) store_chunk(sr0, cc + 1, nxt_);
+                    if (cc + 3 < nall) load_chunk(sr0, cc + 3);
+                } else {
+                    if (cc + 1 < nall) store_chunk(sr1, cc + 1, nxt_);
+                    if (cc + 3 < nall) load_chunk(sr1, cc + 3);
+                }
             }
+            // W_i is lower triangular: W[r][p] = 0 for p > r, so row blocks rb < tp contribute nothing
             f32x4 w[4];
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb)
+            for (int rb = tp; rb < 4; ++rb)
                 w[rb] = *reinterpret_cast<const f32x4*>(sB + (rb * 32 + l31) * SLD + 8 * g + 4 * lh);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float a = T[tp][4 * g + m];
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb)
+                for (int rb = tp; rb < 4; ++rb)
                     O[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[rb][m], O[rb], 0, 0, 0);
             }
         }
         __syncthreads();
     }
+#undef VOLT_TRI_STAGE
     // O[rb] element (row = c_local, col = r_local): lane&31 = r, registers = c.  Y = -O.
     float* Yt = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
 #pragma unroll
