@@ -152,12 +152,13 @@ def main():
                        "profile")
             tot += np.array(list(ms))
         tot /= reps
-        # classes 1 and 3 are the same kernel (diag_trtri_kernel: P2(k) + trtri row k-1, and the last row alone)
-        names = ["potrf_update_kernel", "diag_trtri_kernel", "potrf_trsm_kernel"]
+        # classes 0 and 3 are the same kernel (factor_step_kernel: P1(k) + P2(k) + trtri row k-1 in one grid; the
+        # last trtri row alone); class 1 is unused since the diagonal block moved into the step kernel
+        names = ["factor_step_kernel", "potrf_trsm_kernel"]
         f4 = kernel_class_flops(B, Np)
-        flops = [f4[0], f4[1] + f4[3], f4[2]]
-        cnt = [cnt[0], cnt[1] + cnt[3], cnt[2]]
-        tot = np.array([tot[0], tot[1] + tot[3], tot[2]])
+        flops = [f4[0] + f4[1] + f4[3], f4[2]]
+        cnt = [cnt[0] + cnt[1] + cnt[3], cnt[2]]
+        tot = np.array([tot[0] + tot[1] + tot[3], tot[2]])
         dom = int(np.argmax(tot))
         ach = flops[dom] / (tot[dom] * 1e-3) / 1e12
         traffic = None

@@ -80,10 +80,8 @@ struct KSource {
 };
 
 template <bool FROMK>
-__global__ __launch_bounds__(256, 2) void potrf_update_kernel(float* __restrict__ A, int Np, int k, int B, KSource src) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    int t, b;
-    decode_tile_batch(Np / TS - k, B, t, b);
+__device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int k, int t, int b, const KSource& src,
+                                            float* smem) {
     float* Ab = A + (int64_t)b * Np * Np;
     const float* Arows = Ab + (int64_t)(k + t) * TS * Np;   // L[k+t, 0:k]
     const float* Brows = Ab + (int64_t)k * TS * Np;         // L[k,   0:k]
@@ -606,23 +604,56 @@ __device__ __forceinline__ void trtri_body(const float* __restrict__ A, const fl
     }
 }
 
-// Fused launch: workgroups [0, nd) factor + invert diagonal block k_diag of their matrix (a 90 us
-// latency chain on only B of the 256 CUs), the rest compute the tiles of trtri row i_tri, which is
-// independent work.  Either part may be absent (k_diag < 0 / i_tri < 0).
-__global__ __launch_bounds__(256, 2) void diag_trtri_kernel(float* __restrict__ A, float* __restrict__ Winv,
-                                                           float* __restrict__ Y, int* __restrict__ info, int Np,
-                                                           int k_diag, int i_tri, int B, TriReduce red) {
+// ----------------------------------------------------------------------------- fused step kernel
+// One launch per block column k carries everything that is ready at that point:
+//   workgroups [0, (n-k)B)          P1 tiles of column k; the workgroup that owns the diagonal tile (t = 0)
+//                                   goes straight on to factor and invert it (P2) -- the 90 us latency chain
+//                                   runs next to the other tiles instead of after them
+//   workgroups [(n-k)B, (n-k)B+kB)  tiles of trtri row k-1 (independent of column k)
+// so every launch has n*B tiles of comparable length, longest first (diagonal, P1 tiles with K = 128k,
+// trtri tiles with K = 128(k-j)), instead of three launches of (n-k)B, B and kB.
+//   k_upd < 0: no P1/P2 part (used for the trailing trtri row and by volt_trtri_f32)
+//   i_tri < 0: no trtri part (forward-only factorisation)
+template <bool FROMK>
+__global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                            float* __restrict__ Y, int* __restrict__ info, int Np,
+                                                            int k_upd, int i_tri, int B, KSource src, TriReduce red) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     static_assert(DIAG_LDS_FLOATS <= 2 * STAGE_FLOATS, "diag block must fit the staging area");
     static_assert(TS * WLD + TS <= 2 * STAGE_FLOATS, "W image + reduction scratch must fit");
-    const int nd = (k_diag >= 0) ? B : 0;
-    if ((int)blockIdx.x < nd) {
-        diag_body(A, Winv, info, Np, k_diag, blockIdx.x, smem);
+    const int n = Np / TS;
+    const int nupd = (k_upd >= 0) ? (n - k_upd) * B : 0;
+    if ((int)blockIdx.x < nupd) {
+        int t, b;
+        decode_tile_batch((int)blockIdx.x, n - k_upd, B, t, b);
+        if (k_upd > 0) update_body<FROMK>(A, Np, k_upd, t, b, src, smem);
+        if (t == 0) {
+            if (k_upd > 0) {
+                __threadfence_block();           // this workgroup's own C-tile stores, re-read below
+                __syncthreads();
+            }
+            diag_body(A, Winv, info, Np, k_upd, b, smem);
+        }
         return;
     }
     int j, b;
-    decode_tile_batch((int)blockIdx.x - nd, i_tri + 1, B, j, b);
+    decode_tile_batch((int)blockIdx.x - nupd, i_tri + 1, B, j, b);
     trtri_body(A, Winv, Y, Np, i_tri, j, b, red, smem);
+}
+
+// P1 alone (tuning hook: no diagonal factorisation, so it can be replayed on a finished factor)
+__global__ __launch_bounds__(256, 2) void tune_update_kernel(float* __restrict__ A, int Np, int k, int B, KSource src) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    int t, b;
+    decode_tile_batch(Np / TS - k, B, t, b);
+    update_body<false>(A, Np, k, t, b, src, smem);
+}
+
+// Block column 0: no panel update, just the diagonal blocks of the prepared column.
+__global__ __launch_bounds__(256, 2) void factor_diag0_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                             int* __restrict__ info, int Np) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    diag_body(A, Winv, info, Np, 0, blockIdx.x, smem);
 }
 
 }  // namespace volt
@@ -685,21 +716,26 @@ struct Group {
     hipStream_t s;
 };
 
+// Timer classes: 0 = factor_step_kernel (P1 + P2 + trtri row k-1), 2 = potrf_trsm (P3),
+//                3 = factor_step_kernel carrying only a trtri row (the last row; every row of volt_trtri_f32).
 static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     const int n = Np / TS, B = g.B;
     const TriReduce nored{nullptr, nullptr, nullptr, 0};
-    if (k > 0) {
-        if (tm) tm->begin(0);
-        if (g.o.src.K)
-            hipLaunchKernelGGL(potrf_update_kernel<true>, dim3((n - k) * B), dim3(256), 0, g.s, g.A, Np, k, B, g.o.src);
-        else
-            hipLaunchKernelGGL(potrf_update_kernel<false>, dim3((n - k) * B), dim3(256), 0, g.s, g.A, Np, k, B, g.o.src);
-        if (tm) tm->end();
-    }
     const int itri = (g.o.Y && k > 0) ? k - 1 : -1;
-    if (tm) tm->begin(1);
-    hipLaunchKernelGGL(diag_trtri_kernel, dim3(B + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s, g.A, g.Winv,
-                       g.o.Y, g.info, Np, k, itri, B, g.o.Y ? g.o.red : nored);
+    // k = 0 has no panel update: only the diagonal blocks of the prepared first column (t = 0 of n tiles
+    // would waste n-1 idle workgroups per matrix, so the grid is cut to the diagonal tile alone)
+    const int nupd = (k == 0) ? B : (n - k) * B;
+    if (tm) tm->begin(0);
+    if (k == 0) {
+        // decode_tile_batch(w, n - 0, B) would spread t over n tiles: launch with a private tile count of 1
+        hipLaunchKernelGGL(factor_diag0_kernel, dim3(B), dim3(256), 0, g.s, g.A, g.Winv, g.info, Np);
+    } else if (g.o.src.K) {
+        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
+                           g.A, g.Winv, g.o.Y, g.info, Np, k, itri, B, g.o.src, g.o.Y ? g.o.red : nored);
+    } else {
+        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
+                           g.A, g.Winv, g.o.Y, g.info, Np, k, itri, B, g.o.src, g.o.Y ? g.o.red : nored);
+    }
     if (tm) tm->end();
     if (k + 1 < n) {
         if (tm) tm->begin(2);
@@ -708,8 +744,8 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     }
     if (k + 1 == n && g.o.Y) {
         if (tm) tm->begin(3);
-        hipLaunchKernelGGL(diag_trtri_kernel, dim3(n * B), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, -1, n - 1,
-                           B, g.o.red);
+        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(n * B), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
+                           -1, n - 1, B, g.o.src, g.o.red);
         if (tm) tm->end();
     }
 }
@@ -819,8 +855,9 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
     const TriReduce nored{nullptr, nullptr, nullptr, 0};
     for (int i = 0; i < n; ++i) {
         if (tm) tm->begin(3);
-        hipLaunchKernelGGL(diag_trtri_kernel, dim3((i + 1) * B), dim3(256), 0, s, const_cast<float*>(A),
-                           const_cast<float*>(Winv), Y, nullptr, Np, -1, i, B, nored);
+        hipLaunchKernelGGL(factor_step_kernel<false>, dim3((i + 1) * B), dim3(256), 0, s, const_cast<float*>(A),
+                           const_cast<float*>(Winv), Y, nullptr, Np, -1, i, B, KSource{nullptr, 0, 0, nullptr, 0.f, 0},
+                           nored);
         if (tm) tm->end();
     }
     VOLT_LAUNCH_CHECK();
@@ -871,7 +908,7 @@ int volt_tune_update_f32(float* A, int B, int Np, int k, int var, int reps, void
     hipStream_t s = (hipStream_t)stream;
     const KSource none{nullptr, 0, 0, nullptr, 0.f, 0};
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(potrf_update_kernel<false>, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, none);
+        hipLaunchKernelGGL(tune_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, none);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
