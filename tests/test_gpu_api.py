@@ -301,3 +301,22 @@ def test_train_vol_model_gradients_match_fp64_autograd(va):
         model2.train()
         end = -ExactMarginalLogLikelihood(lh2, model2)(model2(tx), dev(vol).log())
     assert torch.isfinite(end) and float(end) < float(loss)
+
+
+# ------------------------------------------------------------------ next row (f)3: driver loop + output format
+def test_batched_forecast_driver_writes_reference_layout(va, tmp_path):
+    from volt_amd.forecast import GenerateStockPredictionsBatch
+    B, T, ntrain, H, S = 3, 70, 64, 4, 5
+    x, F, vol = sde_batch(B, T - 1, seed=77)
+    closes = dev(F)                                              # [B, T]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    out = GenerateStockPredictionsBatch(["AAA", "BBB", "CCC"], closes, forecast_horizon=H, train_iters=3, nsample=S,
+                                        ntrain=ntrain, mean="ewma", save=True, k=10, ntimes=2, vol_iters=2,
+                                        par_dir=str(tmp_path), generator=g)
+    assert tuple(out.shape) == (B, S, H) and torch.isfinite(out).all()
+    files = sorted(p.name for p in (tmp_path / "BBB").iterdir())
+    assert len(files) == 2 and all(f.startswith("volt_ewma10_") and f.endswith(".pt") for f in files)
+    saved = torch.load(tmp_path / "CCC" / files[-1])
+    assert tuple(saved.shape) == (S, H) and torch.equal(saved, out[2])
+    # log-price scale: forecasts start near the last observed log price
+    assert float((out[:, :, 0].mean(1) - closes[:, ntrain * 0 + T - 1 - ((T - ntrain) % 3) * 0 - 1].log().cpu()).abs().max()) < 0.5

@@ -1,0 +1,86 @@
+"""Batched forecast driver -- SURVEY 8(f) row 3: the sliding-window schedule and output format of
+experiments/stocks/GenerateMultiMeanPreds.py:63-137, with the reference's per-ticker Python ``for``
+(ForecastGenerator.py:27-41) replaced by one batched pass per window:
+
+    window -> [vol paths] -> TrainVoltMagpieBatch (all tickers in one batched model, HIP MLL step)
+           -> TrainVolModel + posterior sample of the vol forecaster per ticker (BM-GP, HIP factorisation)
+           -> rollout engine for all tickers x paths in one launch
+           -> torch.save(samples[S,H], "saved-outputs/<ticker>/<model>_<date>.pt")      (:128)
+
+The GPCV volatility extraction (LearnGPCV, train_utils.py:15-67: variational, out of scope) is a
+caller-supplied hook ``vol_fn(train_x, prices) -> vol [B, N]``; ``realised_vol`` below is a simple
+stand-in so the driver runs end to end on synthetic data -- it is NOT the reference's GPCV.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import rollout_engine
+from .distributed import shard_range
+from .means import EWMAMean, DEWMAMean, TEWMAMean
+from .train_utils import TrainVoltMagpieBatch, TrainVolModel
+
+_MODES = {"ewma": 0, "dewma": 1, "tewma": 2}
+
+
+def realised_vol(train_x, prices, span=20, floor=1e-3):
+    """Annualised EWMA of |log-returns| -- a stand-in for the GPCV scale (NOT the reference's estimator).
+    prices [B, N+1] -> vol [B, N]."""
+    dt = (train_x[1] - train_x[0]).item()
+    r = (prices[:, 1:].log() - prices[:, :-1].log()).abs() / dt ** 0.5
+    from . import ops
+    v = ops.ewma(r, span)[:, 1:]
+    return v.clamp_min(floor)
+
+
+def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=20, train_iters=400, nsample=1000,
+                                  ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=realised_vol,
+                                  vol_iters=None, par_dir="./saved-outputs/", generator=None):
+    """closes [B, T] prices for B tickers on a common calendar (device tensor).  Same window schedule,
+    model name and file layout as GenerateStockPredictions (GenerateMultiMeanPreds.py:69-83,128).
+    Under torch.distributed each rank takes a contiguous shard of the tickers.  Returns the samples of
+    the last window, [B_local, nsample, forecast_horizon] on the CPU."""
+    if mean not in _MODES:
+        raise NotImplementedError("the batched driver covers the EWMA mean family (Rollouts path, :110-112)")
+    dev = closes.device
+    lo, hi = shard_range(len(tickers))
+    tickers, closes = list(tickers)[lo:hi], closes[lo:hi]
+    B, T = closes.shape
+    if ntimes == -1:
+        end_idxs = torch.arange(ntrain, T)
+    else:
+        end_idxs = torch.arange(ntrain, T, int((T - ntrain) / ntimes))
+    dt = 1. / 252
+    model_name = "volt_" + mean + str(k) + "_"
+    vol_iters = train_iters if vol_iters is None else vol_iters
+    last = None
+    for last_day in end_idxs.tolist():
+        date = str(last_day) if dates is None else str(dates[last_day])
+        train_y = closes[:, last_day - ntrain:last_day].float()                       # [B, ntrain] prices
+        train_x = torch.arange(ntrain - 1, device=dev) * dt                             # :89
+        test_x = torch.arange(forecast_horizon, device=dev) * dt + train_x[-1] + train_x[1]     # :90
+        vol = vol_fn(train_x, train_y)                                                  # [B, ntrain-1]
+        # data model: all tickers in one batched VoltMagpie (per-ticker noise), :104-108
+        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=train_iters, k=k)
+        if mean != "ewma":
+            cls = {"dewma": DEWMAMean, "tewma": TEWMAMean}[mean]
+            model.mean_module = cls(train_x, train_y[:, 1:].log(), k)
+        # vol forecaster per ticker (BM-GP over log-vol, :102) and its posterior sample (rollout_utils.py:66)
+        pred_vol = torch.empty(B, nsample, forecast_horizon, device=dev)
+        for b in range(B):
+            vmod, vlh = TrainVolModel(train_x, vol[b], train_iters=vol_iters)
+            vmod.eval()
+            pred_vol[b] = vmod(test_x).sample(torch.Size((nsample,))).exp()
+        z = torch.randn(B, nsample, forecast_horizon, device=dev, generator=generator)
+        samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
+                                                      _MODES[mean], k)
+        last = samples.cpu()
+        if save:
+            os.makedirs(par_dir, exist_ok=True)
+            for b, tckr in enumerate(tickers):
+                savepath = os.path.join(par_dir, tckr)
+                os.makedirs(savepath, exist_ok=True)
+                torch.save(last[b], os.path.join(savepath, model_name + date + ".pt"))  # :128
+    return last
