@@ -80,6 +80,25 @@ def test_mll_autograd_matches_oracle(va):
     assert np.abs(gm - o["d_mean"]).max() <= 1e-4 * np.abs(o["d_mean"]).max()
 
 
+def test_mll_jitter_ladder_like_psd_safe_cholesky(va):
+    """A matrix that fails plain fp32 Cholesky but passes with gpytorch's 1e-6..1e-4 jitter ladder warns
+    and returns a finite value."""
+    import warnings
+    from volt_amd.gp import ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal, NumericalWarning
+    n = 256
+    u = torch.randn(n, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0))
+    K = u @ u.T - 2e-5 * torch.eye(n, device="cuda")            # rank 3, slightly indefinite
+    lh = GaussianLikelihood().cuda()
+    lh.noise_covar.raw_noise.data.fill_(-30.0)                    # sigma^2 = 1e-4 floor: K + s2 I barely not PD in fp32
+    K = K - 1.0e-4 * torch.eye(n, device="cuda")                  # cancel the floor: eigenvalues ~ -2e-5
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        val = ExactMarginalLogLikelihood(lh, None)(MultivariateNormal(torch.zeros(n, device="cuda"), K),
+                                                    torch.zeros(n, device="cuda"))
+    assert torch.isfinite(val)
+    assert any(issubclass(x.category, NumericalWarning) for x in w)
+
+
 def test_mll_raises_on_non_pd(va):
     from volt_amd.gp import ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal, NotPSDError
     n = 130

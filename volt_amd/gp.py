@@ -266,14 +266,23 @@ class _ExactMLL(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[1:4]) or (scale is not None and ctx.needs_input_grad[5])
         ws = holder.workspace(B, n, need_grad, K.device)
         resid = (target - mean).to(torch.float32)
-        jitter = 0.0
-        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter)
+        # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
+        # NumericalWarning, then NotPSDError.  Same ladder here; the jitter is added inside the fused step.
+        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0)
         bad = int((info != 0).sum().item())
         if bad:
-            if torch.isnan(K).any() or torch.isnan(resid).any():
-                raise NanError("cholesky: NaN in the covariance or the residual")
-            raise NotPSDError(f"K + sigma^2 I not positive definite for {bad} of {B} series "
-                              f"(first failing pivot {int(info[info != 0][0].item())})")
+            if torch.isnan(K).any() or torch.isnan(resid).any() or torch.isnan(noise).any():
+                raise NanError("cholesky: NaN in the covariance, the noise or the residual")
+            first = int(info[info != 0][0].item())
+            for i in range(3):
+                jitter = 1e-6 * (10 ** i)
+                out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter)
+                if not bool((info != 0).any().item()):
+                    warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
+                    break
+            else:
+                raise NotPSDError(f"K + sigma^2 I not positive definite for {bad} of {B} series after jitter "
+                                  f"(first failing pivot {first})")
         ctx.n = n
         ctx.has_scale = scale is not None
         if need_grad:
