@@ -7,7 +7,7 @@ import os
 
 import torch  # noqa: F401  -- load torch's libamdhip64 first so the library binds the same HIP runtime
 
-from .build import LIB
+from .build import LIB, build_lib
 
 _lib = None
 ABI_VERSION = 1
@@ -47,9 +47,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(LIB):
-            raise VoltHipError(
-                f"{LIB} not found: build it with `python -m volt_amd.build` (hipcc, gfx950). "
-                "volt_amd has no CPU fallback.")
+            try:                                   # a source-only checkout: compile once (hipcc, ~30 s)
+                build_lib(verbose=False)
+            except Exception as e:
+                raise VoltHipError(
+                    f"{LIB} not found and could not be built ({e}): run `python -m volt_amd.build` "
+                    "(hipcc, gfx950). volt_amd has no CPU fallback.") from e
         handle = C.CDLL(LIB)
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)           # AttributeError if the symbol is missing
