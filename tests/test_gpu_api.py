@@ -339,3 +339,35 @@ def test_batched_forecast_driver_writes_reference_layout(va, tmp_path):
     assert tuple(saved.shape) == (S, H) and torch.equal(saved, out[2])
     # log-price scale: forecasts start near the last observed log price
     assert float((out[:, :, 0].mean(1) - closes[:, ntrain * 0 + T - 1 - ((T - ntrain) % 3) * 0 - 1].log().cpu()).abs().max()) < 0.5
+
+
+def test_model_method_generate_prediction_twin(va):
+    """VoltronGP.GeneratePrediction(test_x, pred_vol, n_sample) (VoltronGP.py:62-95, the notebook's cell 15):
+    H-point joint prediction with n_sample draws, checked against the oracle's GeneratePrediction restatement
+    with the same N(0,1) draws (CPU generator, as torch.randn(...) in the reference)."""
+    from volt_amd.gp import GaussianLikelihood
+    from volt_amd.models import VoltronGP
+    n, T, ns = 90, 6, 3
+    F, vol = sde_series(n, 31)
+    tx = torch.arange(n, device="cuda") / 252.
+    test_x = torch.arange(T, device="cuda") / 252. + tx[-1] + tx[1]
+    m = VoltronGP(tx, dev(F)[1:].log(), GaussianLikelihood().cuda(), dev(vol))
+    with torch.no_grad():
+        m.mean_module.weights.fill_(0.3)
+        m.mean_module.bias.fill_(2.2)
+    pv = dev(np.full(T, vol[-1], dtype=np.float32))
+    torch.manual_seed(11)
+    out = m.GeneratePrediction(test_x, pv, ns)                      # [T, ns]
+    torch.manual_seed(11)
+    z = torch.randn(T, ns).numpy()
+    x = (np.arange(n) / 252.).astype(np.float32)
+    txn = test_x.cpu().numpy()
+    lin = lambda q: (0.3 * np.asarray(q, dtype=np.float32).reshape(-1) + 2.2).astype(np.float32)
+    assert tuple(out.shape) == (T, ns)
+    for c in range(ns):
+        ref = vo.generate_prediction(x, np.log(F[1:]), np.log(m.log_vol_path.exp().cpu().numpy()), txn,
+                                     pv.cpu().numpy()[None], z[None, :, c:c + 1], lin, jitter=None)
+        np.testing.assert_allclose(out[:, c].cpu().numpy(), ref[0], atol=2e-3, rtol=0)
+    m.vol_model.eval()
+    s = m.SamplePrediction(test_x, n_sample=2)
+    assert tuple(s.shape) == (T, 2) and torch.isfinite(s).all()

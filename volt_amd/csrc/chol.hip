@@ -921,7 +921,7 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
     FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}};
-    return run_factor(A, Winv, info, B, Np, (hipStream_t)stream, o, nullptr);
+    return run_factor_groups(A, Winv, info, B, Np, (hipStream_t)stream, o);
 }
 
 int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv,

@@ -57,7 +57,9 @@ class VoltronGP(ExactGP):
 
     def SamplePrediction(self, test_x, n_sample=1, return_vol=False):
         self.vol_model.eval()
-        pred_vol = self.vol_model(test_x).sample().exp().transpose(-1, -2)
+        pred_vol = self.vol_model(test_x).sample().exp()
+        if pred_vol.ndim > 1:                    # reference: .transpose(-1, -2) unconditionally, which only
+            pred_vol = pred_vol.transpose(-1, -2)   # works for its multitask vol model ([H, T] samples)
         prediction = self.GeneratePrediction(test_x, pred_vol, n_sample)
         if return_vol:
             return prediction, pred_vol
@@ -65,7 +67,9 @@ class VoltronGP(ExactGP):
 
     def MeanPrediction(self, test_x, n_sample=1, return_vol=False):
         self.vol_model.eval()
-        pred_vol = self.vol_model(test_x).mean.exp().transpose(-1, -2)
+        pred_vol = self.vol_model(test_x).mean.exp()
+        if pred_vol.ndim > 1:
+            pred_vol = pred_vol.transpose(-1, -2)
         prediction = self.GeneratePrediction(test_x, pred_vol, n_sample)
         if return_vol:
             return prediction, pred_vol
