@@ -1,28 +1,18 @@
 // Marginal log likelihood + analytic gradient.
 //   reference: loss = -mll(model(x), y); loss.backward()  -- voltron/train_utils.py:243-250,
 //   :130-139, voltron/models/Volt.py:133-146; arithmetic in gpytorch ExactMarginalLogLikelihood.
-// All O(N^2) passes here are HBM-bound streams over Y = L^-T (upper triangle only).
+// The O(N^2) passes here are HBM-bound streams over Y = L^-T (upper triangle only); the first of them
+// (z = Y'r partials, Frobenius partials) is fused into the trtri epilogue in chol.hip.
 #include "common.h"
 #include "../../include/volt_hip.h"
 #include <math.h>
 
 namespace volt {
 
-constexpr int VLD2 = TS + 1;
-
 __global__ void pad_resid_kernel(const float* __restrict__ resid, float* __restrict__ rpad, int N, int Np) {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Np) rpad[(int64_t)b * Np + i] = (i < N) ? resid[(int64_t)b * N + i] : 0.f;
-}
-
-__device__ __forceinline__ void upper_tile(int t, int& jb, int& cb) {
-    // t enumerates (cb, jb <= cb) like a lower-triangular index with roles swapped
-    int ti = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    while (ti * (ti + 1) / 2 > t) --ti;
-    cb = ti;
-    jb = t - ti * (ti + 1) / 2;
 }
 
 // R2: z[c] = sum_{jb <= cb} zpart[jb][c]
