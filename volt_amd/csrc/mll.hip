@@ -174,7 +174,7 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     if (N < 1) return -12;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const int Np = volt_padded_n(N), n = Np / TS;
+    const int Np = volt_padded_n(N);
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
