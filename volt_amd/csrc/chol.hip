@@ -79,19 +79,24 @@ struct KSource {
     int N;
 };
 
+// Tile (rowblk, colblk) of the working matrix:  C <- C0 - sum_{m = kb0}^{kb1-1} L[rowblk, m] L[colblk, m]^T,
+// where C0 is the tile as it stands in A, or -- when `fromk` -- the caller's K (+ sigma2/jitter on the
+// diagonal, identity in the padding).  kb0 > 0 continues an update begun by an earlier launch (diagonal
+// look-ahead, see factor_step_kernel).
 template <bool FROMK>
-__device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int k, int t, int b, const KSource& src,
-                                            float* smem) {
+__device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int rowblk, int colblk, int kb0, int kb1,
+                                            bool fromk, int b, const KSource& src, float* smem) {
     float* Ab = A + (int64_t)b * Np * Np;
-    const float* Arows = Ab + (int64_t)(k + t) * TS * Np;   // L[k+t, 0:k]
-    const float* Brows = Ab + (int64_t)k * TS * Np;         // L[k,   0:k]
+    const float* Arows = Ab + (int64_t)rowblk * TS * Np + (int64_t)kb0 * TS;   // L[rowblk, kb0:kb1]
+    const float* Brows = Ab + (int64_t)colblk * TS * Np + (int64_t)kb0 * TS;   // L[colblk, kb0:kb1]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    float* C = Ab + (int64_t)(k + t) * TS * Np + (int64_t)k * TS;
+    float* C = Ab + (int64_t)rowblk * TS * Np + (int64_t)colblk * TS;
     f32x16 acc[4], cpre[4];
     zero_acc(acc);
-    const float add = FROMK ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
-    const float* Kb = FROMK ? src.K + (int64_t)b * src.bsk : nullptr;
+    const bool usek = FROMK && fromk;                      // workgroup-uniform
+    const float add = usek ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
+    const float* Kb = usek ? src.K + (int64_t)b * src.bsk : nullptr;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -100,8 +105,8 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int k
             for (int q = 0; q < 16; ++q) {
                 const int r = wr * 64 + tm * 32 + accrow(q, lane);
                 const int c = wc * 64 + tn * 32 + (lane & 31);
-                if (FROMK) {
-                    const int gi = (k + t) * TS + r, gj = k * TS + c;
+                if (usek) {
+                    const int gi = rowblk * TS + r, gj = colblk * TS + c;
                     float v = (gi < src.N && gj < src.N) ? Kb[(int64_t)gi * src.ldk + gj] : 0.f;
                     if (gi == gj) v = (gi < src.N) ? v + add : 1.f;
                     cpre[tm * 2 + tn][q] = v;
@@ -109,7 +114,7 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int k
                     cpre[tm * 2 + tn][q] = C[(int64_t)r * Np + c];
                 }
             }
-    gemm_nt_128<0>(Arows, Np, Brows, Np, k * (TS / BK), acc, smem);
+    gemm_nt_128<0>(Arows, Np, Brows, Np, (kb1 - kb0) * (TS / BK), acc, smem);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -622,11 +627,25 @@ __global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__
     static_assert(DIAG_LDS_FLOATS <= 2 * STAGE_FLOATS, "diag block must fit the staging area");
     static_assert(TS * WLD + TS <= 2 * STAGE_FLOATS, "W image + reduction scratch must fit");
     const int n = Np / TS;
+    // Diagonal look-ahead: the long part of the update of diagonal tile (k+1,k+1), blocks m < k, does not
+    // need column k, so it is done HERE (one extra workgroup per matrix, first in the grid); the next
+    // launch's diagonal workgroup then only applies block m = k (K = 128) before its 128-pivot chain, and is
+    // no longer the longest workgroup of its launch.
+    const int npre = (k_upd >= 1 && k_upd + 1 < n) ? B : 0;
     const int nupd = (k_upd >= 0) ? (n - k_upd) * B : 0;
-    if ((int)blockIdx.x < nupd) {
+    int w = blockIdx.x;
+    if (w < npre) {
+        update_body<FROMK>(A, Np, k_upd + 1, k_upd + 1, 0, k_upd, true, w, src, smem);
+        return;
+    }
+    w -= npre;
+    if (w < nupd) {
         int t, b;
-        decode_tile_batch((int)blockIdx.x, n - k_upd, B, t, b);
-        if (k_upd > 0) update_body<FROMK>(A, Np, k_upd, t, b, src, smem);
+        decode_tile_batch(w, n - k_upd, B, t, b);
+        if (k_upd > 0) {
+            if (t == 0 && k_upd >= 2) update_body<FROMK>(A, Np, k_upd, k_upd, k_upd - 1, k_upd, false, b, src, smem);
+            else update_body<FROMK>(A, Np, k_upd + t, k_upd, 0, k_upd, true, b, src, smem);
+        }
         if (t == 0) {
             if (k_upd > 0) {
                 __threadfence_block();           // this workgroup's own C-tile stores, re-read below
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__
         return;
     }
     int j, b;
-    decode_tile_batch((int)blockIdx.x - nupd, i_tri + 1, B, j, b);
+    decode_tile_batch(w - nupd, i_tri + 1, B, j, b);
     trtri_body(A, Winv, Y, Np, i_tri, j, b, red, smem);
 }
 
@@ -646,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void tune_update_kernel(float* __restrict__
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     int t, b;
     decode_tile_batch(Np / TS - k, B, t, b);
-    update_body<false>(A, Np, k, t, b, src, smem);
+    update_body<false>(A, Np, k + t, k, 0, k, true, b, src, smem);
 }
 
 // Block column 0: no panel update, just the diagonal blocks of the prepared column.
@@ -725,15 +744,16 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     // k = 0 has no panel update: only the diagonal blocks of the prepared first column (t = 0 of n tiles
     // would waste n-1 idle workgroups per matrix, so the grid is cut to the diagonal tile alone)
     const int nupd = (k == 0) ? B : (n - k) * B;
+    const int npre = (k >= 1 && k + 1 < n) ? B : 0;          // diagonal look-ahead workgroups (factor_step_kernel)
     if (tm) tm->begin(0);
     if (k == 0) {
         // decode_tile_batch(w, n - 0, B) would spread t over n tiles: launch with a private tile count of 1
         hipLaunchKernelGGL(factor_diag0_kernel, dim3(B), dim3(256), 0, g.s, g.A, g.Winv, g.info, Np);
     } else if (g.o.src.K) {
-        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
+        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(npre + nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
                            g.A, g.Winv, g.o.Y, g.info, Np, k, itri, B, g.o.src, g.o.Y ? g.o.red : nored);
     } else {
-        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
+        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(npre + nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
                            g.A, g.Winv, g.o.Y, g.info, Np, k, itri, B, g.o.src, g.o.Y ? g.o.red : nored);
     }
     if (tm) tm->end();
