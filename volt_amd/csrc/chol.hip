@@ -2,10 +2,10 @@
 //   reference call sites: gpytorch MVN.log_prob -> torch.linalg.cholesky (via train_utils.py:249),
 //   psd_safe_cholesky / torch.cholesky_solve at voltron/rollout_utils.py:35,36,44.
 //
-// Layout: A [B,Np,Np] row-major fp32, Np a multiple of 128, lower triangle referenced.  All
-// matrices of the batch advance in lockstep, one launch per stage; a launch's grid is
-// (tiles of the stage) x B so the batch supplies the parallelism a single 4096^2 factorisation
-// lacks in its late panels.
+// Layout: A [B,Np,Np] row-major fp32, Np a multiple of 128, lower triangle referenced.  The matrices
+// of a group advance together, a launch's grid is (tiles of the stage) x B, so the batch supplies the
+// parallelism a single 4096^2 factorisation lacks in its late panels; the batch itself is cut into
+// groups that run the same launch sequence on different streams (run_factor_groups).
 //
 // Left-looking by 128-wide block columns k = 0..n-1:
 //   P1  panel update   A[i,k] -= sum_{m<k} L[i,m] L[k,m]^T   (i >= k)   fp32 MFMA, K = 128 k
@@ -14,6 +14,8 @@
 // Left-looking keeps the accumulator of a panel tile in registers across the whole K range, so
 // each tile of L is written once (N^2/2 words) instead of read-modify-written n times as in a
 // right-looking sweep; HBM traffic is the operand reads, N^3/(6*128) words per matrix.
+// P1 and P2 (and a row of the triangular inverse) share ONE launch per block column
+// (factor_step_kernel); P3 is the second.
 #include "common.h"
 #include "../../include/volt_hip.h"
 #include <mutex>
@@ -714,10 +716,9 @@ struct LaunchTimer {
     }
 };
 
-// One factorisation (+ optional inverse) of the whole batch.  Launch sequence per block column k:
-//     P1(k)  ->  [ P2(k)  U  trtri row k-1 ]  ->  P3(k)        and finally trtri row n-1.
-// Timer classes: 0 = potrf_update (P1), 1 = diag_trtri (fused P2 + trtri row), 2 = potrf_trsm (P3),
-//                3 = trtri_row alone (the last row; every row when called through volt_trtri_f32).
+// One factorisation (+ optional inverse).  Launch sequence per block column k:
+//     factor_step_kernel(k) = [look-ahead for k+1 | P1(k) + P2(k) | trtri row k-1]  ->  P3(k)
+// and finally the trtri row n-1 alone.
 struct FactorOpts {
     KSource src;            // src.K != nullptr: block columns >= 1 take their C tiles straight from K
     float* Y;               // nullptr: no triangular inverse
