@@ -165,7 +165,8 @@ def main():
         try:      # HBM bytes per launch from the PMC passes (scripts/pmc.sh + scripts/pmc_traffic.py), same workload only
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pj["config"] == {"n": n, "batch": B}:
-                traffic = round(pj["kernels"][names[dom].split("(")[0]]["bytes_per_launch"])
+                key = names[dom] + ("<true>" if names[dom] == "factor_step_kernel" else "")   # the K-reading instantiation
+                traffic = round(pj["kernels"][key]["bytes_per_launch"])
         except Exception:
             traffic = None
         roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,

@@ -27,7 +27,8 @@ for k in names:
     if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "SQ_BUSY_CYCLES" in a:
         # MFMA busy cycles are summed over SIMDs? report ratios that are unit-free
         if a.get("GRBM_GUI_ACTIVE"):
-            print(f"   mfma_busy / (gui_active * 256 CU * 4 SIMD)  = {a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] * 1024):.3f}")
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
+            print(f"   MFMA pipe utilisation = mfma_busy / (gui_active/8 * 1024 SIMDs) = {a['SQ_VALU_MFMA_BUSY_CYCLES'] / (a['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f}")
         if a.get("SQ_WAVE_CYCLES"):
             w = a["SQ_WAVE_CYCLES"]
             print(f"   wait_any/wave {a.get('SQ_WAIT_ANY',0)/w:.3f}  wait_inst_any/wave {a.get('SQ_WAIT_INST_ANY',0)/w:.3f}  active_inst_any/wave {a.get('SQ_ACTIVE_INST_ANY',0)/w:.3f}")

@@ -14,7 +14,7 @@ agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(lambda: defaultdict(int))
 for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("volt::", "").replace("void ", "").split("<")[0]
+        k = row["Kernel_Name"].split("(")[0].replace("volt::", "").replace("void ", "")   # keeps <true>/<false>
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
 out = {"config": {"n": n, "batch": batch}, "source": root, "correction": "read bytes = 2 * FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
