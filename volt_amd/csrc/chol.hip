@@ -824,11 +824,18 @@ static int pick_groups(int B) {
     return want;
 }
 
-static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o) {
+typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
+
+static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o,
+                             volt_group_post_fn post = nullptr, void* post_ctx = nullptr) {
     const int n = Np / TS;
     const int G = pick_groups(B);
     StreamPool* pool = G > 1 ? stream_pool() : nullptr;
-    if (G == 1 || !pool) return run_factor(A, Winv, info, B, Np, s, o, nullptr);
+    if (G == 1 || !pool) {
+        const int rc = run_factor(A, Winv, info, B, Np, s, o, nullptr);
+        if (rc == 0 && post) post(post_ctx, 0, B, s);
+        return rc;
+    }
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
     const int Bg = B / G;
@@ -860,6 +867,8 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     }
     for (int k = 0; k < n; ++k)
         for (int g = 0; g < G; ++g) enqueue_step(grp[g], Np, k, nullptr);
+    if (post)
+        for (int g = 0; g < G; ++g) post(post_ctx, g * Bg, Bg, grp[g].s);
     for (int g = 1; g < G; ++g) {
         if ((e = hipEventCreateWithFlags(&join[g], hipEventDisableTiming)) != hipSuccess) return (int)e;
         (void)hipEventRecord(join[g], grp[g].s);
@@ -888,13 +897,13 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, float* ms_host, int* launches_host) {
+                         void* stream, float* ms_host, int* launches_host, volt_group_post_fn post, void* post_ctx) {
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
     // block column 0 (no panel update there) is copied; the others are read from K inside P1
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
     FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}};
-    if (!ms_host) return run_factor_groups(A, Winv, info, B, Np, s, o);
+    if (!ms_host) return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
     LaunchTimer tm(s);
     const int rc = run_factor(A, Winv, info, B, Np, s, o, &tm);
     if (rc) return rc;
@@ -957,7 +966,7 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
     if (!ms_host) return -12;
     if (!launches_host) return -13;
     return volt_internal_factor(K, ldk, bsk, sigma2, 0.f, A, Winv, Y, info, nullptr, nullptr, nullptr, B, N, stream,
-                                ms_host, launches_host);
+                                ms_host, launches_host, nullptr, nullptr);
 }
 
 int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out, float* scratch, int B,

@@ -149,9 +149,46 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
 
 using namespace volt;
 
+// chol.hip: runs the factorisation group by group on the library's streams and calls `post` on each group's
+// stream when that group's factor (+ inverse) is enqueued, so the O(N^2) tail of one group overlaps the other
+// groups' MFMA work instead of running after the join.
+typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, float* ms_host, int* launches_host);
+                         void* stream, float* ms_host, int* launches_host, volt_group_post_fn post, void* post_ctx);
+
+namespace {
+struct TailCtx {
+    volt::MllWs w;
+    const float* sigma2;
+    float jitter;
+    float* out;
+    float* alpha;
+    int N, Np, want_grad;
+};
+
+void mll_tail(void* vctx, int b0, int Bg, hipStream_t s) {
+    const TailCtx& c = *static_cast<const TailCtx*>(vctx);
+    const int Np = c.Np, n = Np / TS;
+    const int64_t mat = (int64_t)Np * Np;
+    float* z = c.w.z + (int64_t)b0 * Np;
+    float* apad = c.w.apad + (int64_t)b0 * Np;
+    const float* A = c.w.A + b0 * mat;
+    if (c.want_grad) {
+        const float* Y = c.w.Y + b0 * mat;
+        hipLaunchKernelGGL(sum_zpart_kernel, dim3((Np + 255) / 256, Bg), dim3(256), 0, s,
+                           c.w.zpart + (int64_t)b0 * n * Np, z, Np);
+        hipLaunchKernelGGL(y_times_z_kernel, dim3((Np / 16) * Bg), dim3(256), 0, s, Y, z, apad, Np, Bg);
+    } else {
+        (void)volt_trsv_lower_f32(A, c.w.Winv + (int64_t)b0 * n * TS * TS, c.w.rpad + (int64_t)b0 * Np, z,
+                                  c.w.scratch + (int64_t)b0 * Np, Bg, Np, (void*)s);
+    }
+    hipLaunchKernelGGL(mll_scalars_kernel, dim3(Bg), dim3(256), 0, s, A, z, apad,
+                       c.want_grad ? c.w.frob + (int64_t)b0 * (n * (n + 1) / 2) : nullptr,
+                       c.sigma2 ? c.sigma2 + b0 : nullptr, c.jitter, c.out + (int64_t)b0 * 8,
+                       c.alpha ? c.alpha + (int64_t)b0 * c.N : nullptr, c.N, Np, c.want_grad);
+}
+}  // namespace
 
 extern "C" {
 
@@ -178,17 +215,11 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
+    TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
-                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, nullptr, nullptr)))
+                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, nullptr, nullptr,
+                                   mll_tail, &ctx)))
         return rc > 0 ? rc : -1;
-    if (want_grad) {
-        hipLaunchKernelGGL(sum_zpart_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, w.zpart, w.z, Np);
-        hipLaunchKernelGGL(y_times_z_kernel, dim3((Np / 16) * B), dim3(256), 0, s, w.Y, w.z, w.apad, Np, B);
-    } else {
-        if ((rc = volt_trsv_lower_f32(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
-    }
-    hipLaunchKernelGGL(mll_scalars_kernel, dim3(B), dim3(256), 0, s, w.A, w.z, w.apad, w.frob, sigma2, jitter, out,
-                       alpha, N, Np, want_grad);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
