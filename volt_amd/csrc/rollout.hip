@@ -16,7 +16,8 @@
 // step against the stored dense rows of L_s -- O(idx^2) words streamed per step, HBM-bound.
 //
 // One wave per sample (a sample's recursion is sequential in idx and in the substitution index);
-// 4 samples per workgroup, EWMA histories in LDS.  H <= 256: a lane owns entries lane + 64 t.
+// 4 samples per workgroup, EWMA histories in LDS.  H <= 256: a lane owns the 4 consecutive entries
+// 4*lane + t, so a stored row is read and written with one 16-byte access per lane.
 #include "common.h"
 #include "../../include/volt_hip.h"
 
@@ -78,12 +79,13 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     const float* pv = p.pred_vol + row;
     const float* zz = p.z + row;
     float* out = p.samples + row;
-    float* Ls = p.Ls + row * H;
+    const int Hs = (H + 3) & ~3;                            // row stride of the factor store (16-byte rows)
+    float* Ls = p.Ls + ((size_t)g * p.S + s) * H * Hs;
     double acc = p.acc0[g];
     float ema_prev = (p.mean_mode == 3) ? p.ema_prev[g] : 0.f;
     int bad = 0;
 
-    float U[4] = {0.f, 0.f, 0.f, 0.f};      // U_s[N+a]  for a = lane + 64 t
+    float U[4] = {0.f, 0.f, 0.f, 0.f};      // U_s[N+a]  for a = 4 lane + t
     float rd[4] = {0.f, 0.f, 0.f, 0.f};     // 1 / L_s[a][a]
     float zs[4] = {0.f, 0.f, 0.f, 0.f};     // z_s[a]
     float wv[4];
@@ -101,12 +103,10 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = a0 + r;
-                const float* La = Ls + (size_t)a * H;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a < idx && 4 * lane < a) v = *reinterpret_cast<const f32x4*>(Ls + (size_t)a * Hs + 4 * lane);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int b = lane + 64 * t;
-                    dst[r][t] = (a < idx && b < a) ? La[b] : 0.f;
-                }
+                for (int t = 0; t < 4; ++t) dst[r][t] = (4 * lane + t < a) ? v[t] : 0.f;   // beyond b < a: never written
             }
         };
         load_rows(cur, 1);                                   // row 0 has no off-diagonal part
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
 #pragma unroll
                     for (int t = 0; t < 4; ++t) part += cur[r][t] * (wv[t] * rd[t]);   // zero beyond b < a
                     const float dot = wave_sum_f(part);
-                    const int ta = a >> 6;
-                    if (lane == (a & 63)) {
+                    const int ta = a & 3;
+                    if (lane == (a >> 2)) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
                             if (t == ta) wv[t] -= dot;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         float ww = 0.f, wz = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int b = lane + 64 * t;
+            const int b = 4 * lane + t;
             wv[t] = (b < idx) ? wv[t] * rd[t] : 0.f;         // now wv = w_s
             ww += wv[t] * wv[t];
             wz += wv[t] * zs[t];
@@ -191,18 +191,19 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         const float ell = sqrtf(d2), rell = 1.f / ell;
         const float znew = ((smp - mstar) - tau - wz) * rell;
         // row idx of L_s = [w_s, ell]
-        float* Lrow = Ls + (size_t)idx * H;
+        float* Lrow = Ls + (size_t)idx * Hs;
+        f32x4 rowv;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int b = lane + 64 * t;
-            if (b < idx) Lrow[b] = wv[t];
+            const int b = 4 * lane + t;
+            rowv[t] = (b < idx) ? wv[t] : ((b == idx) ? ell : 0.f);
             if (b == idx) {
-                Lrow[b] = ell;
                 U[t] = Unew;
                 rd[t] = rell;
                 zs[t] = znew;
             }
         }
+        if (4 * lane <= idx) *reinterpret_cast<f32x4*>(Lrow + 4 * lane) = rowv;
         if (lane == 0) {
             hy[k + idx] = smp;
             he1[k + idx] = ma1;
@@ -222,7 +223,7 @@ extern "C" {
 
 size_t volt_rollout_scratch_bytes(int G, int S, int H) {
     if (G <= 0 || S <= 0 || H <= 0) return 0;
-    return (size_t)G * S * H * H * sizeof(float);
+    return (size_t)G * S * H * ((H + 3) & ~3) * sizeof(float);      // rows padded to 16 bytes
 }
 
 int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* acc0, const float* dx,
