@@ -918,7 +918,7 @@ int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
     if (!K) return -1;
     if (ldk < N) return -2;
     if (!A) return -6;
-    if (B < 0) return -7;
+    if (B < 0 || B > 65535) return -7;          // the batch rides in gridDim.y
     if (N < 1) return -8;
     if (B == 0) return 0;
     const int Np = volt_padded_n(N), n = Np / TS;

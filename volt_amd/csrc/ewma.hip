@@ -38,7 +38,7 @@ extern "C" int volt_ewma_f32(const float* y, int64_t bs_y, const float* w, int k
     if (!w) return -3;
     if (k < 1 || k > 16384) return -4;
     if (!out) return -5;
-    if (B < 0) return -6;
+    if (B < 0 || B > 65535) return -6;
     if (N < 1) return -7;
     if (B == 0) return 0;
     const size_t lds = (size_t)(2 * k + 256) * sizeof(float);

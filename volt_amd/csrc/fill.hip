@@ -94,7 +94,7 @@ template <typename T>
 static int launch_fill(const T* V, T* K, int B, int N, int64_t ldk, int64_t bsk, void* stream) {
     if (!V) return -1;
     if (!K) return -2;
-    if (B < 0) return -3;
+    if (B < 0 || B > 65535) return -3;          // the batch rides in gridDim.z
     if (N < 1) return -4;
     if (ldk < N) return -5;
     if (B == 0) return 0;

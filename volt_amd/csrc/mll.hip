@@ -207,7 +207,7 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     if (want_grad && !alpha) return -8;
     if (!info) return -9;
     if (!workspace || ((uintptr_t)workspace & 255)) return -10;
-    if (B < 0) return -11;
+    if (B < 0 || B > 65535) return -11;
     if (N < 1) return -12;
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
