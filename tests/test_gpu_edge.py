@@ -201,3 +201,12 @@ def test_rollout_engine_shapes_and_extremes(ops, S, H, k):
             ref = (ys[-1] - full[-2]) + full[-1] + np.sqrt(0.5 / 252. * float(pv[s, i]) ** 2) * z[s, i]
             assert abs(ref - out[s, i]) < 2e-4, (s, i)
             ys = np.append(ys, np.float32(out[s, i]))
+
+
+def test_long_series_cumtrapz_needs_large_lds(ops):
+    """N = 30000 fp32 = 120 KB of dynamic LDS (the per-series prefix sum stays in one workgroup)."""
+    n = 30000
+    x = (np.arange(n) / 252.0).astype(np.float32)
+    vol = np.random.RandomState(0).uniform(0.1, 0.4, (2, n)).astype(np.float32)
+    V = ops.cumtrapz(dev(vol), dev(x), square=True)
+    assert np.array_equal(V.cpu().numpy(), vo.cumtrapz(vol * vol, x))

@@ -84,6 +84,11 @@ static int launch_cumtrapz(const T* vol, int64_t bs_vol, const T* x, int64_t bs_
     if (B < 0) return -6;
     if (N < 2 || (size_t)N * sizeof(T) > 160 * 1024) return -7;   // x[1]-x[0] needs N >= 2
     if (B == 0) return 0;
+    if ((size_t)N * sizeof(T) > 48 * 1024) {      // large dynamic LDS has to be opted into
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cumtrapz_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)N * sizeof(T)));
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(cumtrapz_kernel<T>, dim3(B), dim3(256), (size_t)N * sizeof(T), (hipStream_t)stream, vol,
                        bs_vol, x, bs_x, V, N, square);
     VOLT_LAUNCH_CHECK();
