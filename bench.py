@@ -36,14 +36,21 @@ HBM_PEAK_GBS = 8000.0
 
 
 def kernel_class_flops(B: int, Np: int):
-    """Algorithmic flops of each kernel class over one factorisation (+ inverse) of B matrices."""
-    n, t3 = Np // 128, 2.0 * 128 ** 3
-    upd = sum((n - k) * k for k in range(1, n)) * t3            # P1: (n-k) tiles x K = 128 k
-    diag = n * (128 ** 3 / 3 + 128 ** 3 / 3)                     # P2: potrf + trtri of a 128 block
-    trsm = sum(n - k - 1 for k in range(n)) * t3 * 0.5           # P3: triangular W -> half the MACs count
-    row = lambda i: sum((i - j) + 0.5 for j in range(i)) * t3    # trtri row i: phase 1 + triangular phase 2
-    fused = diag + sum(row(i) for i in range(n - 1))             # P2(k) co-launched with trtri row k-1
-    return [B * upd, B * fused, B * trsm, B * row(n - 1)]
+    """ALGORITHMIC flops of each launch class over one factorisation + inverse of B matrices, counted so that the
+    Cholesky parts sum to exactly Np^3/3 and the triangular inverse to Np^3/3 (work the kernels do on structural
+    zeros -- the upper half of diagonal tiles, the zero half of triangular operands -- is NOT credited):
+      P1 tile (i,k): 2*128^3*k off the diagonal, 128^3*k on it;  P2: 128^3/3 (factor) and 128^3/3 (inverse, credited
+      to the trtri total);  P3 tile: 128^3;  trtri tile (i,j), i>j: 2*128^3*(i-j)."""
+    n, c = Np // 128, float(128 ** 3)
+    upd = sum((n - k - 1) * k * 2 * c + k * c for k in range(1, n))      # P1
+    chol_diag = n * c / 3                                                # P2, factor part
+    trsm = sum(n - k - 1 for k in range(n)) * c                          # P3
+    assert abs(upd + chol_diag + trsm - Np ** 3 / 3) < 1e-6 * Np ** 3
+    row = lambda i: sum(2 * c * (i - j) for j in range(i))               # trtri row i (off-diagonal tiles)
+    tri_diag = n * c / 3                                                 # P2, inverse part
+    assert abs(sum(row(i) for i in range(n)) + tri_diag - Np ** 3 / 3) < 1e-6 * Np ** 3
+    fused = upd + chol_diag + tri_diag + sum(row(i) for i in range(n - 1))   # factor_step_kernel, steps 0..n-1
+    return [B * fused, 0.0, B * trsm, B * row(n - 1)]
 
 
 def main():
@@ -156,7 +163,7 @@ def main():
         # last trtri row alone); class 1 is unused since the diagonal block moved into the step kernel
         names = ["factor_step_kernel", "potrf_trsm_kernel"]
         f4 = kernel_class_flops(B, Np)
-        flops = [f4[0] + f4[1] + f4[3], f4[2]]
+        flops = [f4[0] + f4[3], f4[2]]
         cnt = [cnt[0] + cnt[1] + cnt[3], cnt[2]]
         tot = np.array([tot[0] + tot[1] + tot[3], tot[2]])
         dom = int(np.argmax(tot))
