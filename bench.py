@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--n", type=int, default=N_SERIES)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux-legs", action="store_true",
+                    help="skip the ms/Cholesky and forward-only legs (used for the rocprofv3 summaries in profiles/, so "
+                         "that every factor_step_kernel<true> launch in the trace is a gradient-step launch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -159,21 +162,22 @@ def main():
                        "profile")
             tot += np.array(list(ms))
         tot /= reps
-        # classes 0 and 3 are the same kernel (factor_step_kernel: P1(k) + P2(k) + trtri row k-1 in one grid; the
-        # last trtri row alone); class 1 is unused since the diagonal block moved into the step kernel
-        names = ["factor_step_kernel", "potrf_trsm_kernel"]
+        # class 0 = factor_step_kernel<true> (n-1 launches per factorisation: look-ahead + P1(k) + P2(k) + trtri row k-1,
+        # C tiles read from K); class 1 = factor_diag0_kernel (block column 0); class 3 = the trailing trtri row alone
+        names = ["factor_step_kernel<true>", "potrf_trsm_kernel", "factor_step_kernel<false>(last trtri row)",
+                 "factor_diag0_kernel"]
         f4 = kernel_class_flops(B, Np)
-        flops = [f4[0] + f4[3], f4[2]]
-        cnt = [cnt[0] + cnt[1] + cnt[3], cnt[2]]
-        tot = np.array([tot[0] + tot[1] + tot[3], tot[2]])
+        c3 = 2.0 * 128 ** 3 / 3 * B                       # factor + inverse of one 128 block per matrix
+        flops = [f4[0] - c3, f4[2], f4[3], c3]
+        cnt = [cnt[0], cnt[2], cnt[3], cnt[1]]
+        tot = np.array([tot[0], tot[2], tot[3], tot[1]])
         dom = int(np.argmax(tot))
         ach = flops[dom] / (tot[dom] * 1e-3) / 1e12
         traffic = None
         try:      # HBM bytes per launch from the PMC passes (scripts/pmc.sh + scripts/pmc_traffic.py), same workload only
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pj["config"] == {"n": n, "batch": B}:
-                key = names[dom] + ("<true>" if names[dom] == "factor_step_kernel" else "")   # the K-reading instantiation
-                traffic = round(pj["kernels"][key]["bytes_per_launch"])
+                traffic = round(pj["kernels"][names[dom].split("(")[0]]["bytes_per_launch"])
         except Exception:
             traffic = None
         roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
@@ -187,10 +191,13 @@ def main():
                  "factor_plus_inverse_ms": round(float(tot.sum()), 3),
                  "fill_ms": round(fill_ms, 3), "fill_GBps": round(fill_gbs, 1),
                  "fill_frac_of_hbm_peak": round(fill_gbs / HBM_PEAK_GBS, 4)}
+        if args.no_aux_legs:
+            extra["ms_per_cholesky"] = None
         # ---- ms/Cholesky (the other half of BASELINE.json's metric): one batched factorisation of K + s2 I as
         # shipped (copy-in + blocked Cholesky, 4-stream schedule), and the forward-only MLL built on it
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         L_ = _lib.lib()
+        legs = () if args.no_aux_legs else ("chol", "fwd")
 
         def potrf_once():
             _lib.check(L_.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n,
@@ -203,6 +210,8 @@ def main():
                        "mll fwd")
         res = {}
         for name, fn in (("chol", potrf_once), ("fwd", fwd_once)):
+            if name not in legs:
+                continue
             fn()
             torch.cuda.synchronize()
             c0.record()
@@ -212,9 +221,10 @@ def main():
             torch.cuda.synchronize()
             res[name] = c0.elapsed_time(c1) / 3
         f = None
-        extra["ms_per_cholesky"] = round(res["chol"] / B, 4)
-        extra["cholesky_tflops"] = round(B * Np ** 3 / 3 / (res["chol"] * 1e-3) / 1e12, 2)
-        extra["ms_per_mll_forward"] = round(res["fwd"] / B, 4)
+        if legs:
+            extra["ms_per_cholesky"] = round(res["chol"] / B, 4)
+            extra["cholesky_tflops"] = round(B * Np ** 3 / 3 / (res["chol"] * 1e-3) / 1e12, 2)
+            extra["ms_per_mll_forward"] = round(res["fwd"] / B, 4)
         extra["cholesky_note"] = ("ms_per_cholesky = wall time of one batched factorisation of K + s2 I (copy-in + blocked "
                                   "Cholesky, N^3/3 flop each) / 64; ms_per_mll_forward adds the forward solve and log-det")
         del A, Winv, Y, f

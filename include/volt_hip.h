@@ -115,7 +115,8 @@ int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* 
  * K inside the panel update; with Y != NULL also the triangular inverse, co-launched with the diagonal
  * blocks) with every launch bracketed by HIP events on `stream`, synchronises, and writes to HOST
  * arrays the summed milliseconds and launch counts per kernel class:
- *   [0] factor_step_kernel (P1(k) + P2(k) + trtri row k-1 in one grid)   [1] unused   [2] potrf_trsm (P3)
+ *   [0] factor_step_kernel (look-ahead + P1(k) + P2(k) + trtri row k-1 in one grid, k >= 1)
+ *   [1] factor_diag0_kernel (the diagonal blocks of block column 0)   [2] potrf_trsm (P3)
  *   [3] factor_step_kernel carrying only the last trtri row. */
 int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A,
                             float* Winv, float* Y, int* info, int B, int N, void* stream,

@@ -736,7 +736,8 @@ struct Group {
     hipStream_t s;
 };
 
-// Timer classes: 0 = factor_step_kernel (P1 + P2 + trtri row k-1), 2 = potrf_trsm (P3),
+// Timer classes: 0 = factor_step_kernel (P1 + P2 + trtri row k-1), 1 = factor_diag0_kernel (block column 0),
+//                2 = potrf_trsm (P3),
 //                3 = factor_step_kernel carrying only a trtri row (the last row; every row of volt_trtri_f32).
 static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     const int n = Np / TS, B = g.B;
@@ -746,7 +747,7 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     // would waste n-1 idle workgroups per matrix, so the grid is cut to the diagonal tile alone)
     const int nupd = (k == 0) ? B : (n - k) * B;
     const int npre = (k >= 1 && k + 1 < n) ? B : 0;          // diagonal look-ahead workgroups (factor_step_kernel)
-    if (tm) tm->begin(0);
+    if (tm) tm->begin(k == 0 ? 1 : 0);
     if (k == 0) {
         // decode_tile_batch(w, n - 0, B) would spread t over n tiles: launch with a private tile count of 1
         hipLaunchKernelGGL(factor_diag0_kernel, dim3(B), dim3(256), 0, g.s, g.A, g.Winv, g.info, Np);
