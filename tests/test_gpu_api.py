@@ -371,3 +371,27 @@ def test_model_method_generate_prediction_twin(va):
     m.vol_model.eval()
     s = m.SamplePrediction(test_x, n_sample=2)
     assert tuple(s.shape) == (T, 2) and torch.isfinite(s).all()
+
+
+def test_full_length_training_run_tracks_oracle(va):
+    """The reference's loop for 200 Adam iterations at its default size (N=399): sigma^2 is driven from 0.69 to the
+    1e-4 floor (cond(K + s2 I) grows to ~1e7) and the device trajectory must still end where the fp64 oracle's does."""
+    from volt_amd.gp import ExactMarginalLogLikelihood
+    from volt_amd.train_utils import TrainVoltMagpieModel
+    n, k, iters = 399, 25, 200
+    F, vol = sde_series(n, 2024)
+    tx = torch.arange(n, device="cuda") / 252.
+    model, lh = TrainVoltMagpieModel(tx, dev(F)[1:], None, None, dev(vol), train_iters=iters, k=k)
+    x = (np.arange(n) / 252.).astype(np.float32)
+    K = vo.volatility_kernel(x, model.log_vol_path.exp().cpu().numpy())
+    y = np.log(F[1:])
+    mean = vo.ewma_mean(x, x, y, k)
+    losses, raw_end = _oracle_adam(K, y, mean, iters)
+    assert abs(float(lh.raw_noise) - raw_end) < 1e-4 * abs(raw_end)
+    assert float(lh.noise) < 2e-4                                   # reached the neighbourhood of the floor
+    with torch.no_grad():
+        model.train()
+        last = float(-ExactMarginalLogLikelihood(lh, model)(model(tx), dev(F)[1:].log()))
+    o = vo.mll_and_grads(K, y, mean, raw_end)
+    assert abs(last + float(o["mll"])) < 1e-4 * abs(float(o["mll"]))
+    assert losses[-1] < losses[0]
