@@ -137,16 +137,40 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
 // buffered -> one barrier per pivot), every thread reads its 8 row- and 8 column-entries with four
 // ds_read_b128 and applies the rank-1 update to the registers that are still active; which (ii,cc)
 // pairs are active is decided at compile time (the 16-pivot groups are unrolled), only the
-// group's own block row/column needs a lane mask.  Columns of L are kept in LDS (transposed,
-// lane-permuted) for the second phase, W = L^-1 by forward substitution with the same machinery.
-// LDS element order inside a 128-vector: index (i%16)*8 + i/16, i.e. a thread's 8 entries are contiguous.
-constexpr int DIAG_LDS_FLOATS = TS * TS + 2 * TS + TS;          // 67,072 B, fits the GEMM staging area
+// group's own block row/column needs a lane mask.  The finished columns are also written to a row-major
+// LDS image of L for the second phase, the inverse W = L^-1, which is blocked by 32 and runs on the
+// matrix cores (see below).  Broadcast-vector element order: index (i%16)*8 + i/16, so a thread's 8
+// entries are contiguous.
+constexpr int DT = TS + 1;                                      // row stride of the tile image: strided b32 reads conflict-free
+constexpr int DIAG_LDS_FLOATS = TS * DT + 2 * TS + TS;          // 67,584 B, fits the GEMM staging area
+
+// 32x32x32 products on fp32 MFMA for the blocked inverse below.  A (and B) are 32x32 blocks of the LDS tile image
+// (row stride DT); "reg" variants take the B operand straight from an accumulator: register q of lane (c, h) holds
+// B[p_q + 4h][c], p_q = (q&3) + 8(q>>2), which is exactly what MFMA step q wants if A supplies column p_q + 4h.
+__device__ __forceinline__ f32x16 mm32_lds_lds(f32x16 acc, const float* __restrict__ A, const float* __restrict__ B) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int kk = 2 * s2 + lh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[l31 * DT + kk], B[kk * DT + l31], acc, 0, 0, 0);
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x16 mm32_lds_reg(f32x16 acc, const float* __restrict__ A, const f32x16& Breg) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int p = (q & 3) + 8 * (q >> 2) + 4 * lh;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[l31 * DT + p], Breg[q], acc, 0, 0, 0);
+    }
+    return acc;
+}
 
 __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
                                           int Np, int k, int b, float* smem) {
-    float* sLT = smem;                                   // [j][perm(i)] = L[i][j]
-    float (*bc)[TS] = reinterpret_cast<float (*)[TS]>(smem + TS * TS);
-    float* sRinv = smem + TS * TS + 2 * TS;
+    float* sT = smem;                                    // row-major image of L (row stride DT), later of W
+    float (*bc)[TS] = reinterpret_cast<float (*)[TS]>(smem + TS * DT);
+    float* sRinv = smem + TS * DT + 2 * TS;
     const int n = Np / TS;
     float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     float* W = Winv + ((int64_t)b * n + k) * TS * TS;
@@ -203,17 +227,14 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
                 }
             }
             if (tx == jj) {                                                   // column j is final
-                f32x4 lo, hi;
 #pragma unroll
                 for (int ii = 0; ii < 8; ++ii) {
                     float v = 0.f;
                     if (ii > jb) v = li[ii];
                     else if (ii == jb) v = (ty > jj) ? li[ii] : ((ty == jj) ? piv : 0.f);
                     if (ii >= jb) a[ii][jb] = v;
-                    if (ii < 4) lo[ii] = v; else hi[ii - 4] = v;
+                    sT[(ty + 16 * ii) * DT + j] = v;                          // column j of the image (zeros above the diagonal)
                 }
-                *reinterpret_cast<f32x4*>(sLT + j * TS + ty * 8) = lo;
-                *reinterpret_cast<f32x4*>(sLT + j * TS + ty * 8 + 4) = hi;
                 if (ty == jj) sRinv[j] = rinv;
             }
         }
@@ -230,65 +251,76 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         }
     __syncthreads();
 
-    // ---- W = L^-1: rows become final top to bottom -----------------------------------------
-    float w[8][8];
+    // ---- W = L^-1, blocked by 32 on the matrix cores ------------------------------------------------------
+    // (a) wave w inverts diagonal block w: lane c solves L_ww x = e_c by forward substitution, the entries of
+    //     L_ww arrive as LDS broadcasts (32 columns in parallel, 496 FMAs deep);
+    // (b) wave j < 3 owns block column j: W[i,j] = -X_i * sum_{m=j}^{i-1} L[i,m] W[m,j], top to bottom; the W[m,j]
+    //     it produced stay in its accumulators and are fed back as B operands from registers;
+    // (c) the off-diagonal W blocks replace the L blocks in the image, and the image goes out.
+    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
+    {
+        const float* Ld = sT + (wave * 32) * DT + wave * 32;
+        const float* ri = sRinv + wave * 32;
+        float x[32];
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
+        for (int r = 0; r < 32; ++r) {
+            float acc = (r == l31) ? 1.f : 0.f;
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) w[ii][cc] = (ii == cc && ty == tx) ? 1.f : 0.f;
+            for (int m = 0; m < r; ++m) acc -= Ld[r * DT + m] * x[m];         // x[m] == 0 for m < c by construction
+            x[r] = acc * ri[r];
+        }
+        __syncthreads();                                                      // all diagonal L blocks have been read
+        {   // both half-waves hold the same x and write the same words: an `if (lane < 32)` here makes LLVM sink
+            // the whole FMA chain below the barrier into the branch and spill the 496 loaded L entries
+            float* Xd = sT + (wave * 32) * DT + wave * 32;
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-#pragma clang loop unroll(disable)
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = jb * 16 + jj;
-            float* buf = bc[j & 1];
-            if (ty == jj) {                                                   // owners of row j
-                const float rinv = sRinv[j];
-                f32x4 lo, hi;
+            for (int r = 0; r < 32; ++r) Xd[r * DT + l31] = x[r];             // X[r][c], zero above the diagonal
+        }
+    }
+    __syncthreads();
+    f32x16 Wr[3];
+    if (wave < 3) {
+        const int j = wave;
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    float v = 0.f;
-                    if (cc < jb) v = w[jb][cc] * rinv;
-                    else if (cc == jb) v = (tx <= jj) ? w[jb][cc] * rinv : 0.f;
-                    if (cc <= jb) w[jb][cc] = v;
-                    if (cc < 4) lo[cc] = v; else hi[cc - 4] = v;
-                }
-                *reinterpret_cast<f32x4*>(buf + tx * 8) = lo;
-                *reinterpret_cast<f32x4*>(buf + tx * 8 + 4) = hi;
-            }
-            __syncthreads();
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(sLT + j * TS + ty * 8);       // L[i][j], my rows
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(sLT + j * TS + ty * 8 + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(buf + tx * 8);               // W[j][c], my cols
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(buf + tx * 8 + 4);
-            float li[8], lc[8];
+        for (int di = 1; di <= 3; ++di) {
+            const int i = j + di;
+            if (i <= 3) {                                                     // wave-uniform
+                f32x16 S;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                li[q] = r0[q];
-                li[q + 4] = r1[q];
-                lc[q] = c0[q];
-                lc[q + 4] = c1[q];
-            }
+                for (int q = 0; q < 16; ++q) S[q] = 0.f;
+                S = mm32_lds_lds(S, sT + (32 * i) * DT + 32 * j, sT + (32 * j) * DT + 32 * j);       // L[i,j] X_j
 #pragma unroll
-            for (int ii = jb; ii < 8; ++ii) {
-                const bool rowact = (ii > jb) || (ty > jj);                   // i > j
+                for (int dm = 1; dm < di; ++dm)
+                    S = mm32_lds_reg(S, sT + (32 * i) * DT + 32 * (j + dm), Wr[dm - 1]);              // L[i,m] W[m,j]
+                f32x16 R;
 #pragma unroll
-                for (int cc = 0; cc <= jb; ++cc) {
-                    const bool act = rowact && ((cc < jb) || (tx <= jj));     // c <= j
-                    if (act) w[ii][cc] -= li[ii] * lc[cc];
-                }
+                for (int q = 0; q < 16; ++q) R[q] = 0.f;
+                R = mm32_lds_reg(R, sT + (32 * i) * DT + 32 * i, S);                                  // X_i S
+#pragma unroll
+                for (int q = 0; q < 16; ++q) Wr[di - 1][q] = -R[q];
             }
         }
     }
+    __syncthreads();                                                          // every L block has been consumed
+    if (wave < 3) {
+        const int j = wave;
 #pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
+        for (int di = 1; di <= 3; ++di) {
+            const int i = j + di;
+            if (i <= 3) {
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            float v = 0.f;
-            if (ii > cc) v = w[ii][cc];
-            else if (ii == cc) v = (ty >= tx) ? w[ii][cc] : 0.f;
-            W[(ty + 16 * ii) * TS + tx + 16 * cc] = v;
+                for (int q = 0; q < 16; ++q) sT[(32 * i + accrow(q, lane)) * DT + 32 * j + l31] = Wr[di - 1][q];
+            }
         }
+    }
+    __syncthreads();
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        f32x4 w4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w4[q] = (c + q <= r) ? sT[r * DT + c + q] : 0.f;
+        *reinterpret_cast<f32x4*>(W + r * TS + c) = w4;
+    }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
 }
 
