@@ -141,6 +141,34 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
                       int* info, void* workspace, int B, int N, int want_grad, void* stream);
 
+/* ---- f4: GPCV volatility extraction (LearnGPCV, voltron/train_utils.py:15-67) --------------------
+ * Structured batched GEMM on the fp32 MFMA core, C = alpha A B^T + beta C, row-major, K contiguous in
+ * both operands.  uplo_* : 0 dense, 1 lower, 2 upper, at 128-tile granularity: for A (B) it restricts the
+ * k-blocks read for a row-block, for C it selects the tiles written.  M, N, K multiples of 128;
+ * lda/ldb multiples of 4, A and B 16-byte aligned. */
+int volt_gemm_nt_f32(const float* A, int64_t lda, int64_t bsa, int uplo_a, const float* B, int64_t ldb,
+                     int64_t bsb, int uplo_b, float* C, int64_t ldc, int64_t bsc, int uplo_c, float alpha,
+                     float beta, int batch, int M, int N, int K, void* stream);
+
+/* One ELBO + gradient evaluation of the variational GP whose inducing points are its inputs
+ * (single_task_variational_gp.py:69-122 with use_whitened_var_strat=False; likelihood
+ * volatility_likelihood.py:42-50, "exp" parameterisation; VariationalELBO call train_utils.py:44,51-54):
+ *     q(u) = N(m, Lq Lq'),  prior N(mu, K + jitter I),
+ *     ell = sum_i sum_k w_k log N(y_i; 0, max(exp(m_i + sqrt(2 var_i) x_k), min_scale)),  var_i = max(sum_j Lq_ij^2, min_var)
+ *     KL  = 1/2 (tr(K^-1 S) + r'K^-1 r - N + logdet K - logdet S),   r = m - mu  (passed in as `resid`)
+ * K [B,N,N] (ldk, bsk) without jitter; m, resid, y [B,N]; Lq [B,N,N] contiguous (upper triangle ignored);
+ * gh_x, gh_w [Q] Gauss-Hermite nodes and weights / sqrt(pi).
+ *     F   = w_ell ell - w_kl KL      (VariationalELBO: w_ell = 1/N, w_kl = beta/num_data)
+ *     out[b,0..11] = ell, KL, r'K^-1 r, logdet K, logdet S, tr(K^-1 S), tr K^-1, |K^-1 Lq|_F^2, |K^-1 r|^2,
+ *                    F, jitter, 0
+ *     grad_m, grad_mu [B,N], grad_Lq [B,N,N]: gradients of F;  grad_K [B,N,N] (nullable) = dF/dK.
+ * info[b] LAPACK-style for the factorisation of K + jitter I.  workspace: volt_gpcv_workspace_bytes. */
+size_t volt_gpcv_workspace_bytes(int B, int N, int want_dk);
+int volt_gpcv_step_f32(const float* K, int64_t ldk, int64_t bsk, float jitter, const float* resid, const float* m,
+                       const float* Lq, const float* y, const float* gh_x, const float* gh_w, int Q, float min_var,
+                       float min_scale, float w_ell, float w_kl, float* out, float* grad_m, float* grad_mu,
+                       float* grad_Lq, float* grad_K, int* info, void* workspace, int B, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,3 +119,16 @@ def test_install_as_voltron_alias():
         for k in [k for k in sys.modules if k == "voltron" or k.startswith("voltron.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_gpcv_stage_refuses_cpu_tensors_and_validates_arguments():
+    """LearnGPCV has no CPU path either; its C entry validates before touching the device."""
+    from volt_amd import _lib
+    from volt_amd.train_utils import LearnGPCV
+    L = _lib.lib()
+    assert L.volt_gpcv_workspace_bytes(2, 300, 1) > L.volt_gpcv_workspace_bytes(2, 300, 0) > L.volt_mll_workspace_bytes(2, 300, 1)
+    assert L.volt_gpcv_step_f32(None, 8, 64, 1e-3, *([None] * 6), 75, 1e-6, 1e-3, 1.0, 1.0, *([None] * 7), 1, 8, None) == -1
+    assert L.volt_gemm_nt_f32(256, 128, 0, 0, 256, 128, 0, 0, 256, 128, 0, 0, 1.0, 0.0, 1, 100, 128, 128, None) == -16
+    x = torch.arange(50, dtype=torch.float32) / 252
+    with pytest.raises(_lib.VoltHipError):
+        LearnGPCV(x, torch.rand(51) + 1.0, train_iters=1)

@@ -1,0 +1,122 @@
+"""The GPCV oracle (oracle/gpcv_oracle.py) against an independent dense evaluation.
+
+Parity with the reference is UNPINNED for this stage (the ELBO arithmetic is gpytorch's, absent here); what can be
+checked on the CPU is that the restated closed forms equal the textbook definitions computed another way:
+``torch.distributions`` for the MVN-MVN KL and the Normal log-density, brute-force quadrature on a fine grid for the
+Gauss-Hermite expectation, and the reference's own start-up formula evaluated with explicit inverses."""
+import math
+
+import numpy as np
+import torch
+from torch.distributions import MultivariateNormal, Normal, kl_divergence
+
+from oracle import gpcv_oracle as GO
+from volt_amd.synthetic import sde_series
+
+
+def _setup(n=60, seed=2019):
+    F, _ = sde_series(n, seed)
+    x = torch.arange(n, dtype=torch.float64) / 252
+    yy = GO.scaled_returns(x, torch.tensor(F, dtype=torch.float64))
+    f, S_root, c0 = GO.init_variational(x, yy)
+    g = torch.Generator().manual_seed(seed)
+    m = f + 0.1 * torch.randn(n, generator=g, dtype=torch.float64)
+    Lq = (S_root / 10 + 0.01 * torch.randn(n, n, generator=g, dtype=torch.float64)).tril()
+    return x, yy, m, Lq, c0
+
+
+def test_scaled_returns_definition():
+    x = torch.tensor([0.0, 0.5, 1.0])
+    p = torch.tensor([10.0, 11.0, 9.9])
+    r = GO.scaled_returns(x, p)
+    assert torch.allclose(r, torch.tensor([0.1, -0.1]) / math.sqrt(0.5), atol=1e-6)
+
+
+def test_kl_term_equals_torch_distributions():
+    x, yy, m, Lq, c0 = _setup()
+    n = x.shape[0]
+    K = GO.bm_cov(x, torch.tensor(0.2, dtype=torch.float64))
+    gh_x, gh_w = GO.gauss_hermite(75)
+    t = GO.elbo_terms(m, Lq, c0, K, yy, gh_x, gh_w)
+    q = MultivariateNormal(m, covariance_matrix=Lq @ Lq.mT)      # Lq's diagonal may be negative: S = Lq Lq' all the same
+    p = MultivariateNormal(c0.expand(n), covariance_matrix=K + GO.PRIOR_JITTER * torch.eye(n, dtype=torch.float64))
+    assert abs(float(t["kl"]) - float(kl_divergence(q, p))) < 1e-8 * abs(float(t["kl"]))
+
+
+def test_expected_log_prob_equals_brute_force_quadrature():
+    x, yy, m, Lq, c0 = _setup(n=20)
+    K = GO.bm_cov(x, torch.tensor(0.2, dtype=torch.float64))
+    gh_x, gh_w = GO.gauss_hermite(75)
+    t = GO.elbo_terms(m, Lq, c0, K, yy, gh_x, gh_w)
+    var = Lq.pow(2).sum(-1)
+    # E_{f ~ N(m_i, var_i)} log N(y_i; 0, max(exp f, 1e-3)) on a fine trapezoid grid, +-12 sd
+    u = torch.linspace(-12, 12, 200001, dtype=torch.float64)
+    tot = 0.0
+    for i in range(x.shape[0]):
+        fgrid = m[i] + var[i].sqrt() * u
+        logp = Normal(0.0, fgrid.exp().clamp(min=GO.MIN_SCALE)).log_prob(yy[i])
+        w = torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi)
+        tot += float(torch.trapezoid(logp * w, u))
+    assert abs(float(t["ell"]) - tot) < 1e-6 * abs(tot)
+
+
+def test_init_variational_follows_the_reference_formula():
+    """single_task_variational_gp.py:201-236 with explicit dense algebra (inverse instead of Cholesky solves)."""
+    n = 40
+    F, _ = sde_series(n, 2020)
+    x = torch.arange(n, dtype=torch.float64) / 252
+    y = GO.scaled_returns(x, torch.tensor(F, dtype=torch.float64))
+    f, S_root, c0 = GO.init_variational(x, y)
+    rs = torch.stack([y[:i].std(0) for i in range(n)])
+    rs[:10] = rs[10]
+    assert torch.allclose(f, rs.clamp(min=1e-4).log(), atol=1e-12)
+    assert abs(float(c0) - float(rs.mean(0).log())) < 1e-12
+    ih = torch.diag_embed((0.5 * y.pow(-2.0) * (f * 2.0).exp()).T).clamp(min=1e-4, max=1000.)
+    assert float(ih[0, 1]) == 1e-4                                   # the clamp reaches the off-diagonal zeros
+    L = GO.psd_safe_cholesky(GO.bm_cov(x, torch.tensor(0.2, dtype=torch.float64)))
+    S = L @ torch.linalg.inv(L.mT @ ih @ L + torch.eye(n, dtype=torch.float64)) @ L.mT
+    got = (S_root / 10) @ (S_root / 10).mT
+    assert float((got - S).abs().max() / S.abs().max()) < 1e-6
+
+
+def test_elbo_gradients_match_closed_forms():
+    """The closed forms the HIP step implements (gpcv.hip header) against autograd of the oracle."""
+    x, yy, m, Lq, c0 = _setup(n=50)
+    n = x.shape[0]
+    raw_vol = torch.logit(torch.tensor([0.2], dtype=torch.float64))
+    val, (gm, gL, gc, gv) = GO.elbo_and_grads(m, Lq, c0.reshape(1), raw_vol, x, yy)
+    vol = torch.sigmoid(raw_vol)
+    K = GO.bm_cov(x, vol) + GO.PRIOR_JITTER * torch.eye(n, dtype=torch.float64)
+    Kinv = torch.linalg.inv(K)
+    G = Kinv @ Lq
+    beta = Kinv @ (m - c0)
+    # KL part of dF/dLq is -(tril(G) - diag(1/Lq_ii)); the rest is the likelihood's 2 gv_i Lq_ij
+    gh_x, gh_w = GO.gauss_hermite(75)
+    var = Lq.pow(2).sum(-1)
+    fk = m.unsqueeze(0) + torch.sqrt(2 * var).unsqueeze(0) * gh_x.unsqueeze(-1)
+    s = fk.exp()
+    g = (yy.unsqueeze(0) ** 2 / s ** 2 - 1.0) * (s > GO.MIN_SCALE)
+    w = (gh_w / math.sqrt(math.pi)).unsqueeze(-1)
+    dm = (w * g).sum(0)
+    dvar = (w * g * gh_x.unsqueeze(-1)).sum(0) / torch.sqrt(2 * var)
+    want_L = (2 * dvar.unsqueeze(-1) * Lq - (G - torch.diag(1.0 / Lq.diagonal()))).tril() / n
+    assert float((gL - want_L).abs().max()) < 1e-9 * max(1.0, float(want_L.abs().max()))
+    assert float((gm - (dm - beta) / n).abs().max()) < 1e-9 * max(1.0, float(gm.abs().max()))
+    assert abs(float(gc) - float(beta.sum() / n)) < 1e-9 * max(1.0, abs(float(gc)))
+    # d/dvol through K = vol M + j I:  tr(K^-1 M) etc. from quantities the step already has
+    j = GO.PRIOR_JITTER
+    tr_inv, tr_s, gg = torch.trace(Kinv), (Lq.mT @ Kinv @ Lq).trace(), G.pow(2).sum()
+    quad, bb = (m - c0) @ beta, beta @ beta
+    dkl = 0.5 * ((n - j * tr_inv) - (tr_s - j * gg) - (quad - j * bb)) / vol
+    want_v = -dkl / n * vol * (1 - vol)                                  # chain through the sigmoid
+    assert abs(float(gv) - float(want_v)) < 1e-8 * max(1.0, abs(float(want_v)))
+
+
+def test_learn_gpcv_recovers_the_volatility_path_shape():
+    n = 120
+    F, V = sde_series(n, 2019)
+    x = torch.arange(n, dtype=torch.float32) / 252
+    rec = []
+    vol, _ = GO.learn_gpcv(x, torch.tensor(F), train_iters=60, eps=torch.zeros(1, n), record=rec)
+    assert rec[-1] < rec[0] and np.isfinite(rec).all()
+    assert vol.shape == (n,) and bool((vol > 0).all())

@@ -15,15 +15,16 @@ __version__ = "0.1"
 from .kernels import BMKernel, VolatilityKernel            # noqa: F401
 from .models import BMGP, VoltronGP, VoltMagpie            # noqa: F401
 from .rollout_utils import Rollouts, GeneratePrediction    # noqa: F401
+from .train_utils import LearnGPCV                        # noqa: F401
 
 
 def install_as_voltron():
     """Register this package (and its hot-path submodules) under the name ``voltron``."""
     import sys
-    from . import kernels, means, models, rollout_utils, train_utils
+    from . import kernels, likelihoods, means, models, rollout_utils, train_utils
     me = sys.modules[__name__]
     sys.modules.setdefault("voltron", me)
-    for name, mod in (("kernels", kernels), ("means", means), ("models", models),
+    for name, mod in (("kernels", kernels), ("likelihoods", likelihoods), ("means", means), ("models", models),
                       ("rollout_utils", rollout_utils), ("train_utils", train_utils)):
         sys.modules.setdefault("voltron." + name, mod)
     return me

@@ -33,6 +33,11 @@ _SIGS = {
     "volt_tune_update_f32": (C.c_int, [_ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "volt_mll_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "volt_mll_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
+    "volt_gemm_nt_f32": (C.c_int, [_ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _i32, _f32, _f32,
+                                   _i32, _i32, _i32, _i32, _ptr]),
+    "volt_gpcv_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "volt_gpcv_step_f32": (C.c_int, [_ptr, _i64, _i64, _f32] + [_ptr] * 6 + [_i32, _f32, _f32, _f32, _f32] + [_ptr] * 7
+                           + [_i32, _i32, _ptr]),
 }
 
 EXPORTS = tuple(_SIGS)

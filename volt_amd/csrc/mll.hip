@@ -190,6 +190,9 @@ void mll_tail(void* vctx, int b0, int Bg, hipStream_t s) {
 }
 }  // namespace
 
+// gpcv.hip continues from the factor and Y = L^-T this step leaves in its workspace
+const float* volt_internal_mll_y(void* workspace, int B, int N) { return carve(workspace, B, N, 1).Y; }
+
 extern "C" {
 
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {

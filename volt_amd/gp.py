@@ -83,22 +83,26 @@ class _ScaledDense(_Evaluated):
     def __init__(self, scale, base):
         self.scale, self.base = scale, base
 
+    def _product(self, scale):
+        # a batched kernel carries scale [T,1] over one shared base [N,N]
+        return (scale.unsqueeze(-1) if scale.ndim > 1 else scale) * self.base
+
     @property
     def tensor(self):
-        return self.scale * self.base
+        return self._product(self.scale)
 
     @tensor.setter
     def tensor(self, v):
         raise AttributeError("read-only")
 
     def evaluate(self):
-        return self.scale * self.base
+        return self._product(self.scale)
 
     def to_dense(self):
         return self.evaluate()
 
     def detach(self):
-        return (self.scale * self.base).detach()
+        return self._product(self.scale.detach())
 
     @property
     def shape(self):
@@ -124,6 +128,8 @@ class ConstantMean(Mean):
     def forward(self, x):
         if x.shape[:-2] == self.batch_shape:
             return self.constant.expand(x.shape[:-1])
+        if len(self.batch_shape) and x.ndim == 2:              # batched constant over shared inputs [N,1]
+            return self.constant.expand(*self.batch_shape, x.shape[-2])
         return self.constant.expand(*x.shape[:-1]) if x.ndim > 1 else self.constant.expand(x.shape)
 
 

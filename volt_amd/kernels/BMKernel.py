@@ -49,9 +49,9 @@ class BMKernel(Kernel):
 
     def __call__(self, x1, x2=None, **kwargs):
         """Lazy form: keeps K = vol * min(x1, x2) factored so an exact MLL can differentiate wrt vol."""
-        if kwargs.get("diag", False) or self.batch_shape != torch.Size():
-            return super().__call__(x1, x2, **kwargs)
         x2 = x1 if x2 is None else x2
+        if kwargs.get("diag", False) or (self.batch_shape != torch.Size() and (x1.ndim > 2 or x2.ndim > 2)):
+            return super().__call__(x1, x2, **kwargs)
         a = x1[:, 0] if x1.ndim > 1 else x1
         b = x2[:, 0] if x2.ndim > 1 else x2
         return _ScaledDense(self.vol, torch.minimum(a.unsqueeze(-1), b.unsqueeze(-2)))

@@ -177,3 +177,73 @@ def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: Mll
                                             float(jitter), ws.out.data_ptr(), ws.alpha.data_ptr(), ws.info.data_ptr(),
                                             ws.ptr, B, n, int(want_grad), _lib.stream_ptr()), "volt_mll_step")
     return ws.out, ws.alpha, ws.info
+
+
+# ------------------------------------------------------------------ GPCV stage
+def gemm_nt(A: torch.Tensor, B: torch.Tensor, uplo_a: int = 0, uplo_b: int = 0) -> torch.Tensor:
+    """A @ B.mT on the library's fp32 MFMA GEMM.  A [T,M,K], B [T,N,K] (or 2-D); uplo_* = 1 / 2 declare an
+    operand lower / upper triangular so its zero 128-blocks are skipped.  Operands are zero-padded to the
+    128 tile here (plumbing); the arithmetic is volt_gemm_nt_f32."""
+    _need_gpu(A, B)
+    two_d = A.ndim == 2
+    A3 = (A.unsqueeze(0) if two_d else A).to(torch.float32)
+    B3 = (B.unsqueeze(0) if B.ndim == 2 else B).to(torch.float32)
+    T, M, K = A3.shape
+    N = B3.shape[1]
+    if B3.shape[0] != T or B3.shape[2] != K:
+        raise ValueError("gemm_nt: A [T,M,K] and B [T,N,K] disagree")
+    Mp, Np_, Kp = padded_n(M), padded_n(N), padded_n(K)
+    Ap = torch.zeros(T, Mp, Kp, dtype=torch.float32, device=A.device)
+    Bp = torch.zeros(T, Np_, Kp, dtype=torch.float32, device=A.device)
+    Ap[:, :M, :K] = A3
+    Bp[:, :N, :K] = B3
+    Cp = torch.empty(T, Mp, Np_, dtype=torch.float32, device=A.device)
+    _lib.check(_lib.lib().volt_gemm_nt_f32(Ap.data_ptr(), Kp, Mp * Kp, uplo_a, Bp.data_ptr(), Kp, Np_ * Kp, uplo_b,
+                                           Cp.data_ptr(), Np_, Mp * Np_, 0, 1.0, 0.0, T, Mp, Np_, Kp,
+                                           _lib.stream_ptr()), "volt_gemm_nt")
+    C = Cp[:, :M, :N]
+    return C[0] if two_d else C
+
+
+class GpcvWorkspace:
+    """Caller-owned scratch and outputs of volt_gpcv_step_f32, reusable across steps of the same (B,N)."""
+
+    def __init__(self, B: int, N: int, want_dk: bool, device):
+        self.B, self.N, self.want_dk = B, N, bool(want_dk)
+        nbytes = _lib.lib().volt_gpcv_workspace_bytes(B, N, int(want_dk))
+        self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        self.ptr = (self.buf.data_ptr() + 255) // 256 * 256
+        f32 = dict(dtype=torch.float32, device=device)
+        self.out = torch.empty(B, 12, **f32)
+        self.grad_m = torch.empty(B, N, **f32)
+        self.grad_mu = torch.empty(B, N, **f32)
+        self.grad_Lq = torch.empty(B, N, N, **f32)
+        self.grad_K = torch.empty(B, N, N, **f32) if want_dk else None
+        self.info = torch.empty(B, dtype=torch.int32, device=device)
+
+
+def gpcv_step(K, resid, m, Lq, y, gh_x, gh_w, ws: GpcvWorkspace | None = None, want_dk: bool = False,
+              jitter: float = 1e-3, min_var: float = 1e-6, min_scale: float = 1e-3, w_ell: float = 1.0,
+              w_kl: float = 1.0):
+    """One ELBO + gradient evaluation of the GPCV variational GP (include/volt_hip.h, volt_gpcv_step_f32).
+    K [B,N,N] prior covariance without jitter; resid = m - prior mean, m, y [B,N]; Lq [B,N,N].
+    Gradients are those of F = w_ell * ell - w_kl * KL (out[:, 9]).
+    Returns the workspace: .out [B,12], .grad_m, .grad_mu, .grad_Lq (.grad_K if want_dk), .info."""
+    _need_gpu(K, resid, m, Lq, y, gh_x, gh_w)
+    if K.ndim != 3 or K.dtype != torch.float32:
+        raise ValueError("K must be [B,N,N] fp32")
+    B, n, _ = K.shape
+    if K.stride(-1) != 1:
+        K = K.contiguous()
+    c = lambda t, shape: t.reshape(shape).to(torch.float32).contiguous()
+    resid, m, y, Lq = c(resid, (B, n)), c(m, (B, n)), c(y, (B, n)), c(Lq, (B, n, n))
+    gh_x, gh_w = gh_x.to(torch.float32).contiguous(), gh_w.to(torch.float32).contiguous()
+    if ws is None or ws.B != B or ws.N != n or ws.want_dk != bool(want_dk):
+        ws = GpcvWorkspace(B, n, want_dk, K.device)
+    _lib.check(_lib.lib().volt_gpcv_step_f32(
+        K.data_ptr(), K.stride(1), K.stride(0), float(jitter), resid.data_ptr(), m.data_ptr(), Lq.data_ptr(),
+        y.data_ptr(), gh_x.data_ptr(), gh_w.data_ptr(), gh_x.numel(), float(min_var), float(min_scale), float(w_ell), float(w_kl),
+        ws.out.data_ptr(), ws.grad_m.data_ptr(), ws.grad_mu.data_ptr(), ws.grad_Lq.data_ptr(),
+        ws.grad_K.data_ptr() if want_dk else None, ws.info.data_ptr(), ws.ptr, B, n, _lib.stream_ptr()),
+        "volt_gpcv_step")
+    return ws

@@ -4,8 +4,8 @@ voltron/train_utils.py (TrainDataModel :98-144, TrainVoltMagpieModel :192-257).
 The loop bodies are the reference's, statement for statement: ``optimizer.zero_grad(); output =
 voltron(train_x); loss = -mll(output, y); loss.backward(); optimizer.step()``.  What changes is
 what runs underneath: ``mll`` is volt_amd.gp.ExactMarginalLogLikelihood, one fused HIP step with
-an analytic backward.  LearnGPCV / TrainVolModel / TrainBasicModel (variational ELBO, BM-kernel
-GP, Matern/SM baselines) are outside the accelerated path.
+an analytic backward.  LearnGPCV (:15-67, the variational GPCV stage) and TrainVolModel (:69-95) are here
+too, on the same library; TrainBasicModel (Matern/SM baselines) is outside the accelerated path.
 
 ``TrainVoltMagpieBatch`` is an addition for the multi-series case the reference only loops over
 in Python (experiments/stocks/ForecastGenerator.py:27-41): B independent series in one batched
@@ -17,6 +17,71 @@ from . import gp
 from .gp import ExactMarginalLogLikelihood, GaussianLikelihood
 from .means import LogLinearMean, EWMAMean, DEWMAMean, TEWMAMean, MeanRevertingEMAMean
 from .models import VoltronGP, VoltMagpie
+
+
+def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm"):
+    """The fit of LearnGPCV (train_utils.py:15-58) returning what it builds: (model, likelihood, losses)."""
+    from .kernels import BMKernel, FBMKernel
+    from .likelihoods import VolatilityGaussianLikelihood
+    from .models import SingleTaskVariationalGP
+    from .variational import VariationalELBO, num_gauss_hermite_locs
+    dt = train_x[1] - train_x[0]
+    scaled_returns = (train_y[..., 1:] - train_y[..., :-1]) / (train_y[..., :-1]) / (dt ** 0.5)
+    yy = scaled_returns
+    batch_shape = yy.shape[:-1]
+
+    likelihood = VolatilityGaussianLikelihood(param="exp")
+    kw = {"batch_shape": batch_shape} if len(batch_shape) else {}
+    if kernel == "bm":
+        covar_module = BMKernel(**kw)
+    elif kernel == "fbm":
+        covar_module = FBMKernel(**kw)
+    model = SingleTaskVariationalGP(
+        init_points=train_x.view(-1, 1), likelihood=likelihood, use_piv_chol_init=False,
+        mean_module=gp.ConstantMean(**kw), covar_module=covar_module,
+        learn_inducing_locations=False, use_whitened_var_strat=False
+    )
+    model.initialize_variational_parameters(likelihood, train_x, y=yy)
+
+    model.train()
+    likelihood.train()
+
+    optimizer = torch.optim.Adam([
+        {"params": model.parameters()},
+    ], lr=0.01)
+
+    mll = VariationalELBO(likelihood, model, yy.shape[-1], combine_terms=True)
+
+    print_every = 50
+    losses = []
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        with num_gauss_hermite_locs(75):
+            output = model(train_x)
+            loss = -mll(output, yy)
+            losses.append(loss.detach())
+            if loss.ndim:
+                loss = loss.sum()                      # independent series: one backward for all of them
+            loss.backward()
+            if printing:
+                if i % print_every == 0:
+                    print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
+            optimizer.step()
+    model.eval()
+    likelihood.eval()
+    return model, likelihood, losses
+
+
+def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping=False, kernel="bm"):
+    """voltron/train_utils.py:15-67 -- SURVEY 8(f) row 4: extract the volatility path from prices by fitting a
+    variational GP (BM or FBM prior over log-vol, ``y | f ~ N(0, exp f)``) to the scaled returns.  Same statements
+    as the reference; ``mll`` is volt_amd.variational.VariationalELBO, one HIP step per iteration.
+    train_y [N+1] prices -> pred_scale [N]; train_y [T,N+1] fits T series at once (batched parameters)."""
+    model, likelihood, _ = FitGPCV(train_x, train_y, train_iters=train_iters, printing=printing, kernel=kernel)
+    predictive = model(train_x)
+    pred_scale = likelihood(predictive, return_gaussian=False).scale.mean(0).detach()
+
+    return pred_scale
 
 
 def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm"):
