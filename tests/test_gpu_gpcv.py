@@ -174,3 +174,27 @@ def test_learn_gpcv_batched_equals_single():
             finally:
                 torch.randn = orig
             assert float((vi - vb[i]).abs().max() / vb[i].abs().max()) < 2e-3
+
+
+def test_reference_pipeline_end_to_end():
+    """The stock driver's body (experiments/stocks/GenerateMultiMeanPreds.py:95-107), statement for statement:
+    LearnGPCV -> TrainVolModel -> TrainVoltMagpieModel -> Rollouts, every stage on the HIP path."""
+    import warnings
+    from volt_amd.train_utils import LearnGPCV, TrainVolModel, TrainVoltMagpieModel
+    from volt_amd.rollout_utils import Rollouts
+    n, H, S = 150, 6, 16
+    F, _ = _prices(n, 2030)
+    train_y = F.cuda()
+    train_x = (torch.arange(train_y.shape[0] - 1) / 252.).cuda()
+    test_x = (torch.arange(H) / 252.).cuda() + train_x[-1] + train_x[1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vol = LearnGPCV(train_x, train_y, train_iters=30, printing=False)
+        assert vol.shape == (n,) and bool((vol > 0).all())
+        vmod, vlh = TrainVolModel(train_x, vol, train_iters=10, printing=False)
+        voltron, lh = TrainVoltMagpieModel(train_x, train_y[1:], vmod, vlh, vol, printing=False, train_iters=10, k=20,
+                                           mean_func="ewma")
+        vmod.eval()
+        samples = Rollouts(train_x, train_y, test_x, voltron, nsample=S)
+    assert tuple(samples.shape) == (S, H) and bool(torch.isfinite(samples).all())
+    assert float((samples[:, 0].mean() - train_y[-1].log().cpu()).abs()) < 0.5

@@ -2,14 +2,15 @@
 experiments/stocks/GenerateMultiMeanPreds.py:63-137, with the reference's per-ticker Python ``for``
 (ForecastGenerator.py:27-41) replaced by one batched pass per window:
 
-    window -> [vol paths] -> TrainVoltMagpieBatch (all tickers in one batched model, HIP MLL step)
+    window -> LearnGPCV for all tickers at once (batched variational fit, HIP ELBO step)          (:95-96)
+           -> TrainVoltMagpieBatch (all tickers in one batched model, HIP MLL step)               (:99-103)
            -> TrainVolModel + posterior sample of the vol forecaster per ticker (BM-GP, HIP factorisation)
-           -> rollout engine for all tickers x paths in one launch
-           -> torch.save(samples[S,H], "saved-outputs/<ticker>/<model>_<date>.pt")      (:128)
+           -> rollout engine for all tickers x paths in one launch                                (:105-107)
+           -> torch.save(samples[S,H], "saved-outputs/<ticker>/<model>_<date>.pt")                (:128)
 
-The GPCV volatility extraction (LearnGPCV, train_utils.py:15-67: variational, out of scope) is a
-caller-supplied hook ``vol_fn(train_x, prices) -> vol [B, N]``; ``realised_vol`` below is a simple
-stand-in so the driver runs end to end on synthetic data -- it is NOT the reference's GPCV.
+``vol_fn(train_x, prices [B,N+1]) -> vol [B,N]`` is the volatility-extraction stage: by default the reference's
+LearnGPCV (train_utils.py:15-67) fitted for all tickers in one batch; ``realised_vol`` is a cheap non-reference
+estimator kept for quick smoke runs.
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import torch
 from . import rollout_engine
 from .distributed import shard_range
 from .means import EWMAMean, DEWMAMean, TEWMAMean
-from .train_utils import TrainVoltMagpieBatch, TrainVolModel
+from .train_utils import LearnGPCV, TrainVoltMagpieBatch, TrainVolModel
 
 _MODES = {"ewma": 0, "dewma": 1, "tewma": 2}
 
@@ -36,7 +37,7 @@ def realised_vol(train_x, prices, span=20, floor=1e-3):
 
 
 def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=20, train_iters=400, nsample=1000,
-                                  ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=realised_vol,
+                                  ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=None,
                                   vol_iters=None, par_dir="./saved-outputs/", generator=None):
     """closes [B, T] prices for B tickers on a common calendar (device tensor).  Same window schedule,
     model name and file layout as GenerateStockPredictions (GenerateMultiMeanPreds.py:69-83,128).
@@ -61,7 +62,10 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
         train_y = closes[:, last_day - ntrain:last_day].float()                       # [B, ntrain] prices
         train_x = torch.arange(ntrain - 1, device=dev) * dt                             # :89
         test_x = torch.arange(forecast_horizon, device=dev) * dt + train_x[-1] + train_x[1]     # :90
-        vol = vol_fn(train_x, train_y)                                                  # [B, ntrain-1]
+        if vol_fn is None:
+            vol = LearnGPCV(train_x, train_y, train_iters=train_iters)                  # :95-96, all tickers at once
+        else:
+            vol = vol_fn(train_x, train_y)                                              # [B, ntrain-1]
         # data model: all tickers in one batched VoltMagpie (per-ticker noise), :104-108
         model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=train_iters, k=k)
         if mean != "ewma":
