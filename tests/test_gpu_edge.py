@@ -118,7 +118,13 @@ def test_volt_class_train_and_forecast(ops):
     F, vol = sde_series(n, 5)
     tx = torch.arange(n + 1, device="cuda") / 252.
     m = Volt(tx, dev(F).log(), mean="ewma", vol_path=dev(vol), k=10)
-    m.Train(data_mod_iters=4)
+    m.Train(data_mod_iters=4, vol=dev(vol))                               # data-model stage only
+    assert torch.isfinite(m.likelihood.raw_noise).all()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.Train(gpcv_iters=5, vol_mod_iters=5, data_mod_iters=4)          # Volt.py:95-146: GPCV -> vol model -> data model
+    assert m.log_vol_path.shape == (n,) and torch.isfinite(m.log_vol_path).all()
     assert torch.isfinite(m.likelihood.raw_noise).all()
     test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + 1 / 252.
     pv, z = rollout_inputs(vol[-1], S, H, seed=1)

@@ -1,10 +1,11 @@
 """Volt -- drop-in for voltron/models/Volt.py (all-in-one Train / Forecast class; the reference does
 not export it from models/__init__.py either).
 
+``Train`` runs the reference's three stages (Volt.py:95-146) on the HIP path: LearnGPCV (variational
+volatility extraction), TrainVolModel (BM-GP over log-vol) and the exact-GP data model; ``Train(vol=...)``
+skips the first two when a volatility path is supplied.
+
 Deliberate deviations, each a reference defect (SURVEY 7 hard part 5):
-* ``Train`` needs the GPCV volatility extraction (LearnGPCV, variational -- SURVEY 8(f) row 4, out
-  of scope) unless a ``vol_path`` is supplied; ``Train(vol=...)`` / ``TrainDataModel`` cover the
-  exact-GP stage, which is what this package accelerates.
 * ``Forecast`` in the reference passes ``return_vol`` / ``latent_mean`` keywords that ``Rollouts``
   does not accept (Volt.py:155-160 vs rollout_utils.py:57) and would raise TypeError; here it calls
   ``Rollouts`` with the arguments it does accept (``theta`` only when mean_revert is set).
@@ -50,6 +51,7 @@ class Volt(ExactGP):
         else:
             self.train_x = train_x[1:]
         self.train_y = log_data[..., 1:]
+        self._full_x, self._full_log_data = train_x, log_data            # Train's GPCV stage starts from the prices
 
         if vol_path is None:
             self.log_vol_path = -1 * torch.ones(train_x.shape[0] - 1, device=train_x.device)
@@ -86,11 +88,17 @@ class Volt(ExactGP):
 
     def Train(self, gpcv_iters=400, vol_mod_iters=1000, data_mod_iters=400, display=False, vol=None,
               vol_model=None, vol_lh=None):
-        """Volt.py:95-146.  The GPCV + vol-model stage (:103-104) is out of scope: pass ``vol`` (and
-        optionally a trained ``vol_model``/``vol_lh``); the data-model stage (:108-146) is mirrored."""
+        """Volt.py:95-146: GPCV + vol model (:103-104), then the data model (:108-146).  ``vol`` (and optionally a
+        trained ``vol_model``/``vol_lh``) skips the first stage."""
+        from ..train_utils import LearnGPCV, TrainVolModel
         x = self.train_x.squeeze()
-        if vol is not None:
-            self.UpdateVolPath(vol)
+        if vol is None:
+            if self._full_log_data.ndim > 1:
+                raise NotImplementedError("batched Volt.Train: fit the vol path with LearnGPCV(train_x, prices [T,N+1]) "
+                                          "and pass it as vol= (the reference's MultitaskBMGP stage is out of scope)")
+            vol = LearnGPCV(self._full_x[1:], self._full_log_data.exp(), gpcv_iters, printing=display)
+            vol_model, vol_lh = TrainVolModel(self._full_x[1:], vol, vol_mod_iters, printing=display)
+        self.UpdateVolPath(vol)
         if isinstance(self.mean_module, (EWMAMean, DEWMAMean, TEWMAMean)):
             grad_flags = [True, False, False, False]
         else:
