@@ -110,6 +110,15 @@ int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* 
                               float* scratch, int* info, int G, int S, int H, int k, int mean_mode,
                               int use_theta, float theta, float mr_theta, float jitter, void* stream);
 
+/* nonvol_rollouts (voltron/rollout_utils.py:95-115): rollouts of a GP whose kernel is the same for every sample.
+ * e [G,S,H] is the GP part of every path (posterior mean offset + correlated noise, computed by the caller from one
+ * shared factorisation: e = c + M z, see volt_amd/rollout_engine.py); this adds the moving-average mean of the
+ * sample's own stacked series, sequentially in the horizon: samples[.., idx] = mean_s(idx) + e[.., idx].
+ * hist_* [G,k], ema_prev / mr_latent [G], w [k] and mean_mode as in volt_rollout_bordered_f32. */
+int volt_rollout_shared_f32(const float* hist_y, const float* hist_e1, const float* hist_e2, const float* ema_prev,
+                            const float* mr_latent, const float* w, const float* e, float* samples, int G, int S,
+                            int H, int k, int mean_mode, float mr_theta, void* stream);
+
 /* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
  * Runs exactly the factorisation of volt_mll_step_f32 (block column 0 copied from K, the rest read from
  * K inside the panel update; with Y != NULL also the triangular inverse, co-launched with the diagonal
@@ -140,6 +149,13 @@ size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid,
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
                       int* info, void* workspace, int B, int N, int want_grad, void* stream);
+
+/* Dense gradient of the MLL wrt the covariance, for kernels with trainable parameters (Matern / RBF / spectral
+ * mixture baselines, voltron/models/BasicGPModels.py, TrainBasicModel train_utils.py:146-190):
+ *     grad_K[b] = d mll_b / d K_b = 1/2 (alpha alpha' - K_s^-1) / N,   K_s^-1 = Y Y' on the structured GEMM.
+ * Call after volt_mll_step_f32(want_grad = 1) on the same workspace; scratch [B, Np, Np] floats, 16-byte aligned. */
+int volt_mll_grad_k_f32(void* mll_workspace, const float* alpha, float* scratch, float* grad_K, int B, int N,
+                        void* stream);
 
 /* ---- f4: GPCV volatility extraction (LearnGPCV, voltron/train_utils.py:15-67) --------------------
  * Structured batched GEMM on the fp32 MFMA core, C = alpha A B^T + beta C, row-major, K contiguous in

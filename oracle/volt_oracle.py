@@ -21,6 +21,8 @@ function here          follows
                        softplus constraint (third-party, restated)
 ``mll_and_grads``      gpytorch ``ExactMarginalLogLikelihood`` / ``MultivariateNormal.log_prob``
                        call sites ``voltron/train_utils.py:127,240,249``; closed form
+``nonvol_rollouts``    ``voltron/rollout_utils.py:95-115``; ``gp_posterior`` = the latent exact-GP
+                       predictive behind botorch's ``model.posterior`` (third-party, restated)
 =====================  =========================================================
 
 PINNING STATUS
@@ -337,6 +339,71 @@ def rollouts(train_x, train_y, test_x, log_vol_path, pred_vol, z, mean_name="ewm
             rolling_x, stack_y, stack_vol, test_x[idx:idx + 1], pred_vol[:, idx:idx + 1], z[:, idx],
             lambda x, rx=rolling_x, sy=stack_y: mfn(x, rx, sy), latent_mean,
             0.5 if theta is None else theta)[:, 0]                                 # :87-90
+    return samples
+
+
+# ------------------------------------------------------------------ (f)2: baseline GPs
+def rbf_kernel(a, b, lengthscale, outputscale=1.0):
+    """gpytorch ScaleKernel(RBFKernel()): os * exp(-1/2 (a-b)^2 / ls^2)   (BasicWind.py:30-34)."""
+    d = (np.asarray(a, dtype=np.float64)[:, None] - np.asarray(b, dtype=np.float64)[None, :]) / lengthscale
+    return outputscale * np.exp(-0.5 * d * d)
+
+
+def matern_kernel(a, b, lengthscale, outputscale=1.0, nu=2.5):
+    """gpytorch ScaleKernel(MaternKernel(nu)) (BasicGPModels.py:10): os * c_nu(d) exp(-sqrt(2 nu) d), d = |a-b|/ls."""
+    d = np.abs(np.asarray(a, dtype=np.float64)[:, None] - np.asarray(b, dtype=np.float64)[None, :]) / lengthscale
+    c = {0.5: 1.0, 1.5: 1.0 + math.sqrt(3) * d, 2.5: 1.0 + math.sqrt(5) * d + 5.0 / 3.0 * d * d}[nu]
+    return outputscale * c * np.exp(-math.sqrt(2 * nu) * d)
+
+
+def sm_kernel(a, b, weights, means, scales):
+    """gpytorch SpectralMixtureKernel, 1-D inputs: sum_q w_q exp(-2 pi^2 tau^2 v_q^2) cos(2 pi tau mu_q)."""
+    tau = np.asarray(a, dtype=np.float64)[:, None] - np.asarray(b, dtype=np.float64)[None, :]
+    out = np.zeros_like(tau)
+    for w, mu, v in zip(weights, means, scales):
+        out += w * np.exp(-2 * math.pi ** 2 * tau ** 2 * v ** 2) * np.cos(2 * math.pi * tau * mu)
+    return out
+
+
+def gp_posterior(kfun, noise, xt, y, mean_t, xs, mean_s):
+    """Latent exact-GP predictive (botorch ``posterior``, observation_noise=False):  y [.., N] may be stacked."""
+    Ktt = kfun(xt, xt) + noise * np.eye(len(xt))
+    Kst = kfun(xs, xt)
+    sol = np.linalg.solve(Ktt, (np.asarray(y, dtype=np.float64) - mean_t)[..., None])[..., 0]
+    mean = mean_s + sol @ Kst.T
+    cov = kfun(xs, xs) - Kst @ np.linalg.solve(Ktt, Kst.T)
+    return mean, cov
+
+
+def nonvol_rollouts(train_x, train_y, test_x, kfun, noise, z, mean_name="ewma", k=20):
+    """rollout_utils.py:95-115 with the normal draws ``z`` [S,H] passed in.  train_x [N], train_y [N] RAW prices
+    (the reference stacks ``train_y.log()`` whole, :100), kfun(a, b) the model's covariance, noise the likelihood's.
+    Step 0 samples the un-stacked model S times (:99); every later step re-conditions the S stacked series (:102-114)
+    from scratch, exactly as the reference does."""
+    f32 = np.float32
+    train_x = np.asarray(train_x, dtype=f32)
+    log_y = np.log(np.asarray(train_y, dtype=f32)).astype(f32)
+    test_x = np.asarray(test_x, dtype=f32)
+    z = np.asarray(z, dtype=np.float64)
+    S, H = z.shape
+    def mfull(y):                                             # the means' third branch: train points + next point
+        e1 = ewma(y, k)
+        if mean_name == "ewma":
+            return e1
+        e2 = ewma(e1, k)[..., :-1]                            # EWMA.py:83-84
+        if mean_name == "dewma":
+            return 2 * e1 - e2
+        e3 = ewma(e2, k)[..., :-1]                            # EWMA.py:104-106
+        return 3 * e1 - 3 * e2 + e3
+    samples = np.zeros((S, H), dtype=f32)
+    stack0 = np.repeat(log_y[None, :], S, axis=0)
+    for idx in range(H):
+        stack_y = log_y if idx == 0 else np.concatenate([stack0, samples[:, :idx]], axis=-1)
+        rolling_x = np.concatenate([train_x, test_x[:idx]])
+        ma = mfull(stack_y).astype(np.float64)                # [.., N+idx+1]: train-point means then the next point's
+        mean, cov = gp_posterior(kfun, noise, rolling_x, stack_y, ma[..., :-1], test_x[idx:idx + 1], ma[..., -1:])
+        sd = math.sqrt(max(float(cov[0, 0]), 0.0))
+        samples[:, idx] = (np.broadcast_to(mean, (S, 1))[:, 0] if idx == 0 else mean[:, 0]) + sd * z[:, idx]
     return samples
 
 

@@ -257,7 +257,71 @@ def main():
               gpm_const=np.array(const), gpm_samples=gp_out.numpy())
     np.savez_compressed(os.path.join(OUT, "rollouts.npz"), **ro)
 
-    for f in ("fill.npz", "ewma.npz", "rollouts.npz"):
+    # ---- (f)2: nonvol_rollouts (rollout_utils.py:95-115) -------------------------------------------------
+    # The loop is the reference's; ``model.posterior`` (botorch, absent) is a dense fp64 exact-GP predictive written
+    # out here, fed by the reference's own EWMA mean classes.  Pins: what is stacked, which mean branch is hit,
+    # how the draws are consumed.
+    def matern25(a, b, ls, os_):
+        d = (a.reshape(-1, 1) - b.reshape(1, -1)).abs() / ls
+        return os_ * (1 + np.sqrt(5) * d + 5. / 3. * d ** 2) * torch.exp(-np.sqrt(5) * d)
+
+    def rbf(a, b, ls, os_):
+        d = (a.reshape(-1, 1) - b.reshape(1, -1)) / ls
+        return os_ * torch.exp(-0.5 * d ** 2)
+
+    class FakePosterior:
+        def __init__(self, mean, cov):
+            self.mean_, self.cov = mean, cov            # mean [q] or [S,q]; cov [q,q]
+
+        def sample(self, sample_shape=torch.Size()):
+            L = torch.linalg.cholesky(self.cov)
+            eps = torch.randn(*sample_shape, *self.mean_.shape)
+            return (self.mean_ + (L @ eps.double().unsqueeze(-1)).squeeze(-1)).float().unsqueeze(-1)
+
+    class FakeExactGP:
+        def __init__(self, train_x, log_y, mean_module, kfun, noise):
+            self.train_inputs, self.train_targets = (train_x.view(-1, 1),), log_y
+            self.mean_module, self.kfun, self.noise = mean_module, kfun, noise
+
+        def train(self):
+            return self
+
+        def posterior(self, X):
+            xt = self.train_inputs[0].reshape(-1)
+            xs = X.reshape(-1)
+            y = self.train_targets.double()
+            full_mean = self.mean_module(torch.cat((xt, xs)).view(-1, 1)).double()      # third branch of EWMAMean.forward
+            n = xt.numel()
+            mt, ms = full_mean[..., :n], full_mean[..., n:]
+            xt, xs = xt.double(), xs.double()
+            Ktt = self.kfun(xt, xt) + self.noise * torch.eye(n, dtype=torch.float64)
+            Kst = self.kfun(xs, xt)
+            sol = torch.linalg.solve(Ktt, (y - mt).unsqueeze(-1)).squeeze(-1)
+            mean = ms + sol @ Kst.T
+            cov = self.kfun(xs, xs) - Kst @ torch.linalg.solve(Ktt, Kst.T)
+            return FakePosterior(mean, cov)
+
+    nv = {}
+    for tag, (n, S, H, k, mean_cls, kf, ls, os_, noise) in {
+            "matern_ewma": (60, 4, 6, 5, EW.EWMAMean, matern25, 0.3, 0.5, 0.05),
+            "rbf_dewma": (50, 3, 5, 7, EW.DEWMAMean, rbf, 0.2, 0.3, 0.1),
+            "matern_tewma": (80, 5, 8, 10, EW.TEWMAMean, matern25, 0.5, 0.2, 0.02)}.items():
+        F, _ = sde_series(n - 1, 3000 + len(nv))
+        train_y = torch.tensor(F)                                       # n prices; nonvol uses all of them (:100)
+        train_x = torch.arange(n) / 252.
+        test_x = torch.arange(H) / 252. + train_x[-1] + train_x[1]
+        model = FakeExactGP(train_x, train_y.log(), mean_cls(train_x, train_y.log(), k),
+                            lambda a, b, kf=kf, ls=ls, os_=os_: kf(a, b, ls, os_), noise)
+        torch.manual_seed(99)
+        with _RecordRandn() as rec:
+            samples = RU.Rollouts(train_x, train_y, test_x, model, nsample=S, method="nonvol")
+        zs = torch.stack([d.reshape(-1) for d in rec.draws], 1)                         # [S,H]
+        nv.update({f"{tag}_train_x": train_x.numpy(), f"{tag}_train_y": train_y.numpy(), f"{tag}_test_x": test_x.numpy(),
+                   f"{tag}_z": zs.numpy(), f"{tag}_k": np.array(k), f"{tag}_ls": np.array(ls), f"{tag}_os": np.array(os_),
+                   f"{tag}_noise": np.array(noise), f"{tag}_samples": samples.numpy()})
+    np.savez_compressed(os.path.join(OUT, "nonvol.npz"), **nv)
+
+    for f in ("fill.npz", "ewma.npz", "rollouts.npz", "nonvol.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
 

@@ -129,6 +129,11 @@ def test_gpcv_stage_refuses_cpu_tensors_and_validates_arguments():
     assert L.volt_gpcv_workspace_bytes(2, 300, 1) > L.volt_gpcv_workspace_bytes(2, 300, 0) > L.volt_mll_workspace_bytes(2, 300, 1)
     assert L.volt_gpcv_step_f32(None, 8, 64, 1e-3, *([None] * 6), 75, 1e-6, 1e-3, 1.0, 1.0, *([None] * 7), 1, 8, None) == -1
     assert L.volt_gemm_nt_f32(256, 128, 0, 0, 256, 128, 0, 0, 256, 128, 0, 0, 1.0, 0.0, 1, 100, 128, 128, None) == -16
+    assert L.volt_mll_grad_k_f32(None, None, None, None, 1, 8, None) == -1
+    assert L.volt_rollout_shared_f32(*([None] * 8), 1, 1, 4, 5, 0, 0.5, None) == -1
     x = torch.arange(50, dtype=torch.float32) / 252
     with pytest.raises(_lib.VoltHipError):
         LearnGPCV(x, torch.rand(51) + 1.0, train_iters=1)
+    from volt_amd.train_utils import TrainBasicModel
+    with pytest.raises(_lib.VoltHipError):
+        TrainBasicModel(x, torch.rand(50) + 1.0, train_iters=1)

@@ -91,3 +91,17 @@ def test_generate_prediction_multipoint(golden):
                                  lambda x: np.full((np.asarray(x).shape[0],), c, dtype=np.float32))
     assert out.shape == g["gpm_samples"].shape
     np.testing.assert_allclose(out, g["gpm_samples"], rtol=0, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------- (f)2: nonvol_rollouts
+@pytest.mark.parametrize("tag,mean,kern", [("matern_ewma", "ewma", "matern"), ("rbf_dewma", "dewma", "rbf"),
+                                           ("matern_tewma", "tewma", "matern")])
+def test_nonvol_rollouts_match_reference_loop(golden, tag, mean, kern):
+    """oracle.nonvol_rollouts vs the reference's own loop (rollout_utils.py:95-115) run with its EWMA mean classes and
+    a dense fp64 predictive standing in for botorch's ``posterior`` (tests/golden/make_golden.py)."""
+    d = golden("nonvol")
+    ls, os_, noise, k = (float(d[f"{tag}_{n}"]) for n in ("ls", "os", "noise", "k"))
+    kf = vo.matern_kernel if kern == "matern" else vo.rbf_kernel
+    out = vo.nonvol_rollouts(d[f"{tag}_train_x"], d[f"{tag}_train_y"], d[f"{tag}_test_x"],
+                             lambda a, b: kf(a, b, ls, os_), noise, d[f"{tag}_z"], mean_name=mean, k=int(k))
+    assert np.abs(out - d[f"{tag}_samples"]).max() < 5e-5

@@ -33,6 +33,8 @@ _SIGS = {
     "volt_tune_update_f32": (C.c_int, [_ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "volt_mll_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "volt_mll_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
+    "volt_mll_grad_k_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_rollout_shared_f32": (C.c_int, [_ptr] * 8 + [_i32] * 5 + [_f32, _ptr]),
     "volt_gemm_nt_f32": (C.c_int, [_ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _i32, _ptr, _i64, _i64, _i32, _f32, _f32,
                                    _i32, _i32, _i32, _i32, _ptr]),
     "volt_gpcv_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -373,4 +373,26 @@ int volt_gpcv_step_f32(const float* K, int64_t ldk, int64_t bsk, float jitter, c
     return 0;
 }
 
+int volt_mll_grad_k_f32(void* mll_workspace, const float* alpha, float* scratch, float* grad_K, int B, int N,
+                        void* stream) {
+    if (!mll_workspace || ((uintptr_t)mll_workspace & 255)) return -1;
+    if (!alpha) return -2;
+    if (!scratch || ((uintptr_t)scratch & 15)) return -3;
+    if (!grad_K) return -4;
+    if (B < 0 || B > 65535) return -5;
+    if (N < 1) return -6;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    const int64_t mat = (int64_t)Np * Np;
+    const float* Y = volt_internal_mll_y(mll_workspace, B, N);
+    GemmArgs g{Y, Y, scratch, Np, mat, Np, mat, Np, mat, n, n, n, 2, 2, 0, 1.f, 0.f, nullptr};       // K_s^-1 = Y Y'
+    int rc = launch_gemm(g, B, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gpcv_dk_kernel, dim3((N + 255) / 256, N, B), dim3(256), 0, s, scratch, alpha, grad_K, N, Np,
+                       1.f / (float)N);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // extern "C"

@@ -29,6 +29,33 @@ __device__ __forceinline__ double wave_sum_d(double x) {
     return x;
 }
 
+
+// Mean of the appended point idx for the EWMA family (EWMA.py:20-37, :39-54, :74-91, :94-113, :116-135) from the
+// per-sample histories in LDS (k train-tail values followed by the values appended so far).  ma1 = plain EMA at
+// the new index, e2new = EMA(EMA) there (dewma / tewma).
+__device__ __forceinline__ float family_mean(int mode, int idx, int k, int lane, const float* sw, const float* hy,
+                                             const float* he1, const float* he2, float ema_prev, float mr_theta,
+                                             float mr_latent, float& ma1, float& e2new) {
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int j = lane; j < k; j += 64) {
+        const double wj = (double)sw[j];
+        a1 += wj * (double)hy[idx + j];
+        if (mode == 1 || mode == 2) a2 += wj * (double)he1[idx + j];
+        if (mode == 2) a3 += wj * (double)he2[idx + j];
+    }
+    ma1 = (float)wave_sum_d(a1);
+    float mstar = ma1;
+    e2new = 0.f;
+    if (mode == 1 || mode == 2) {
+        e2new = (float)wave_sum_d(a2);                       // EMA(EMA) at the new index
+        if (mode == 1) mstar = 2.f * ma1 - e2new;
+        else mstar = 3.f * ma1 - 3.f * e2new + (float)wave_sum_d(a3);
+    } else if (mode == 3) {
+        mstar = ma1 - mr_theta * (ema_prev - mr_latent);
+    }
+    return mstar;
+}
+
 struct RolloutParams {
     // per series g (G series), all device pointers
     const float* rho;        // [G]   q'q
@@ -145,23 +172,9 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         wz = wave_sum_f(wz);
 
         // ---- mean of the new point: EWMA family on the stacked series (EWMA.py:20-37) ----------
-        double a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int j = lane; j < k; j += 64) {
-            const double wj = (double)sw[j];
-            a1 += wj * (double)hy[idx + j];
-            if (p.mean_mode == 1 || p.mean_mode == 2) a2 += wj * (double)he1[idx + j];
-            if (p.mean_mode == 2) a3 += wj * (double)he2[idx + j];
-        }
-        const float ma1 = (float)wave_sum_d(a1);
-        float mstar = ma1;
-        float e2new = 0.f;
-        if (p.mean_mode == 1 || p.mean_mode == 2) {
-            e2new = (float)wave_sum_d(a2);                   // EMA(EMA) at the new index
-            if (p.mean_mode == 1) mstar = 2.f * ma1 - e2new;
-            else mstar = 3.f * ma1 - 3.f * e2new + (float)wave_sum_d(a3);
-        } else if (p.mean_mode == 3) {
-            mstar = ma1 - p.mr_theta * (ema_prev - p.mr_latent[g]);
-        }
+        float ma1, e2new;
+        const float mstar = family_mean(p.mean_mode, idx, k, lane, sw, hy, he1, he2, ema_prev, p.mr_theta,
+                                        (p.mean_mode == 3) ? p.mr_latent[g] : 0.f, ma1, e2new);
 
         // ---- conditional and draw (rollout_utils.py:36-53) --------------------------------------
         const float v = pv[idx];
@@ -217,6 +230,58 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     if (lane == 0) p.info[(size_t)g * p.S + s] = bad;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Rollouts of a GP whose kernel does not depend on the sample (voltron/rollout_utils.py:95-115, nonvol_rollouts):
+// every sample shares one factorisation of the (N+H)^2 matrix, and the new entry of L^-1 r for an appended draw
+// is gamma_j z_j whatever the history, so the GP part of every path is e = c + M z (one small GEMM on the host
+// side, volt_amd/rollout_engine.py).  What stays sequential per sample is the moving-average mean of the
+// stacked series: samples[idx] = mean_s(idx) + e[idx], with mean_s over the sample's own earlier draws.
+struct SharedParams {
+    const float *hist_y, *hist_e1, *hist_e2, *ema_prev, *mr_latent, *w, *e;
+    float* samples;
+    int G, S, H, k, mean_mode;
+    float mr_theta;
+};
+
+__global__ __launch_bounds__(256) void rollout_shared_kernel(SharedParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + wave, g = blockIdx.y;
+    const int H = p.H, k = p.k, hl = k + H;
+    float* hy = lds + (size_t)wave * 3 * hl;
+    float* he1 = hy + hl;
+    float* he2 = he1 + hl;
+    float* sw = lds + (size_t)4 * 3 * hl;
+    for (int j = threadIdx.x; j < k; j += 256) sw[j] = p.w[j];
+    if (s < p.S) {
+        for (int j = lane; j < k; j += 64) {
+            hy[j] = p.hist_y[(size_t)g * k + j];
+            he1[j] = (p.mean_mode == 1 || p.mean_mode == 2) ? p.hist_e1[(size_t)g * k + j] : 0.f;
+            he2[j] = (p.mean_mode == 2) ? p.hist_e2[(size_t)g * k + j] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (s >= p.S) return;
+    const size_t row = ((size_t)g * p.S + s) * H;
+    float ema_prev = (p.mean_mode == 3) ? p.ema_prev[g] : 0.f;
+    for (int idx = 0; idx < H; ++idx) {
+        float ma1, e2new;
+        const float mstar = family_mean(p.mean_mode, idx, k, lane, sw, hy, he1, he2, ema_prev, p.mr_theta,
+                                        (p.mean_mode == 3) ? p.mr_latent[g] : 0.f, ma1, e2new);
+        const float smp = mstar + p.e[row + idx];
+        if (lane == 0) {
+            p.samples[row + idx] = smp;
+            hy[k + idx] = smp;
+            he1[k + idx] = ma1;
+            he2[k + idx] = e2new;
+        }
+        ema_prev = ma1;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+}
+
 }  // namespace volt
 
 extern "C" {
@@ -261,6 +326,34 @@ int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(rollout_bordered_kernel, dim3((S + 3) / 4, G), dim3(256), lds, (hipStream_t)stream, p);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_rollout_shared_f32(const float* hist_y, const float* hist_e1, const float* hist_e2, const float* ema_prev,
+                            const float* mr_latent, const float* w, const float* e, float* samples, int G, int S, int H,
+                            int k, int mean_mode, float mr_theta, void* stream) {
+    using namespace volt;
+    if (!hist_y) return -1;
+    if (!w) return -6;
+    if (!e) return -7;
+    if (!samples) return -8;
+    if (G < 0) return -9;
+    if (S < 0) return -10;
+    if (H < 1 || H > 4096) return -11;
+    if (k < 1 || k > 2048) return -12;
+    if (mean_mode < 0 || mean_mode > 3) return -13;
+    if ((mean_mode == 1 || mean_mode == 2) && !hist_e1) return -2;
+    if (mean_mode == 2 && !hist_e2) return -3;
+    if (mean_mode == 3 && (!ema_prev || !mr_latent)) return -4;
+    if (G == 0 || S == 0) return 0;
+    SharedParams p{hist_y, hist_e1, hist_e2, ema_prev, mr_latent, w, e, samples, G, S, H, k, mean_mode, mr_theta};
+    const size_t lds = ((size_t)4 * 3 * (k + H) + k) * sizeof(float);
+    if (lds > 160 * 1024) return -11;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_shared_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(rollout_shared_kernel, dim3((S + 3) / 4, G), dim3(256), lds, (hipStream_t)stream, p);
     VOLT_LAUNCH_CHECK();
     return 0;
 }

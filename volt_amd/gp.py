@@ -40,7 +40,33 @@ class NumericalWarning(RuntimeWarning):
 
 # ------------------------------------------------------------------------------------ modules
 class Module(nn.Module):
-    pass
+    """gpytorch.Module stand-in: nn.Module plus ``register_prior`` (train_utils.py:158-159 puts a NormalPrior on the
+    log-linear mean's slope; ExactMarginalLogLikelihood adds the log-priors / N like gpytorch does)."""
+
+    def register_prior(self, name, prior, param_or_closure, setting_closure=None):
+        if not hasattr(self, "_priors"):
+            object.__setattr__(self, "_priors", {})
+        if isinstance(param_or_closure, str) and not hasattr(self, param_or_closure):
+            raise AttributeError(f"Unknown parameter {param_or_closure} for {type(self).__name__}")
+        self._priors[name] = (prior, param_or_closure)
+
+    def named_priors(self, prefix=""):
+        for name, (prior, target) in getattr(self, "_priors", {}).items():
+            closure = (lambda m, t=target: getattr(m, t)) if isinstance(target, str) else target
+            yield prefix + name, self, prior, closure
+        for cname, child in self.named_children():
+            if isinstance(child, Module):
+                yield from child.named_priors(prefix + cname + ".")
+
+
+class NormalPrior:
+    """gpytorch.priors.NormalPrior(loc, scale): log-density evaluated on the parameter's own device."""
+
+    def __init__(self, loc, scale, validate_args=None, transform=None):
+        self.loc, self.scale = float(loc), float(scale)
+
+    def log_prob(self, x):
+        return -0.5 * ((x - self.loc) / self.scale) ** 2 - math.log(self.scale) - 0.5 * math.log(2 * math.pi)
 
 
 class Kernel(Module):
@@ -258,6 +284,55 @@ class ExactGP(Module):
             "use GeneratePrediction / Rollouts (voltron/rollout_utils.py) which this package does implement")
 
 
+def exact_posterior(model, x, observation_noise=False):
+    """Exact-GP predictive at x for a model with ``mean_module(x)`` and a two-input ``covar_module(x1, x2)``:
+    mean = m(x) + K_*t K_s^-1 (y - m(X)),  cov = K_** - K_*t K_s^-1 K_t*  (+ noise).  K_s = L L' on the HIP potrf,
+    K_s^-1 = Y Y' with Y = L^-T from the HIP triangular inverse, products on the library GEMM.
+    Targets [S,N] (one shared input set, S target vectors -- nonvol_rollouts' stacked samples) give a batch mean."""
+    with torch.no_grad():
+        xt = model.train_inputs[0]
+        x = x.unsqueeze(-1) if x.ndim == 1 else x
+        y = model.train_targets
+        n = xt.shape[-2]
+        Ktt = _dense(model.covar_module(xt, xt)).to(torch.float32)
+        noise = model.likelihood.noise.reshape(-1)[:1]
+        A = (Ktt + noise * torch.eye(n, device=xt.device)).reshape(1, n, n)
+        f, _ = _safe_factor(A)
+        Y = ops.trtri(f)[0]                                           # L^-T  (upper)
+        Kst = _dense(model.covar_module(x, xt)).to(torch.float32)     # [H,N]
+        G = ops.gemm_nt(Kst, Y.mT.contiguous(), uplo_b=1)             # K_*t L^-T
+        r = (y - model.mean_module(xt)).to(torch.float32).reshape(-1, n)
+        z = ops.gemm_nt(r, Y.mT.contiguous(), uplo_b=1)               # rows L^-1 r
+        mean = model.mean_module(x) + ops.gemm_nt(z, G).reshape(*y.shape[:-1], x.shape[-2])
+        cov = _dense(model.covar_module(x, x)).to(torch.float32) - ops.gemm_nt(G, G)
+        if observation_noise:
+            cov = cov + noise * torch.eye(x.shape[-2], device=x.device)
+        return MultivariateNormal(mean, cov)
+
+
+class GPPosterior:
+    """What botorch's ``model.posterior(X)`` hands back, as far as rollout_utils.py:99,114 uses it:
+    ``.mean`` / ``.variance`` [.., q, 1] and ``.sample(sample_shape)`` -> sample_shape x .. x q x 1."""
+
+    def __init__(self, mvn):
+        self.mvn = mvn
+
+    @property
+    def mean(self):
+        return self.mvn.mean.unsqueeze(-1)
+
+    @property
+    def variance(self):
+        return self.mvn.variance.unsqueeze(-1)
+
+    def rsample(self, sample_shape=torch.Size(), base_samples=None):
+        return self.mvn.rsample(sample_shape, base_samples).unsqueeze(-1)
+
+    def sample(self, sample_shape=torch.Size(), base_samples=None):
+        with torch.no_grad():
+            return self.rsample(sample_shape, base_samples)
+
+
 # --------------------------------------------------------------------------------------- MLL
 class _ExactMLL(torch.autograd.Function):
     """mll[b] = log N(y_b; m_b, K_b + s2_b I) / N  with analytic backward:
@@ -265,11 +340,10 @@ class _ExactMLL(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, K, mean, noise, target, holder, scale=None):
-        if K.requires_grad:
-            raise NotImplementedError("the volatility covariance has no trainable parameters on this path "
-                                      "(train_cov is detached, VoltMagpie.py:46); K.requires_grad is unsupported")
         B, n = mean.shape
-        need_grad = any(ctx.needs_input_grad[1:4]) or (scale is not None and ctx.needs_input_grad[5])
+        want_dk = bool(ctx.needs_input_grad[0])       # kernels with trainable parameters (Matern / SM / FBM baselines)
+        K = K.detach()
+        need_grad = want_dk or any(ctx.needs_input_grad[1:4]) or (scale is not None and ctx.needs_input_grad[5])
         ws = holder.workspace(B, n, need_grad, K.device)
         resid = (target - mean).to(torch.float32)
         # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
@@ -291,24 +365,29 @@ class _ExactMLL(torch.autograd.Function):
                                   f"(first failing pivot {first})")
         ctx.n = n
         ctx.has_scale = scale is not None
+        ctx.want_dk = want_dk
         if need_grad:
             extra = (out[:, 2:6].clone(), noise.detach().clone(), scale.detach().clone()) if scale is not None else ()
-            ctx.save_for_backward(out[:, 1].clone(), alpha.clone(), *extra)
+            gk = (ops.mll_grad_k(ws),) if want_dk else ()       # 1/2 (a a' - K_s^-1) / N from the step's own Y = L^-T
+            ctx.save_for_backward(out[:, 1].clone(), alpha.clone(), *gk, *extra)
         return out[:, 0].clone()
 
     @staticmethod
     def backward(ctx, g):
         dsig, alpha = ctx.saved_tensors[:2]
         gm = g.unsqueeze(-1) * alpha / ctx.n
-        gscale = None
+        gscale = gK = None
+        rest = ctx.saved_tensors[2:]
+        if ctx.want_dk:
+            gK, rest = g.reshape(-1, 1, 1) * rest[0], rest[1:]
         if ctx.has_scale:
             # K = c M  =>  a'Ma = (r'a - s2 a'a)/c  and  tr(K_s^-1 M) = (N - s2 tr K_s^-1)/c
-            q, noise, c = ctx.saved_tensors[2:]
+            q, noise, c = rest
             quad, tr, aa = q[:, 0], q[:, 2], q[:, 3]
             gscale = (g * 0.5 * ((quad - noise * aa) - (ctx.n - noise * tr)) / (ctx.n * c.reshape(-1))).reshape(c.shape)
             if gscale.shape != c.shape:
                 gscale = gscale.sum().reshape(c.shape)
-        return None, gm, g * dsig, -gm, None, gscale
+        return gK, gm, g * dsig, -gm, None, gscale
 
 
 class ExactMarginalLogLikelihood(Module):
@@ -345,7 +424,11 @@ class ExactMarginalLogLikelihood(Module):
         noise = self.likelihood.noise.reshape(-1)
         noise = noise.expand(mean2.shape[0]) if noise.numel() == 1 else noise
         res = _ExactMLL.apply(K3, mean2.to(torch.float32), noise.to(torch.float32), t2.to(torch.float32), self, scale)
-        return res.reshape(mean.shape[:-1]) if batched else res.reshape(())
+        res = res.reshape(mean.shape[:-1]) if batched else res.reshape(())
+        priors = self.model.named_priors() if isinstance(self.model, Module) else ()
+        for _, module, prior, closure in priors:                          # gpytorch: + sum log p(theta) / num_data
+            res = res + prior.log_prob(closure(module)).sum() / n
+        return res
 
 
 # -------------------------------------------------------------------------- psd_safe_cholesky

@@ -11,14 +11,16 @@ import torch
 from .. import ops
 from ..gp import ExactGP, MultivariateNormal, _safe_factor
 from ..kernels.BMKernel import BMKernel
+from ..kernels.FBMKernel import FBMKernel
 
 
 class BMGP(ExactGP):
     def __init__(self, train_x, train_y, likelihood, kernel="bm"):
         super().__init__(train_x, train_y, likelihood)
-        if kernel != "bm":
-            raise NotImplementedError("only the Brownian-motion kernel is provided (FBMKernel is out of scope)")
-        self.covar_module = BMKernel().to(train_x.device)
+        if kernel == "bm":
+            self.covar_module = BMKernel().to(train_x.device)
+        elif kernel == "fbm":
+            self.covar_module = FBMKernel().to(train_x.device)          # BMGP.py:15-16; dense d mll / d K path
         self.scaling = (train_x[1] - train_x[0])
 
     def mean_module(self, x):
@@ -32,7 +34,7 @@ class BMGP(ExactGP):
             xt = self.train_inputs[0]
             y = self.train_targets
             n = xt.shape[0]
-            Ktt = self.covar_module.forward(xt, xt)
+            Ktt = self.covar_module.forward(xt, xt).reshape(n, n)
             noise = self.likelihood.noise.reshape(-1)[:1]
             A = (Ktt + noise * torch.eye(n, device=xt.device)).unsqueeze(0)
             f, _ = _safe_factor(A)

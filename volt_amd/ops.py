@@ -247,3 +247,17 @@ def gpcv_step(K, resid, m, Lq, y, gh_x, gh_w, ws: GpcvWorkspace | None = None, w
         ws.grad_K.data_ptr() if want_dk else None, ws.info.data_ptr(), ws.ptr, B, n, _lib.stream_ptr()),
         "volt_gpcv_step")
     return ws
+
+
+def mll_grad_k(ws: MllWorkspace) -> torch.Tensor:
+    """d mll / d K = 1/2 (alpha alpha' - K_s^-1) / N  [B,N,N], from the Y = L^-T the last ``mll_step(want_grad=True)``
+    left in ``ws`` (volt_mll_grad_k_f32) -- for kernels with trainable parameters."""
+    if not ws.want_grad:
+        raise ValueError("mll_grad_k needs a workspace used with want_grad=True")
+    B, n = ws.B, ws.N
+    Np = padded_n(n)
+    scratch = torch.empty(B, Np, Np, dtype=torch.float32, device=ws.buf.device)
+    gK = torch.empty(B, n, n, dtype=torch.float32, device=ws.buf.device)
+    _lib.check(_lib.lib().volt_mll_grad_k_f32(ws.ptr, ws.alpha.data_ptr(), scratch.data_ptr(), gK.data_ptr(), B, n,
+                                              _lib.stream_ptr()), "volt_mll_grad_k")
+    return gK

@@ -12,7 +12,7 @@ import warnings
 import torch
 
 from . import _lib, ops
-from .gp import NumericalWarning, _safe_factor
+from .gp import NumericalWarning, _safe_factor, _dense as _dense_cov
 from .means import DEWMAMean, EWMAMean, MeanRevertingEMAMean, TEWMAMean
 
 _MODES = {EWMAMean: 0, DEWMAMean: 1, TEWMAMean: 2, MeanRevertingEMAMean: 3}
@@ -25,6 +25,36 @@ def _tail(series: torch.Tensor, k: int) -> torch.Tensor:
         return series[..., n - k:].contiguous()
     pad = series[..., :1].expand(*series.shape[:-1], k - n)
     return torch.cat((pad, series), -1).contiguous()
+
+
+def _family_state(log_y, k, mean_mode, mr_theta=0.5, mr_latent=None):
+    """Train-point means of the EWMA family for log_y [G,N] and the k-long tails the rollout kernels continue from:
+    (m_tr [G,N], hist_y, hist_e1, hist_e2 [G,k], ema_prev [G], mr_latent [G], taps [k])."""
+    f32 = torch.float32
+    G, N = log_y.shape
+    w = ops.ewma_weights(k, log_y.device)
+    ema = ops.ewma(log_y, k)                                                   # [G,N+1]
+    hist_e1 = hist_e2 = ema_prev = mrl = None
+    if mean_mode == 0:
+        m_tr = ema[:, :-1]
+    elif mean_mode == 1:
+        ee = ops.ewma(ema, k)[:, :-1]                                          # [G,N+1]
+        m_tr = (2 * ema - ee)[:, :-1]
+        hist_e1, hist_e2 = _tail(ema[:, :-1], k), None
+    elif mean_mode == 2:
+        ee = ops.ewma(ema, k)[:, :-1]
+        eee = ops.ewma(ee, k)[:, :-1]
+        m_tr = (3 * ema - 3 * ee + eee)[:, :-1]
+        hist_e1, hist_e2 = _tail(ema[:, :-1], k), _tail(ee[:, :-1], k)
+    elif mean_mode == 3:
+        mrl = (log_y.mean(-1) if mr_latent is None else mr_latent.reshape(-1).expand(G)).to(f32).contiguous()
+        em = ema.clone()
+        em[:, 1:] -= mr_theta * (ema[:, :-1] - mrl[:, None])
+        m_tr = em[:, :-1]
+        ema_prev = ema[:, N - 1].contiguous()
+    else:
+        raise ValueError("mean_mode")
+    return m_tr, _tail(log_y.to(f32), k), hist_e1, hist_e2, ema_prev, mrl, w
 
 
 def _refined_solve(K, fct, rhs, jitter_used=0.0, iters=30, tol=1e-12):
@@ -84,28 +114,7 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
     K = ops.fill(U)
     fct, used = _safe_factor(K, jitter)                                        # psd_safe_cholesky(K_tr, 1e-4), :35
     # train residuals with the model's mean family
-    w = ops.ewma_weights(k, dev)
-    ema = ops.ewma(log_y, k)                                                   # [G,N+1]
-    hist_e1 = hist_e2 = ema_prev = mrl = None
-    if mean_mode == 0:
-        m_tr = ema[:, :-1]
-    elif mean_mode == 1:
-        ee = ops.ewma(ema, k)[:, :-1]                                          # [G,N+1]
-        m_tr = (2 * ema - ee)[:, :-1]
-        hist_e1, hist_e2 = _tail(ema[:, :-1], k), None
-    elif mean_mode == 2:
-        ee = ops.ewma(ema, k)[:, :-1]
-        eee = ops.ewma(ee, k)[:, :-1]
-        m_tr = (3 * ema - 3 * ee + eee)[:, :-1]
-        hist_e1, hist_e2 = _tail(ema[:, :-1], k), _tail(ee[:, :-1], k)
-    elif mean_mode == 3:
-        mrl = (log_y.mean(-1) if mr_latent is None else mr_latent.reshape(-1).expand(G)).to(f32).contiguous()
-        em = ema.clone()
-        em[:, 1:] -= mr_theta * (ema[:, :-1] - mrl[:, None])
-        m_tr = em[:, :-1]
-        ema_prev = ema[:, N - 1].contiguous()
-    else:
-        raise ValueError("mean_mode")
+    m_tr, hist_y, hist_e1, hist_e2, ema_prev, mrl, w = _family_state(log_y, k, mean_mode, mr_theta, mr_latent)
     r_tr = (log_y.to(f32) - m_tr).contiguous()
     # rho = u'K^-1 u and tau = u'K^-1 r_tr enter every sample's Schur complement C_s - rho 11', whose
     # entries are ~dx vol^2 while rho ~ V[N-1]: they must be accurate far beyond fp32 round-off times
@@ -113,8 +122,6 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
     xu = _refined_solve(K, fct, U, used)
     rho = (U.double() * xu).sum(-1).to(f32).contiguous()
     tau = (r_tr.double() * xu).sum(-1).to(f32).contiguous()
-    hist_y = _tail(log_y.to(f32), k)
-
     samples = torch.empty(G, S, H, dtype=f32, device=dev)
     info = torch.empty(G, S, dtype=torch.int32, device=dev)
     nbytes = _lib.lib().volt_rollout_scratch_bytes(G, S, H)
@@ -165,3 +172,58 @@ def rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean,
         mm.train_y, mm.train_x = stack_y, rolling_x
         model.train_x, model.train_y, model.log_vol_path = rolling_x, stack_y, stack_vol
     return samples.cpu()
+
+
+def rollouts_shared(train_x, train_y, test_x, model, nsample, z=None):
+    """nonvol_rollouts (voltron/rollout_utils.py:95-115) for an exact GP whose kernel does not depend on the sample.
+
+    The reference re-conditions S stacked series on one more point per step through ``model.posterior``.  All S
+    systems share their matrix, and that matrix is a leading block of K([train, test]) + s2 I, so ONE factorisation
+    L of the (N+H)^2 matrix serves every step: with l = L[N+i, :N+i], d = L[N+i, N+i] the latent conditional of
+    point N+i is  mean = m_s(x_i) + l w_s,  var = d^2 - s2,  and the entry of w_s = L^-1 r_s the draw appends is
+    sqrt(var) z / d -- independent of the history.  Hence  sample_s = m_s + c + M z_s  with c = L[N:, :N] L_NN^-1 r_tr
+    and a fixed lower-triangular M: one GEMM, plus the moving-average recursion of the mean (csrc/rollout.hip).
+    Returns samples [S,H] (device) and the dense pieces for the caller's bookkeeping."""
+    dev = train_x.device
+    f32 = torch.float32
+    N, H, S = train_x.numel(), test_x.numel(), nsample
+    log_y = train_y.log().to(f32).reshape(1, N)
+    mm = model.mean_module
+    xs = torch.cat((train_x, test_x)).to(f32).unsqueeze(-1)
+    with torch.no_grad():
+        K = _dense_cov(model.covar_module(xs, xs)).to(f32)
+        noise = float(model.likelihood.noise.reshape(-1)[0])
+        fct, _ = _safe_factor((K + noise * torch.eye(N + H, device=dev)).unsqueeze(0))
+        L = fct.L[0]
+        family = type(mm) in _MODES
+        if family:
+            kw = dict(mr_theta=mm.theta, mr_latent=mm.latent_mean) if isinstance(mm, MeanRevertingEMAMean) else {}
+            m_tr, hist_y, hist_e1, hist_e2, ema_prev, mrl, w = _family_state(log_y, mm.k, _MODES[type(mm)], **kw)
+        else:
+            m_all = mm(xs).to(f32).reshape(-1)
+            m_tr = m_all[:N].reshape(1, N)
+        r = torch.zeros(1, N + H, device=dev, dtype=f32)
+        r[:, :N] = log_y - m_tr
+        w0 = ops.trsv(fct, r)[:, :N]                                             # L_NN^-1 r_tr (leading block of L)
+        c = ops.gemm_nt(L[N:, :N].contiguous(), w0)[:, 0]                        # [H]
+        d = L.diagonal()[N:]
+        var = d * d - noise
+        for jit in (1e-6, 1e-5, 1e-4):                                           # psd_safe_cholesky of the 1x1 covariance
+            var = torch.where(var > 0, var, var + jit)
+        var = var.clamp_min(0.0)
+        sd = var.sqrt()
+        M = torch.tril(L[N:, N:], -1) * (sd / d).unsqueeze(0) + torch.diag(sd)
+        if z is None:
+            z = torch.randn(S, H, device=dev)
+        e = ops.gemm_nt(z.to(f32).contiguous(), M.contiguous(), uplo_b=1) + c    # [S,H]
+        if not family:
+            return m_all[N:].unsqueeze(0) + e
+        samples = torch.empty(1, S, H, dtype=f32, device=dev)
+        e3 = e.reshape(1, S, H).contiguous()
+
+        def P(t):
+            return None if t is None else t.data_ptr()
+        _lib.check(_lib.lib().volt_rollout_shared_f32(
+            P(hist_y), P(hist_e1), P(hist_e2), P(ema_prev), P(mrl), P(w), P(e3), P(samples), 1, S, H, mm.k,
+            _MODES[type(mm)], float(kw.get("mr_theta", 0.5)), _lib.stream_ptr()), "volt_rollout_shared")
+        return samples[0]

@@ -172,7 +172,21 @@ def Rollouts(train_x, train_y, test_x, model, nsample=50, method="volt", theta=N
     return samples
 
 
-def nonvol_rollouts(train_x, train_y, test_x, model, nsample=50):
-    """voltron/rollout_utils.py:95-115 goes through botorch ``model.posterior`` -- SURVEY 8(f) row 2,
-    not part of this path yet."""
-    raise NotImplementedError("nonvol_rollouts (botorch posterior path) is outside the accelerated hot path")
+def nonvol_rollouts(train_x, train_y, test_x, model, nsample=50, *, z=None):
+    """voltron/rollout_utils.py:95-115 -- SURVEY 8(f) row 2: sequential rollouts of a baseline GP (generic kernel,
+    usually a moving-average mean).  The reference conditions ``nsample`` stacked series on one more point per step
+    through botorch's ``model.posterior``; here one shared factorisation + one GEMM + the mean recursion
+    (rollout_engine.rollouts_shared) produce the same draws.  The model is left in the state the reference leaves it
+    in (:106-111); samples come back on the CPU, log-price units.  ``z`` [nsample, H] optionally fixes the N(0,1) draws."""
+    from . import rollout_engine
+    ntest = test_x.numel()
+    samples = rollout_engine.rollouts_shared(train_x, train_y, test_x, model, nsample, z=z)
+    if ntest > 1:
+        stack_y = torch.cat((train_y.log().repeat(nsample, 1), samples[:, :ntest - 1]), -1)
+        rolling_x = torch.cat((train_x, test_x[:ntest - 1]))
+        model.mean_module.train_y = stack_y
+        model.mean_module.train_x = rolling_x
+        model.train_inputs = (rolling_x.view(-1, 1),)
+        model.train_targets = stack_y
+        model.train()
+    return samples.cpu()

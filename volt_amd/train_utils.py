@@ -5,7 +5,8 @@ The loop bodies are the reference's, statement for statement: ``optimizer.zero_g
 voltron(train_x); loss = -mll(output, y); loss.backward(); optimizer.step()``.  What changes is
 what runs underneath: ``mll`` is volt_amd.gp.ExactMarginalLogLikelihood, one fused HIP step with
 an analytic backward.  LearnGPCV (:15-67, the variational GPCV stage) and TrainVolModel (:69-95) are here
-too, on the same library; TrainBasicModel (Matern/SM baselines) is outside the accelerated path.
+too, on the same library, and so is TrainBasicModel (:146-190, Matern / spectral-mixture baselines: dense
+d mll / d K from the HIP step, kernel derivatives by autograd).
 
 ``TrainVoltMagpieBatch`` is an addition for the multi-series case the reference only loops over
 in Python (experiments/stocks/ForecastGenerator.py:27-41): B independent series in one batched
@@ -109,6 +110,43 @@ def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="b
                 print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
         optimizer.step()
     return vol_model, vol_lh
+
+
+def TrainBasicModel(train_x, train_y, train_iters=1000, printing=False, model_type="matern", num_mixtures=10,
+                    mean_func="loglinear"):
+    """voltron/train_utils.py:146-190 -- SURVEY 8(f) row 2: the Matern / spectral-mixture baselines on log prices."""
+    from .models import MaternGP, SMGP
+    lh = GaussianLikelihood()
+
+    if model_type == "matern":
+        model = MaternGP(train_x, train_y.log(), lh)
+    else:
+        model = SMGP(train_x, train_y.log(), lh, num_mixtures)
+
+    if mean_func == "loglinear":
+        model.mean_module = LogLinearMean(1)
+        model.mean_module.register_prior("slope_prior", gp.NormalPrior(0, 0.1), 'weights')
+        model.mean_module.initialize_from_data(train_x, train_y.log())
+
+    model.likelihood.raw_noise.data = torch.tensor([1e-5])
+    model = model.to(train_x.device)
+    model.train()
+    lh.train()
+
+    optimizer = torch.optim.Adam([{'params': model.parameters()}], lr=0.1)
+    mll = ExactMarginalLogLikelihood(lh, model)
+    print_every = 50
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        output = model(train_x)
+        loss = -mll(output, train_y.log())
+        loss.backward()
+        if printing:
+            if i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
+        optimizer.step()
+
+    return model, lh
 
 
 def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False):
