@@ -142,7 +142,7 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
 // matrix cores (see below).  Broadcast-vector element order: index (i%16)*8 + i/16, so a thread's 8
 // entries are contiguous.
 constexpr int DT = TS + 1;                                      // row stride of the tile image: strided b32 reads conflict-free
-constexpr int DIAG_LDS_FLOATS = TS * DT + 2 * TS + TS;          // 67,584 B, fits the GEMM staging area
+constexpr int DIAG_LDS_FLOATS = TS * DT;                        // 66,048 B, fits the GEMM staging area
 
 // 32x32x32 products on fp32 MFMA for the blocked inverse below.  A (and B) are 32x32 blocks of the LDS tile image
 // (row stride DT); "reg" variants take the B operand straight from an accumulator: register q of lane (c, h) holds
@@ -166,118 +166,193 @@ __device__ __forceinline__ f32x16 mm32_lds_reg(f32x16 acc, const float* __restri
     return acc;
 }
 
+// acc += (neg ? -1 : 1) * A B^T for 32x32 blocks of the LDS image: A[r][p], B[c][p] both row-major (stride DT).
+template <bool NEG>
+__device__ __forceinline__ f32x16 mm32_nt(f32x16 acc, const float* __restrict__ A, const float* __restrict__ B) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+        const int kk = 2 * s2 + lh;
+        const float av = A[l31 * DT + kk];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(NEG ? -av : av, B[l31 * DT + kk], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int src) {       // readlane is an integer builtin: bit-cast
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+// acc_i = fma(-b_i, readlane(src_i, lane_i), acc_i): SGPR broadcast + FMA pinned together in one asm block.  Left to
+// the compiler the broadcasts (independent of the FMA chains) are all hoisted to the top and spilled lane by lane
+// (v_writelane), doubling the instruction count of the pivot loop.  A VALU may read a readlane's SGPR two wait
+// states after it: three broadcasts in a row cover that for each other, shorter groups pad with s_nop.
+#define VOLT_RL "v_readlane_b32 "
+__device__ __forceinline__ void rl_fma3(float& c0, float& c1, float& c2, float b0, float b1, float b2, float s0,
+                                        float s1, float s2, int l0, int l1, int l2) {
+    float t0, t1, t2;
+    asm volatile(VOLT_RL "%3, %9, %12\n\t" VOLT_RL "%4, %10, %13\n\t" VOLT_RL "%5, %11, %14\n\t"
+                 "v_fma_f32 %0, -%6, %3, %0\n\tv_fma_f32 %1, -%7, %4, %1\n\tv_fma_f32 %2, -%8, %5, %2"
+                 : "+v"(c0), "+v"(c1), "+v"(c2), "=&s"(t0), "=&s"(t1), "=&s"(t2)
+                 : "v"(b0), "v"(b1), "v"(b2), "v"(s0), "v"(s1), "v"(s2), "i"(l0), "i"(l1), "i"(l2));
+}
+__device__ __forceinline__ void rl_fma2(float& c0, float& c1, float b0, float b1, float s0, float s1, int l0, int l1) {
+    float t0, t1;
+    asm volatile(VOLT_RL "%2, %6, %8\n\t" VOLT_RL "%3, %7, %9\n\ts_nop 0\n\t"
+                 "v_fma_f32 %0, -%4, %2, %0\n\tv_fma_f32 %1, -%5, %3, %1"
+                 : "+v"(c0), "+v"(c1), "=&s"(t0), "=&s"(t1)
+                 : "v"(b0), "v"(b1), "v"(s0), "v"(s1), "i"(l0), "i"(l1));
+}
+// A VALU result needs one wait state before v_readlane may read that VGPR (the hardware does not interlock this
+// path and the compiler cannot see into the asm blocks): tie a one-cycle nop to the value.
+__device__ __forceinline__ void settle(float& v) { asm volatile("s_nop 0" : "+v"(v)); }
+
+// the same with one accumulator: acc -= b0 rl(s0) + b1 rl(s1) + b2 rl(s2)
+__device__ __forceinline__ void rl_dot3(float& acc, float b0, float b1, float b2, float s0, float s1, float s2, int ln) {
+    float t0, t1, t2;
+    asm volatile(VOLT_RL "%1, %7, %10\n\t" VOLT_RL "%2, %8, %10\n\t" VOLT_RL "%3, %9, %10\n\t"
+                 "v_fma_f32 %0, -%4, %1, %0\n\tv_fma_f32 %0, -%5, %2, %0\n\tv_fma_f32 %0, -%6, %3, %0"
+                 : "+v"(acc), "=&s"(t0), "=&s"(t1), "=&s"(t2)
+                 : "v"(b0), "v"(b1), "v"(b2), "v"(s0), "v"(s1), "v"(s2), "i"(ln));
+}
+__device__ __forceinline__ void rl_dot2(float& acc, float b0, float b1, float s0, float s1, int ln) {
+    float t0, t1;
+    asm volatile(VOLT_RL "%1, %5, %7\n\t" VOLT_RL "%2, %6, %7\n\ts_nop 0\n\t"
+                 "v_fma_f32 %0, -%3, %1, %0\n\tv_fma_f32 %0, -%4, %2, %0"
+                 : "+v"(acc), "=&s"(t0), "=&s"(t1)
+                 : "v"(b0), "v"(b1), "v"(s0), "v"(s1), "i"(ln));
+}
+__device__ __forceinline__ void rl_fma1(float& c0, float b0, float s0, int l0) {
+    float t0;
+    asm volatile(VOLT_RL "%1, %3, %4\n\ts_nop 1\n\tv_fma_f32 %0, -%2, %1, %0"
+                 : "+v"(c0), "=&s"(t0)
+                 : "v"(b0), "v"(s0), "i"(l0));
+}
+
+// One wave factors the 32x32 diagonal sub-block kb of the image and inverts it.  Lane r (both half-waves hold the
+// same data) keeps row r in registers; per pivot the pivot and the column entries travel by v_readlane (SGPR
+// broadcast), so the 32 dependent pivots cost no barrier and no LDS round trip.  L_kk goes straight to global
+// memory; its inverse X = L_kk^-1 (column c solved in lane c, L entries again by readlane) replaces it in the
+// image: the panel solve, the trailing updates and the blocked inverse only ever need X.
+__device__ __forceinline__ void factor32(float* __restrict__ sT, int kb, float* __restrict__ Dg, int Np, int& bad) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    float* Dk = sT + (32 * kb) * DT + 32 * kb;
+    float a[32], rv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = Dk[l31 * DT + c];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        settle(a[j]);                                                       // last written inside an asm block
+        const float d = lane_bcast(a[j], j);
+        if (!(d > 0.f) && bad == 0) bad = 32 * kb + j + 1;                  // non-positive or NaN pivot (wave-uniform)
+        const float rinv = __builtin_amdgcn_rsqf(d);
+        rv[j] = rinv;
+        float l = a[j] * rinv;                                              // lane r: L[r][j]; lane j: sqrt(d)
+        settle(l);
+        a[j] = l;
+        // a[c] -= L[r][j] L[c][j] for c > j (valid where r >= c)
+        int c = j + 1;
+#pragma unroll
+        for (; c + 2 < 32; c += 3) rl_fma3(a[c], a[c + 1], a[c + 2], l, l, l, l, l, l, c, c + 1, c + 2);
+        if (c + 1 < 32) rl_fma2(a[c], a[c + 1], l, l, l, l, c, c + 1);
+        else if (c < 32) rl_fma1(a[c], l, l, c);
+    }
+    // L_kk out (zeros above the diagonal); both half-waves write the same words
+    float* Dgk = Dg + (int64_t)(32 * kb + l31) * Np + 32 * kb;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; ++c4) {
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = (4 * c4 + q <= l31) ? a[4 * c4 + q] : 0.f;
+        *reinterpret_cast<f32x4*>(Dgk + 4 * c4) = v;
+    }
+    // X = L_kk^-1: lane c solves L x = e_c;  x[r] = (delta_rc - sum_{m<r} L[r][m] x[m]) / L[r][r], with L[r][m]
+    // broadcast from lane r's register a[m]  (x[m] == 0 for m < c by construction)
+    float x[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+        float acc = (r == l31) ? 1.f : 0.f;
+        int m = 0;
+#pragma unroll
+        for (; m + 2 < r; m += 3) rl_dot3(acc, x[m], x[m + 1], x[m + 2], a[m], a[m + 1], a[m + 2], r);
+        if (m + 1 < r) rl_dot2(acc, x[m], x[m + 1], a[m], a[m + 1], r);
+        else if (m < r) rl_fma1(acc, x[m], a[m], r);
+        x[r] = acc * rv[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) Dk[r * DT + l31] = x[r];                   // X[r][c], zero above the diagonal
+}
+
 __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
                                           int Np, int k, int b, float* smem) {
-    float* sT = smem;                                    // row-major image of L (row stride DT), later of W
-    float (*bc)[TS] = reinterpret_cast<float (*)[TS]>(smem + TS * DT);
-    float* sRinv = smem + TS * DT + 2 * TS;
+    float* sT = smem;                                    // row-major image (row stride DT): A -> L / X -> W
     const int n = Np / TS;
     float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     float* W = Winv + ((int64_t)b * n + k) * TS * TS;
     const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
-
-    float a[8][8];
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc)
-            a[ii][cc] = (ii >= cc) ? D[(int64_t)(ty + 16 * ii) * Np + tx + 16 * cc] : 0.f;
-
-    int bad = 0;
-#pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-#pragma clang loop unroll(disable)
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = jb * 16 + jj;
-            float* buf = bc[j & 1];
-            if (tx == jj) {
-                f32x4 lo, hi;
-#pragma unroll
-                for (int ii = 0; ii < 4; ++ii) lo[ii] = (ii >= jb) ? a[ii][jb] : 0.f;
-#pragma unroll
-                for (int ii = 4; ii < 8; ++ii) hi[ii - 4] = (ii >= jb) ? a[ii][jb] : 0.f;
-                *reinterpret_cast<f32x4*>(buf + ty * 8) = lo;
-                *reinterpret_cast<f32x4*>(buf + ty * 8 + 4) = hi;
-            }
-            __syncthreads();
-            const float d = buf[jj * 8 + jb];
-            if (!(d > 0.f) && bad == 0) bad = j + 1;            // non-positive or NaN pivot
-            const float piv = sqrtf(d);
-            const float rinv = 1.f / piv;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(buf + ty * 8);
-            const f32x4 r1 = *reinterpret_cast<const f32x4*>(buf + ty * 8 + 4);
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(buf + tx * 8);
-            const f32x4 c1 = *reinterpret_cast<const f32x4*>(buf + tx * 8 + 4);
-            float li[8], lc[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                li[q] = r0[q] * rinv;
-                li[q + 4] = r1[q] * rinv;
-                lc[q] = c0[q] * rinv;
-                lc[q + 4] = c1[q] * rinv;
-            }
-#pragma unroll
-            for (int cc = jb; cc < 8; ++cc) {
-                const bool colact = (cc > jb) || (tx > jj);                   // c > j
-#pragma unroll
-                for (int ii = cc; ii < 8; ++ii) {
-                    const bool act = colact && ((ii > cc) || (ty >= tx));     // i >= c
-                    if (act) a[ii][cc] -= li[ii] * lc[cc];
-                }
-            }
-            if (tx == jj) {                                                   // column j is final
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-                    float v = 0.f;
-                    if (ii > jb) v = li[ii];
-                    else if (ii == jb) v = (ty > jj) ? li[ii] : ((ty == jj) ? piv : 0.f);
-                    if (ii >= jb) a[ii][jb] = v;
-                    sT[(ty + 16 * ii) * DT + j] = v;                          // column j of the image (zeros above the diagonal)
-                }
-                if (ty == jj) sRinv[j] = rinv;
-            }
-        }
-    }
-    // L out (strict upper of the tile zeroed)
-#pragma unroll
-    for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) {
-            float v = 0.f;
-            if (ii > cc) v = a[ii][cc];
-            else if (ii == cc) v = (ty >= tx) ? a[ii][cc] : 0.f;
-            D[(int64_t)(ty + 16 * ii) * Np + tx + 16 * cc] = v;
-        }
-    __syncthreads();
-
-    // ---- W = L^-1, blocked by 32 on the matrix cores ------------------------------------------------------
-    // (a) wave w inverts diagonal block w: lane c solves L_ww x = e_c by forward substitution, the entries of
-    //     L_ww arrive as LDS broadcasts (32 columns in parallel, 496 FMAs deep);
-    // (b) wave j < 3 owns block column j: W[i,j] = -X_i * sum_{m=j}^{i-1} L[i,m] W[m,j], top to bottom; the W[m,j]
-    //     it produced stay in its accumulators and are fed back as B operands from registers;
-    // (c) the off-diagonal W blocks replace the L blocks in the image, and the image goes out.
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
-    {
-        const float* Ld = sT + (wave * 32) * DT + wave * 32;
-        const float* ri = sRinv + wave * 32;
-        float x[32];
+
+    for (int e = tid; e < TS * TS / 4; e += NT) {        // lower triangle in, zeros above
+        const int r = e >> 5, c = (e & 31) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(D + (int64_t)r * Np + c);
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            float acc = (r == l31) ? 1.f : 0.f;
-#pragma unroll
-            for (int m = 0; m < r; ++m) acc -= Ld[r * DT + m] * x[m];         // x[m] == 0 for m < c by construction
-            x[r] = acc * ri[r];
-        }
-        __syncthreads();                                                      // all diagonal L blocks have been read
-        {   // both half-waves hold the same x and write the same words: an `if (lane < 32)` here makes LLVM sink
-            // the whole FMA chain below the barrier into the branch and spill the 496 loaded L entries
-            float* Xd = sT + (wave * 32) * DT + wave * 32;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) Xd[r * DT + l31] = x[r];             // X[r][c], zero above the diagonal
-        }
+        for (int q = 0; q < 4; ++q) sT[r * DT + c + q] = (c + q <= r) ? v[q] : 0.f;
     }
     __syncthreads();
+
+    // ---- L = chol(D), blocked by 32: factor32 on one wave, panel solve and trailing updates on the matrix cores.
+    // Wave 0 runs ahead: it updates the next diagonal sub-block first and factors it while waves 1..3 finish the
+    // other updates of the step.
+    int bad = 0;
+    if (wave == 0) factor32(sT, 0, D, Np, bad);
+    __syncthreads();
+#pragma unroll 1
+    for (int kb = 0; kb < 3; ++kb) {
+        // panel: L[i,kb] = A[i,kb] X_kb^T, block row i = kb+1+wave
+        if (kb + 1 + wave <= 3) {
+            const int i = kb + 1 + wave;
+            float* P = sT + (32 * i) * DT + 32 * kb;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            acc = mm32_nt<false>(acc, P, sT + (32 * kb) * DT + 32 * kb);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) P[accrow(q, lane) * DT + l31] = acc[q];
+        }
+        __syncthreads();
+        // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3: (kb+1,kb+1) on wave 0, the rest dealt to 1..3
+        int cnt = 0;
+        for (int i = kb + 1; i <= 3; ++i)
+            for (int j = kb + 1; j <= i; ++j) {
+                const bool first = (i == kb + 1);                              // then j == kb+1 too
+                const int owner = first ? 0 : 1 + (cnt++ % 3);
+                if (wave == owner) {
+                    float* C = sT + (32 * i) * DT + 32 * j;
+                    f32x16 acc;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = C[accrow(q, lane) * DT + l31];
+                    acc = mm32_nt<true>(acc, sT + (32 * i) * DT + 32 * kb, sT + (32 * j) * DT + 32 * kb);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) C[accrow(q, lane) * DT + l31] = acc[q];
+                }
+            }
+        if (wave == 0) factor32(sT, kb + 1, D, Np, bad);
+        __syncthreads();
+    }
+    // off-diagonal L blocks out (the diagonal sub-blocks went out of factor32's registers), zeros above
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        if ((r >> 5) != (c >> 5)) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (c < r) ? sT[r * DT + c + q] : 0.f;
+            *reinterpret_cast<f32x4*>(D + (int64_t)r * Np + c) = v;
+        }
+    }
+
+    // ---- W = L^-1, blocked by 32 on the matrix cores: wave j < 3 owns block column j,
+    // W[i,j] = -X_i * sum_{m=j}^{i-1} L[i,m] W[m,j], top to bottom; the W[m,j] it produced stay in its accumulators
+    // and are fed back as B operands from registers; then the W blocks replace the L blocks and the image goes out.
     f32x16 Wr[3];
     if (wave < 3) {
         const int j = wave;
@@ -321,7 +396,7 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         for (int q = 0; q < 4; ++q) w4[q] = (c + q <= r) ? sT[r * DT + c + q] : 0.f;
         *reinterpret_cast<f32x4*>(W + r * TS + c) = w4;
     }
-    if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
+    if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);          // tid 0 sits in wave 0, which tracked the pivots
 }
 
 // ----------------------------------------------------------------------------- P3
