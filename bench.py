@@ -71,13 +71,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # dry-run hooks for a 1-GPU box (tests of the world > 1 code path only): all ranks on device 0 over gloo
+    if os.environ.get("VOLT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("VOLT_BENCH_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from volt_amd import _lib, ops
     from volt_amd.synthetic import sde_batch
@@ -289,6 +296,7 @@ def main():
         line.update(extra)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()                       # rank 0 ran the roofline legs: leave together
         dist.destroy_process_group()
 
 
