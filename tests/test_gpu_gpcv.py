@@ -198,3 +198,30 @@ def test_reference_pipeline_end_to_end():
         samples = Rollouts(train_x, train_y, test_x, voltron, nsample=S)
     assert tuple(samples.shape) == (S, H) and bool(torch.isfinite(samples).all())
     assert float((samples[:, 0].mean() - train_y[-1].log().cpu()).abs()) < 0.5
+
+
+def test_batched_vol_model_equals_per_series():
+    """TrainVolModelBatch (T vol models in one batched BMGP) == T runs of TrainVolModel (train_utils.py:69-95), and the
+    batched posterior equals the per-series posteriors."""
+    import warnings
+    from volt_amd.train_utils import TrainVolModel, TrainVolModelBatch
+    n, T, H, iters = 90, 3, 5, 12
+    vols = torch.stack([torch.tensor(sde_series(n, 50 + i)[1]) for i in range(T)]).cuda()
+    tx = (torch.arange(n) / 252.).cuda()
+    test_x = (torch.arange(H) / 252.).cuda() + tx[-1] + tx[1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vb, lb = TrainVolModelBatch(tx, vols, train_iters=iters)
+        vb.eval()
+        pb = vb(test_x)
+        assert tuple(pb.mean.shape) == (T, H) and tuple(pb.covariance_matrix.shape) == (T, H, H)
+        s = pb.sample(torch.Size((7,)))
+        assert tuple(s.shape) == (7, T, H) and bool(torch.isfinite(s).all())
+        for i in range(T):
+            vi, li = TrainVolModel(tx, vols[i], train_iters=iters)
+            assert abs(float(vi.covar_module.raw_vol.detach()) - float(vb.covar_module.raw_vol[i].detach())) < 1e-4
+            assert abs(float(li.raw_noise.detach()) - float(lb.raw_noise[i].detach())) < 1e-4
+            vi.eval()
+            pi = vi(test_x)
+            assert float((pi.mean - pb.mean[i]).abs().max()) < 2e-3
+            assert float((pi.covariance_matrix - pb.covariance_matrix[i]).abs().max()) < 2e-3 * float(pi.covariance_matrix.abs().max()) + 1e-6

@@ -4,7 +4,7 @@ experiments/stocks/GenerateMultiMeanPreds.py:63-137, with the reference's per-ti
 
     window -> LearnGPCV for all tickers at once (batched variational fit, HIP ELBO step)          (:95-96)
            -> TrainVoltMagpieBatch (all tickers in one batched model, HIP MLL step)               (:99-103)
-           -> TrainVolModel + posterior sample of the vol forecaster per ticker (BM-GP, HIP factorisation)
+           -> TrainVolModelBatch + posterior samples of the vol forecasters (batched BM-GP, HIP factorisation)
            -> rollout engine for all tickers x paths in one launch                                (:105-107)
            -> torch.save(samples[S,H], "saved-outputs/<ticker>/<model>_<date>.pt")                (:128)
 
@@ -21,7 +21,7 @@ import torch
 from . import rollout_engine
 from .distributed import shard_range
 from .means import EWMAMean, DEWMAMean, TEWMAMean
-from .train_utils import LearnGPCV, TrainVoltMagpieBatch, TrainVolModel
+from .train_utils import LearnGPCV, TrainVoltMagpieBatch, TrainVolModelBatch
 
 _MODES = {"ewma": 0, "dewma": 1, "tewma": 2}
 
@@ -71,12 +71,11 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
         if mean != "ewma":
             cls = {"dewma": DEWMAMean, "tewma": TEWMAMean}[mean]
             model.mean_module = cls(train_x, train_y[:, 1:].log(), k)
-        # vol forecaster per ticker (BM-GP over log-vol, :102) and its posterior sample (rollout_utils.py:66)
-        pred_vol = torch.empty(B, nsample, forecast_horizon, device=dev)
-        for b in range(B):
-            vmod, vlh = TrainVolModel(train_x, vol[b], train_iters=vol_iters)
-            vmod.eval()
-            pred_vol[b] = vmod(test_x).sample(torch.Size((nsample,))).exp()
+        # vol forecasters (BM-GP over log-vol, :102), all tickers in one batched model, and their posterior samples
+        # (rollout_utils.py:66)
+        vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters)
+        vmod.eval()
+        pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous()   # [B,S,H]
         z = torch.randn(B, nsample, forecast_horizon, device=dev, generator=generator)
         samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
                                                       _MODES[mean], k)

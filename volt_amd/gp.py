@@ -413,7 +413,7 @@ class ExactMarginalLogLikelihood(Module):
         scale = None
         if isinstance(lazy, _ScaledDense):
             scale = lazy.scale
-            K = lazy.scale.detach() * lazy.base
+            K = lazy._product(lazy.scale.detach())
         else:
             K = function_dist.covariance_matrix
         batched = mean.ndim > 1

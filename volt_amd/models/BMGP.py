@@ -5,6 +5,9 @@ SURVEY 8(f) row 1: it supplies ``pred_vol`` at voltron/rollout_utils.py:66 throu
 call -> exact-GP posterior at the test points, computed with the same HIP Cholesky / triangular
 inverse as the data model (K_s^-1 = Y Y^T, Y = L^-T) plus two plain library matmuls.
 The botorch-based MultitaskBMGP (:30-56) is out of scope.
+
+Addition: ``train_y`` [T,N] builds T independent vol models over shared inputs in one object (batched kernel
+parameter, noise and posterior) -- what the batched forecast driver trains instead of looping over tickers.
 """
 import torch
 
@@ -17,10 +20,11 @@ from ..kernels.FBMKernel import FBMKernel
 class BMGP(ExactGP):
     def __init__(self, train_x, train_y, likelihood, kernel="bm"):
         super().__init__(train_x, train_y, likelihood)
+        kw = {"batch_shape": train_y.shape[:-1]} if train_y.ndim > 1 else {}
         if kernel == "bm":
-            self.covar_module = BMKernel().to(train_x.device)
+            self.covar_module = BMKernel(**kw).to(train_x.device)
         elif kernel == "fbm":
-            self.covar_module = FBMKernel().to(train_x.device)          # BMGP.py:15-16; dense d mll / d K path
+            self.covar_module = FBMKernel(**kw).to(train_x.device)      # BMGP.py:15-16; dense d mll / d K path
         self.scaling = (train_x[1] - train_x[0])
 
     def mean_module(self, x):
@@ -30,6 +34,8 @@ class BMGP(ExactGP):
         return MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
     def posterior_call(self, x):
+        if self.train_targets.ndim > 1:
+            return self._posterior_batched(x)
         with torch.no_grad():
             xt = self.train_inputs[0]
             y = self.train_targets
@@ -44,4 +50,23 @@ class BMGP(ExactGP):
             r = (y - self.mean_module(xt)).to(torch.float32)
             mean = self.mean_module(x) + G @ (Y.t() @ r)
             cov = self.covar_module.forward(x, x) - G @ G.t()
+            return MultivariateNormal(mean, cov)
+
+    def _posterior_batched(self, x):
+        """T independent posteriors over shared inputs: MultivariateNormal(mean [T,H], cov [T,H,H])."""
+        with torch.no_grad():
+            xt = self.train_inputs[0]
+            y = self.train_targets                                        # [T,N]
+            T, n = y.shape
+            from ..gp import _dense
+            Ktt = _dense(self.covar_module(xt, xt)).reshape(T, n, n)
+            noise = self.likelihood.noise.reshape(-1).expand(T)
+            A = Ktt + noise.reshape(T, 1, 1) * torch.eye(n, device=xt.device)
+            f, _ = _safe_factor(A)
+            Y = ops.trtri(f)                                              # [T,N,N]  L^-T
+            Kst = _dense(self.covar_module(x, xt)).reshape(T, x.shape[0], n)
+            G = Kst @ Y
+            r = (y - self.mean_module(xt)).to(torch.float32)
+            mean = self.mean_module(x) + (G @ (Y.mT @ r.unsqueeze(-1))).squeeze(-1)
+            cov = _dense(self.covar_module(x, x)).reshape(T, x.shape[0], x.shape[0]) - G @ G.mT
             return MultivariateNormal(mean, cov)

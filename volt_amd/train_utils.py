@@ -112,6 +112,29 @@ def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="b
     return vol_model, vol_lh
 
 
+def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kernel="bm"):
+    """TrainVolModel for T series at once: vol_path [T,N] -> one batched BMGP (per-series kernel parameter and noise).
+    The series are independent, so the summed loss gives every series exactly the gradient its own TrainVolModel
+    loop would (Adam is elementwise)."""
+    from .models import BMGP
+    T = vol_path.shape[0]
+    vol_lh = GaussianLikelihood(batch_shape=torch.Size([T])).to(train_x.device)
+    vol_model = BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device)
+    optimizer = torch.optim.Adam([{'params': vol_model.parameters()}], lr=0.01)
+    mll = ExactMarginalLogLikelihood(vol_lh, vol_model)
+    print_every = 50
+    for i in range(train_iters):
+        optimizer.zero_grad()
+        output = vol_model(train_x)
+        loss = -mll(output, vol_path.log()).sum()
+        loss.backward()
+        if printing:
+            if i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item() / T))
+        optimizer.step()
+    return vol_model, vol_lh
+
+
 def TrainBasicModel(train_x, train_y, train_iters=1000, printing=False, model_type="matern", num_mixtures=10,
                     mean_func="loglinear"):
     """voltron/train_utils.py:146-190 -- SURVEY 8(f) row 2: the Matern / spectral-mixture baselines on log prices."""
