@@ -26,6 +26,36 @@ from torch import nn
 from . import ops
 
 
+def same_values(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """``torch.equal(a, b)`` without its device synchronisation when the answer is known from the host side: two views
+    of the same memory with the same layout hold the same values.  The reference's loops pass the stored training
+    inputs back into ``model(train_x)`` on every iteration (train_utils.py:246), where each ``torch.equal`` on GPU
+    tensors (VoltMagpie.py:122, EWMA.py:49) costs a full host-device round trip."""
+    if (a.shape == b.shape and a.dtype == b.dtype and a.device == b.device and a.stride() == b.stride()
+            and a.data_ptr() == b.data_ptr()):
+        return True
+    return a.shape == b.shape and torch.equal(a, b)
+
+
+class EqualMemo:
+    """Remembers that one particular tensor OBJECT compared equal to a stored tensor; valid while both version counters
+    (bumped by any in-place write through any view) are unchanged.  Keyed on identity through a weak reference, never
+    on addresses, so a new tensor that happens to reuse freed memory is always compared for real."""
+
+    def __init__(self):
+        self._ref, self._ver = None, None
+
+    def equal(self, x: torch.Tensor, stored: torch.Tensor, compare) -> bool:
+        held = self._ref() if self._ref is not None else None
+        if held is x and self._ver == (x._version, stored._version):
+            return True
+        ok = bool(compare())
+        if ok:
+            import weakref
+            self._ref, self._ver = weakref.ref(x), (x._version, stored._version)
+        return ok
+
+
 class NotPSDError(RuntimeError):
     pass
 

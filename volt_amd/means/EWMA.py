@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..gp import Mean
+from ..gp import Mean, same_values
 
 
 def EWMA(y, k):
@@ -29,7 +29,7 @@ class _MAMean(Mean):
         dev = self.train_x.device
         if x.numel() == 1:
             return ma[..., -1].unsqueeze(0).to(dev)
-        elif torch.equal(x.squeeze(), self.train_x.squeeze()):
+        elif same_values(x.squeeze(), self.train_x.squeeze()):
             return ma[..., :-1].to(dev)
         else:
             return ma.to(dev)
@@ -45,7 +45,7 @@ class HEWMAMean(_MAMean):
         wma_k = EWMA(self.train_y, self.k)
         wma_k2 = EWMA(self.train_y, int(self.k / 2))
         hma = EWMA(2 * wma_k2[:-1] - wma_k[:-1], int(np.sqrt(self.k)))
-        if torch.equal(x.squeeze(), self.train_x.squeeze()):
+        if same_values(x.squeeze(), self.train_x.squeeze()):
             return hma[:-1].to(self.train_x.device)
         return hma.to(self.train_x.device)
 

@@ -12,7 +12,7 @@ Deliberate deviations, each a reference defect (SURVEY 7 hard part 5):
 """
 import torch
 
-from ..gp import ConstantMean, ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal
+from ..gp import ConstantMean, ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal, same_values
 from ..kernels import VolatilityKernel
 from ..means import EWMAMean, DEWMAMean, TEWMAMean
 from ..rollout_utils import Rollouts
@@ -80,7 +80,7 @@ class Volt(ExactGP):
 
     def forward(self, x):
         mean_x = self.mean_module(x)
-        if torch.equal(x, self.train_inputs[0]):
+        if same_values(x, self.train_inputs[0]):                  # torch.equal without the device sync when aliased
             covar_x = self.train_cov
         else:
             covar_x = self.covar_module(x, self.log_vol_path.exp())

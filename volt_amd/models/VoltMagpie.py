@@ -7,7 +7,7 @@ Batched layout as documented there: train_x [N], train_y [T,N], vol_path [T,N].
 """
 import torch
 
-from ..gp import ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal
+from ..gp import ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal, same_values
 from ..kernels import VolatilityKernel
 from ..means import EWMAMean, DEWMAMean, TEWMAMean            # noqa: F401  (re-exported like the reference)
 from .BMGP import BMGP
@@ -85,7 +85,7 @@ class VoltMagpie(ExactGP):
 
     def forward(self, x):
         mean_x = self.mean_module(x)
-        if torch.equal(x, self.train_inputs[0]):
+        if same_values(x, self.train_inputs[0]):                  # torch.equal without the device sync when aliased
             covar_x = self.train_cov
         else:
             covar_x = self.covar_module(x, self.log_vol_path.exp())

@@ -2,7 +2,7 @@
 notebook's ``TrainDataModel`` swaps in a LogLinearMean (train_utils.py:102)."""
 import torch
 
-from ..gp import ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, LinearMean, MultivariateNormal
+from ..gp import ExactGP, ExactMarginalLogLikelihood, GaussianLikelihood, LinearMean, MultivariateNormal, same_values
 from ..kernels import VolatilityKernel
 from .BMGP import BMGP
 
@@ -77,7 +77,7 @@ class VoltronGP(ExactGP):
 
     def forward(self, x):
         mean_x = self.mean_module(x)
-        if torch.equal(x, self.train_inputs[0]):
+        if same_values(x, self.train_inputs[0]):                  # torch.equal without the device sync when aliased
             covar_x = self.train_cov
         else:
             covar_x = self.covar_module(x, self.log_vol_path.exp())

@@ -8,7 +8,7 @@ factorisations of ``initialize_variational_parameters`` -- runs through the HIP 
 import torch
 
 from .. import ops
-from ..gp import ConstantMean, Module, MultivariateNormal, _dense, _safe_factor
+from ..gp import ConstantMean, EqualMemo, Module, MultivariateNormal, _dense, _safe_factor
 from ..likelihoods import VolatilityGaussianLikelihood  # noqa: F401  (re-exported like the reference's module namespace)
 from ..variational import CholeskyVariationalDistribution, UnwhitenedVariationalStrategy, VariationalLatent
 
@@ -36,6 +36,7 @@ class SingleTaskVariationalGP(Module):
         self.train_inputs = [train_inputs] if train_inputs is not None else [init_points]
         self.train_targets = train_targets if train_targets is not None else init_targets
         self.condition_into_exact = True
+        object.__setattr__(self, "_eq_memo", EqualMemo())
         self.to(init_points.device)
 
     @property
@@ -47,10 +48,12 @@ class SingleTaskVariationalGP(Module):
         return MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
     def __call__(self, x):
+        arg = x
         if x.ndim == 1:
             x = x.unsqueeze(-1)
         Z = self.variational_strategy.inducing_points
-        if x.shape == Z.shape and torch.equal(x, Z):
+        # LearnGPCV passes the same train_x object on every iteration (train_utils.py:51): compare once, not 1000 times
+        if x.shape == Z.shape and self._eq_memo.equal(arg, Z, lambda: torch.equal(x, Z)):
             return VariationalLatent(self)
         raise NotImplementedError("SingleTaskVariationalGP(x) away from the inducing points is outside the accelerated "
                                   "path: LearnGPCV only evaluates the model at train_x (train_utils.py:51,60)")

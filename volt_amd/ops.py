@@ -58,11 +58,19 @@ def fill(V: torch.Tensor) -> torch.Tensor:
     return K.reshape(*V.shape[:-1], n, n)
 
 
+_TAPS = {}
+
+
 def ewma_weights(k: int, device) -> torch.Tensor:
-    """The reference's taps, computed with the same torch expression (voltron/means/EWMA.py:21-24)."""
-    alpha = 2. / (k + 1)
-    wghts = alpha * (1 - alpha) ** (torch.arange(k - 1, -1, -1))
-    return (wghts / wghts.sum()).to(torch.float32).to(device)
+    """The reference's taps, computed with the same torch expression (voltron/means/EWMA.py:21-24); cached per
+    (k, device) -- the reference rebuilds them (and a Conv1d) on every call, here that would be a host-to-device
+    copy per training iteration."""
+    key = (int(k), str(device))
+    if key not in _TAPS:
+        alpha = 2. / (k + 1)
+        wghts = alpha * (1 - alpha) ** (torch.arange(k - 1, -1, -1))
+        _TAPS[key] = (wghts / wghts.sum()).to(torch.float32).to(device)
+    return _TAPS[key]
 
 
 def ewma(y: torch.Tensor, k: int) -> torch.Tensor:
