@@ -137,3 +137,102 @@ def test_gpcv_stage_refuses_cpu_tensors_and_validates_arguments():
     from volt_amd.train_utils import TrainBasicModel
     with pytest.raises(_lib.VoltHipError):
         TrainBasicModel(x, torch.rand(50) + 1.0, train_iters=1)
+
+
+def test_reference_call_sites_resolve_through_the_aliases():
+    """example.ipynb cells 0 and 8 and train_utils.py reach everything by name: voltron.* and gpytorch.*."""
+    import importlib
+    import sys
+    import volt_amd
+    had = {k: sys.modules.get(k) for k in list(sys.modules) if k == "gpytorch" or k.startswith("gpytorch.")}
+    try:
+        volt_amd.install_as_voltron()
+        import gpytorch
+        from voltron.likelihoods import VolatilityGaussianLikelihood
+        from voltron.models import SingleTaskVariationalGP, VoltronGP, VoltMagpie, BMGP, MaternGP, SMGP      # noqa: F401
+        from voltron.kernels import BMKernel, VolatilityKernel, FBMKernel                                  # noqa: F401
+        from voltron.train_utils import TrainVolModel, TrainVoltMagpieModel, LearnGPCV, TrainDataModel, TrainBasicModel  # noqa: F401
+        from voltron.rollout_utils import Rollouts, GeneratePrediction, nonvol_rollouts                     # noqa: F401
+        x = torch.arange(12.) / 252
+        lik = VolatilityGaussianLikelihood(param="exp")
+        model = SingleTaskVariationalGP(init_points=x.view(-1, 1), likelihood=lik, use_piv_chol_init=False,
+                                        mean_module=gpytorch.means.ConstantMean(), covar_module=BMKernel(),
+                                        learn_inducing_locations=False, use_whitened_var_strat=False)
+        mll = gpytorch.mlls.VariationalELBO(lik, model, 12, combine_terms=True)
+        with gpytorch.settings.num_gauss_hermite_locs(75):
+            from volt_amd.variational import num_gauss_hermite_locs
+            assert num_gauss_hermite_locs.value() == 75
+        assert num_gauss_hermite_locs.value() == 20
+        assert [n for n, _ in model.named_parameters()][:2] == [
+            "variational_strategy._variational_distribution.variational_mean",
+            "variational_strategy._variational_distribution.chol_variational_covar"]
+        with gpytorch.settings.max_cholesky_size(2000):                     # GPGenerator.py:62
+            pass
+        importlib.import_module("gpytorch.utils.cholesky").psd_safe_cholesky
+        assert isinstance(mll, gpytorch.mlls.VariationalELBO)
+        from gpytorch.kernels import ScaleKernel, MaternKernel              # BasicWind.py:16
+        assert ScaleKernel(MaternKernel()).outputscale.item() > 0
+    finally:
+        for k in [k for k in sys.modules if k == "gpytorch" or k.startswith("gpytorch.")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in had.items() if v is not None})
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/voltron/train_utils.py"), reason="reference tree not mounted")
+def test_reference_train_utils_imports_against_our_namespaces():
+    """The reference's own voltron/train_utils.py and rollout_utils.py, loaded from /root/reference (never copied),
+    import cleanly when ``voltron`` and ``gpytorch`` resolve to this package: every name their module-level imports
+    and function bodies look up exists here with the reference's spelling."""
+    import importlib.util
+    import sys
+    import volt_amd
+    sys.dont_write_bytecode = True
+    had = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("gpytorch", "voltron")}
+    try:
+        volt_amd.install_as_voltron()
+        for rel in ("train_utils.py", "rollout_utils.py"):
+            spec = importlib.util.spec_from_file_location("ref_" + rel[:-3], "/root/reference/voltron/" + rel)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            names = set()
+            import ast
+            tree = ast.parse(open("/root/reference/voltron/" + rel).read())
+            for node in ast.walk(tree):
+                if (isinstance(node, ast.Attribute) and isinstance(node.value, ast.Attribute)
+                        and isinstance(node.value.value, ast.Name) and node.value.value.id == "gpytorch"):
+                    names.add((node.value.attr, node.attr))
+            import gpytorch
+            for sub, attr in sorted(names):
+                assert hasattr(getattr(gpytorch, sub), attr), f"gpytorch.{sub}.{attr} used by {rel} is missing"
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("gpytorch", "voltron")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in had.items() if v is not None})
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/voltron/train_utils.py"), reason="reference tree not mounted")
+def test_public_signatures_match_the_reference():
+    """Same function names, argument names, order and defaults as voltron/train_utils.py and rollout_utils.py
+    (keyword-only extras such as ``z=`` / ``pred_vol=`` are additions)."""
+    import ast
+    import inspect
+    from volt_amd import rollout_utils, train_utils
+
+    def ref_sigs(path):
+        out = {}
+        for node in ast.parse(open(path).read()).body:
+            if isinstance(node, ast.FunctionDef):
+                a = node.args
+                names = [x.arg for x in a.args]
+                defaults = [ast.literal_eval(d) if isinstance(d, (ast.Constant, ast.UnaryOp)) else "?" for d in a.defaults]
+                out[node.name] = (names, defaults)
+        return out
+
+    for mod, rel in ((train_utils, "train_utils.py"), (rollout_utils, "rollout_utils.py")):
+        for name, (names, defaults) in ref_sigs("/root/reference/voltron/" + rel).items():
+            assert hasattr(mod, name), f"{rel}:{name} has no counterpart"
+            sig = inspect.signature(getattr(mod, name))
+            pos = [p for p in sig.parameters.values() if p.kind == p.POSITIONAL_OR_KEYWORD]
+            assert [p.name for p in pos][:len(names)] == names, (name, [p.name for p in pos], names)
+            ours = [p.default for p in pos[:len(names)] if p.default is not inspect.Parameter.empty]
+            assert ours == defaults, (name, ours, defaults)

@@ -18,9 +18,14 @@ from .rollout_utils import Rollouts, GeneratePrediction    # noqa: F401
 from .train_utils import LearnGPCV                        # noqa: F401
 
 
-def install_as_voltron():
-    """Register this package (and its hot-path submodules) under the name ``voltron``."""
+def install_as_voltron(gpytorch_standin=True):
+    """Register this package (and its hot-path submodules) under the name ``voltron``; with ``gpytorch_standin`` also
+    offer the stand-ins of volt_amd/gp.py as ``gpytorch`` when no real gpytorch is importable, so that call sites such
+    as ``gpytorch.mlls.VariationalELBO`` (example.ipynb cell 8) resolve."""
     import sys
+    if gpytorch_standin:
+        from . import gpytorch_compat
+        gpytorch_compat.install()
     from . import kernels, likelihoods, means, models, rollout_utils, train_utils
     me = sys.modules[__name__]
     sys.modules.setdefault("voltron", me)
