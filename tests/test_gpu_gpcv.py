@@ -225,3 +225,30 @@ def test_batched_vol_model_equals_per_series():
             pi = vi(test_x)
             assert float((pi.mean - pb.mean[i]).abs().max()) < 2e-3
             assert float((pi.covariance_matrix - pb.covariance_matrix[i]).abs().max()) < 2e-3 * float(pi.covariance_matrix.abs().max()) + 1e-6
+
+
+def test_expected_log_prob_agrees_with_the_fused_step():
+    """VolatilityGaussianLikelihood.expected_log_prob (volatility_likelihood.py:52-57; torch, per point) sums to the
+    likelihood term the HIP step computes."""
+    import warnings
+    from volt_amd import ops
+    from volt_amd.train_utils import FitGPCV
+    from volt_amd.variational import num_gauss_hermite_locs
+    n = 140
+    F, _ = _prices(n, 77)
+    x = (torch.arange(n, dtype=torch.float32) / 252).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, lik, _ = FitGPCV(x, F.cuda(), train_iters=3)
+    yy = GO.scaled_returns(x.cpu(), F).cuda()
+    latent = model(x)
+    with num_gauss_hermite_locs(75), torch.no_grad():
+        per_point = lik.expected_log_prob(yy, latent)
+    assert tuple(per_point.shape) == (n,)
+    d = model.variational_strategy._variational_distribution
+    gh_x, gh_w = GO.gauss_hermite(75)
+    K = GO.bm_cov(x.cpu().double(), torch.tensor(0.2, dtype=torch.float64)).float().cuda().unsqueeze(0)
+    ws = ops.gpcv_step(K, d.variational_mean.detach().reshape(1, n), d.variational_mean.detach().reshape(1, n),
+                       d.chol_variational_covar.detach().reshape(1, n, n), yy.reshape(1, n), gh_x.cuda(),
+                       (gh_w / math.sqrt(math.pi)).cuda())
+    assert abs(float(per_point.sum()) - float(ws.out[0, 0])) < 2e-4 * abs(float(ws.out[0, 0]))

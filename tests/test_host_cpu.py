@@ -236,3 +236,35 @@ def test_public_signatures_match_the_reference():
             assert [p.name for p in pos][:len(names)] == names, (name, [p.name for p in pos], names)
             ours = [p.default for p in pos[:len(names)] if p.default is not inspect.Parameter.empty]
             assert ours == defaults, (name, ours, defaults)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/voltron/models/VoltMagpie.py"), reason="reference tree not mounted")
+def test_class_surfaces_match_the_reference():
+    """Every class of the reference's path files exists here under the same module path, with the same constructor
+    argument names / order and at least the same public methods ("same names, argument order, defaults")."""
+    import ast
+    import importlib
+    import inspect
+    files = {"models/VoltMagpie.py": ["VoltMagpie"], "models/VoltronGP.py": ["VoltronGP"], "models/Volt.py": ["Volt"],
+             "models/BMGP.py": ["BMGP"], "models/BasicGPModels.py": ["MaternGP", "SMGP"],
+             "models/single_task_variational_gp.py": ["SingleTaskVariationalGP"],
+             "means/EWMA.py": ["EWMAMean", "DEWMAMean", "TEWMAMean", "MeanRevertingEMAMean"],
+             "means/loglinear_mean.py": ["LogLinearMean"], "kernels/VolKernel.py": ["VolatilityKernel"],
+             "kernels/BMKernel.py": ["BMKernel"], "kernels/FBMKernel.py": ["FBMKernel"],
+             "likelihoods/volatility_likelihood.py": ["VolatilityGaussianLikelihood"]}
+    for rel, classes in files.items():
+        tree = ast.parse(open("/root/reference/voltron/" + rel).read())
+        ours = importlib.import_module("volt_amd." + rel[:-3].replace("/", "."))
+        for node in tree.body:
+            if not (isinstance(node, ast.ClassDef) and node.name in classes):
+                continue
+            cls = getattr(ours, node.name)
+            for fn in [f for f in node.body if isinstance(f, ast.FunctionDef)]:
+                if fn.name.startswith("_") and fn.name != "__init__":
+                    continue
+                assert hasattr(cls, fn.name), f"{rel}:{node.name}.{fn.name} missing"
+                if fn.name == "__init__":
+                    want = [a.arg for a in fn.args.args][1:]
+                    got = [p.name for p in inspect.signature(cls.__init__).parameters.values()
+                           if p.kind == p.POSITIONAL_OR_KEYWORD][1:]
+                    assert got[:len(want)] == want, (rel, node.name, got, want)

@@ -46,6 +46,19 @@ class VolatilityGaussianLikelihood(Module):
             summed_transform = function_samples.exp()
         return Normal(torch.zeros_like(summed_transform), summed_transform.clamp(min=self.MIN_SCALE))
 
+    def expected_log_prob(self, target, input, *params, **kwargs):
+        """volatility_likelihood.py:52-57 (gpytorch ``_OneDimensionalLikelihood.expected_log_prob``): E_{q(f_i)} log p(y_i|f_i)
+        per point by Gauss-Hermite quadrature with ``num_gauss_hermite_locs`` nodes.  O(N Q) elementwise, kept in
+        torch for direct callers; LearnGPCV's loop gets the same numbers (and their gradients) from the fused HIP step."""
+        import math
+        from ..variational import _gauss_hermite, num_gauss_hermite_locs
+        gx, gw = _gauss_hermite(num_gauss_hermite_locs.value(), target.device)
+        mean, var = input.mean, input.variance
+        locs = torch.sqrt(2.0 * var).unsqueeze(-1) * gx + mean.unsqueeze(-1)
+        logp = self.forward(locs.movedim(-1, 0)).log_prob(target)               # [Q, ..., N]
+        res = (logp * gw.reshape(-1, *([1] * (logp.ndim - 1)))).sum(0)
+        return res
+
     def marginal(self, function_dist, *args, **kwargs):
         """gpytorch Likelihood.marginal: push ``num_likelihood_samples`` joint draws of f through ``forward``."""
         samples = function_dist.rsample(torch.Size([NUM_LIKELIHOOD_SAMPLES]))
