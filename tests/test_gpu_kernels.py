@@ -191,6 +191,44 @@ def test_mll_step_full_size_properties(ops):
     assert ((back.squeeze(-1) - r.double()).norm() / r.double().norm()).item() < 1e-3
 
 
+@pytest.mark.parametrize("B,n", [(64, 2048), (64, 4096)])
+def test_mll_step_baseline_batches_properties(ops, B, n):
+    """BASELINE configs 3 (64 x 2048) and the metric's 64 x 4096 at FULL batch, through the 4-stream schedule the bench
+    times: size-independent properties per series, checked on the device in fp64 --
+    (K + s2 I) alpha = r;  quad = r'alpha;  the analytic log-det of this kernel's factor
+    (K = C diag(d) C' => chol(K + 0 I)[i,i] = sqrt(d_i)) is covered at small N, here
+    logdet(K + s2 I) must lie between N log s2 and N log(s2 + max K);  tr(K_s^-1) in (0, N/s2];
+    every series of the batch is processed (no group of the 4-stream split dropped): outputs differ per series and
+    a permutation of the batch permutes the outputs."""
+    x, F, vol = sde_batch(B, n)
+    Kd = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    s2v = torch.linspace(0.3, 0.9, B, device="cuda")
+    y = torch.log(dev(F[:, 1:]))
+    r = (y - y.mean(-1, keepdim=True)).float()
+    o, a, info = ops.mll_step(Kd, r, s2v, want_grad=True)
+    o, a = o.clone(), a.clone()
+    assert int(info.abs().sum()) == 0 and bool(torch.isfinite(o).all())
+    rd, ad = r.double(), a.double()
+    back = torch.empty_like(rd)
+    for b0 in range(0, B, 8):                                   # fp64 K v in slices: 8 x N^2 doubles at a time
+        sl = slice(b0, b0 + 8)
+        back[sl] = (Kd[sl].double() @ ad[sl].unsqueeze(-1)).squeeze(-1) + s2v[sl].double().unsqueeze(-1) * ad[sl]
+    rel = (back - rd).norm(dim=-1) / rd.norm(dim=-1)
+    assert float(rel.max()) < 2e-3, float(rel.max())
+    quad = (rd * ad).sum(-1)
+    assert float(((o[:, 2].double() - quad).abs() / quad.abs()).max()) < 1e-4
+    kmax = Kd.amax(dim=(-1, -2)).double()
+    ld = o[:, 3].double()
+    assert bool((ld > n * torch.log(s2v.double())).all()) and bool((ld < n * torch.log(s2v.double() + n * kmax)).all())
+    tr = o[:, 4].double()
+    assert bool((tr > 0).all()) and bool((tr <= n / s2v.double() * (1 + 1e-5)).all())
+    assert torch.unique(o[:, 0]).numel() == B
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    o2, a2, _ = ops.mll_step(Kd[perm].contiguous(), r[perm].contiguous(), s2v[perm].contiguous(), want_grad=True)
+    assert torch.allclose(o2[:, :6], o[perm][:, :6], rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a2, a[perm], rtol=1e-4, atol=1e-6)
+
+
 def test_ops_refuse_cpu_tensors(ops):
     from volt_amd._lib import VoltHipError
     with pytest.raises(VoltHipError):
