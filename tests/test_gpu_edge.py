@@ -216,3 +216,30 @@ def test_long_series_cumtrapz_needs_large_lds(ops):
     vol = np.random.RandomState(0).uniform(0.1, 0.4, (2, n)).astype(np.float32)
     V = ops.cumtrapz(dev(vol), dev(x), square=True)
     assert np.array_equal(V.cpu().numpy(), vo.cumtrapz(vol * vol, x))
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_randomised_sizes_batches_and_noise_against_oracle(ops, seed):
+    """Odd sizes (ragged padding inside the last 128-block and inside its 32-sub-blocks), batches that do and do not
+    divide into stream groups / XCDs, noise from 2.5e-3 to 2: fused MLL step vs the fp64 oracle.
+    (scripts/fuzz_mll.py is the long form: 140 cases, worst MLL 3e-7, d/dsigma2 2e-6, alpha 1e-5.)"""
+    rng = np.random.RandomState(seed)
+    for _ in range(14):
+        n = int(rng.choice([2, 3, 5, 31, 33, 64, 100, 127, 129, 160, 255, 257, 300, 383, 385, 500]))
+        B = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 32, 33]))
+        if n >= 300:
+            B = min(B, 9)
+        x, F, vol = sde_batch(B, n, seed=int(rng.randint(1, 10000)))
+        raw = rng.uniform(-6, 2, size=B)
+        K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+        y = np.log(F[:, 1:])
+        mean = y.mean(-1, keepdims=True) + 0 * y
+        s2 = torch.tensor([vo.noise_from_raw(r) for r in raw], dtype=torch.float32).cuda()
+        o, a, info = ops.mll_step(K, torch.tensor(y - mean).float().cuda(), s2, want_grad=True)
+        assert int(info.abs().sum()) == 0, (n, B)
+        o, a = o.cpu().double().numpy(), a.cpu().double().numpy()
+        ref = vo.mll_and_grads(K.cpu().double().numpy(), y, mean, raw)
+        dsig = 0.5 * (ref["aa"] - ref["trinv"]) / n
+        assert np.all(np.abs(o[:, 0] - ref["mll"]) <= 2e-5 * np.maximum(1.0, np.abs(ref["mll"]))), (n, B)
+        assert np.all(np.abs(o[:, 1] - dsig) <= 1e-3 * np.maximum(np.abs(dsig), 1e-4 * ref["trinv"] / n)), (n, B)
+        assert np.all(np.abs(a - ref["alpha"]).max(-1) <= 1e-4 * np.abs(ref["alpha"]).max(-1)), (n, B)
