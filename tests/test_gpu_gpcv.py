@@ -26,7 +26,8 @@ def _problem(n, seed, dtype=torch.float64):
     return x, yy, m, Lq, c0.reshape(1)
 
 
-@pytest.mark.parametrize("n,B,kernel", [(200, 1, "bm"), (399, 3, "bm"), (512, 2, "bm"), (300, 2, "fbm")])
+@pytest.mark.parametrize("n,B,kernel", [(200, 1, "bm"), (399, 3, "bm"), (512, 2, "bm"), (300, 2, "fbm"),
+                                        (33, 1, "bm"), (129, 2, "bm"), (257, 1, "fbm"), (640, 9, "bm")])
 def test_gpcv_step_matches_oracle(n, B, kernel):
     from volt_amd import ops
     dev = "cuda:0"
