@@ -721,7 +721,7 @@ __device__ __forceinline__ void trtri_body(const float* __restrict__ A, const fl
 // ----------------------------------------------------------------------------- fused step kernel
 // One launch per block column k carries everything that is ready at that point:
 //   workgroups [0, (n-k)B)          P1 tiles of column k; the workgroup that owns the diagonal tile (t = 0)
-//                                   goes straight on to factor and invert it (P2) -- the 90 us latency chain
+//                                   goes straight on to factor and invert it (P2) -- the 46 us latency chain
 //                                   runs next to the other tiles instead of after them
 //   workgroups [(n-k)B, (n-k)B+kB)  tiles of trtri row k-1 (independent of column k)
 // so every launch has n*B tiles of comparable length, longest first (diagonal, P1 tiles with K = 128k,
