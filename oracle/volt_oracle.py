@@ -375,7 +375,7 @@ def gp_posterior(kfun, noise, xt, y, mean_t, xs, mean_s):
     return mean, cov
 
 
-def nonvol_rollouts(train_x, train_y, test_x, kfun, noise, z, mean_name="ewma", k=20):
+def nonvol_rollouts(train_x, train_y, test_x, kfun, noise, z, mean_name="ewma", k=20, mean_theta=0.5):
     """rollout_utils.py:95-115 with the normal draws ``z`` [S,H] passed in.  train_x [N], train_y [N] RAW prices
     (the reference stacks ``train_y.log()`` whole, :100), kfun(a, b) the model's covariance, noise the likelihood's.
     Step 0 samples the un-stacked model S times (:99); every later step re-conditions the S stacked series (:102-114)
@@ -386,10 +386,16 @@ def nonvol_rollouts(train_x, train_y, test_x, kfun, noise, z, mean_name="ewma", 
     test_x = np.asarray(test_x, dtype=f32)
     z = np.asarray(z, dtype=np.float64)
     S, H = z.shape
+    mr_latent = log_y.mean(dtype=f32)                         # MeanRevertingEMAMean fixes it at construction (EWMA.py:124)
+
     def mfull(y):                                             # the means' third branch: train points + next point
         e1 = ewma(y, k)
         if mean_name == "ewma":
             return e1
+        if mean_name == "meanrevert":                         # EWMA.py:126-128
+            e = e1.copy()
+            e[..., 1:] -= f32(mean_theta) * (e1[..., :-1] - mr_latent)
+            return e
         e2 = ewma(e1, k)[..., :-1]                            # EWMA.py:83-84
         if mean_name == "dewma":
             return 2 * e1 - e2

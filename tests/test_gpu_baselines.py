@@ -184,3 +184,21 @@ def test_train_basic_model_runs_the_reference_loop():
         ms, ls_ = TrainBasicModel(tx, ty, train_iters=5, model_type="sm", num_mixtures=4, mean_func="constant")
         assert math.isfinite(loss(ms, ls_))
     assert [n_ for n_, _ in m1.named_parameters()][:1] == ["likelihood.noise_covar.raw_noise"]
+
+
+def test_nonvol_rollouts_mean_reverting_mean_vs_oracle():
+    """The fourth mean of the family (MeanRevertingEMAMean, EWMA.py:116-135) through nonvol_rollouts: HIP path vs the
+    oracle's restatement of the reference loop, same draws."""
+    from volt_amd.means import MeanRevertingEMAMean
+    from volt_amd.rollout_utils import nonvol_rollouts
+    n, H, S, k, theta = 90, 7, 6, 8, 0.3
+    F, _ = sde_series(n - 1, 17)
+    tx = np.arange(n, dtype=np.float32) / 252
+    te = np.arange(H, dtype=np.float32) / 252 + tx[-1] + tx[1]
+    ls, os_, noise = 0.3, 0.4, 0.05
+    z = np.random.RandomState(3).normal(size=(S, H)).astype(np.float32)
+    ref = vo.nonvol_rollouts(tx, F, te, lambda a, b: vo.matern_kernel(a, b, ls, os_), noise, z, "meanrevert", k, theta)
+    mean = MeanRevertingEMAMean(dev(tx), dev(F).log(), k, theta)
+    model = _baseline_model("matern", dev(tx), dev(F).log(), ls, os_, noise, mean)
+    got = nonvol_rollouts(dev(tx), dev(F), dev(te), model, nsample=S, z=dev(z)).numpy()
+    assert np.abs(got - ref).max() < 2e-3
