@@ -395,3 +395,22 @@ def test_full_length_training_run_tracks_oracle(va):
     o = vo.mll_and_grads(K, y, mean, raw_end)
     assert abs(last + float(o["mll"])) < 1e-4 * abs(float(o["mll"]))
     assert losses[-1] < losses[0]
+
+
+def test_batched_wind_driver_writes_reference_layout(va, tmp_path):
+    """experiments/weather/GPGenerator.py volt/ewma branch, all stations per window: window schedule (:33-34), +1 offset
+    and -99 handling (:47,55), theta = 0.01 rollouts, file names (:103-106)."""
+    from volt_amd.forecast import GenerateWindPredictionsBatch
+    B, T, ntrain, H, S = 3, 120, 64, 5, 6
+    rng = np.random.RandomState(3)
+    wind = np.abs(np.cumsum(rng.normal(0, 0.3, size=(B, T)), axis=1) + 6).astype(np.float32)
+    wind[1, 10] = -99.0                                                    # a missing reading
+    g = torch.Generator(device="cuda").manual_seed(2)
+    out = GenerateWindPredictionsBatch([0, 1, 2], dev(wind), forecast_horizon=H, ntrain=ntrain, n_test_times=3, nsample=S,
+                                       k=20, gpcv_iters=3, vol_iters=2, save=True, par_dir=str(tmp_path), generator=g)
+    assert tuple(out.shape) == (B, S, H) and torch.isfinite(out).all()
+    step = int((T - H - ntrain) / 3)
+    want = [f"volt_ema20_theta0.01_{d}.pt" for d in range(ntrain, T - H, step)]
+    assert sorted(p.name for p in (tmp_path / "stn1").iterdir()) == sorted(want)
+    saved = torch.load(tmp_path / "stn2" / want[-1])
+    assert tuple(saved.shape) == (S, H) and torch.equal(saved, out[2])

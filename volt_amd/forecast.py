@@ -1,6 +1,7 @@
-"""Batched forecast driver -- SURVEY 8(f) row 3: the sliding-window schedule and output format of
-experiments/stocks/GenerateMultiMeanPreds.py:63-137, with the reference's per-ticker Python ``for``
-(ForecastGenerator.py:27-41) replaced by one batched pass per window:
+"""Batched forecast drivers -- SURVEY 8(f) row 3: the sliding-window schedule and output format of
+experiments/stocks/GenerateMultiMeanPreds.py:63-137 (and of the weather driver's volt/ewma branch,
+experiments/weather/GPGenerator.py:20-112), with the reference's per-ticker / per-station Python ``for``
+(ForecastGenerator.py:27-41, GPGenerator.py --stn_idx) replaced by one batched pass per window:
 
     window -> LearnGPCV for all tickers at once (batched variational fit, HIP ELBO step)          (:95-96)
            -> TrainVoltMagpieBatch (all tickers in one batched model, HIP MLL step)               (:99-103)
@@ -36,6 +37,40 @@ def realised_vol(train_x, prices, span=20, floor=1e-3):
     return v.clamp_min(floor)
 
 
+def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample, mean, k, gpcv_iters, vol_iters,
+                      data_iters, theta, vol_fn, generator, save, path_fn):
+    """One batched pass per window: GPCV -> data model -> vol forecasters -> rollouts, every stage for all series of
+    this rank at once.  series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e]."""
+    dev = series.device
+    B = series.shape[0]
+    H = test_x.numel()
+    last = None
+    for last_day in end_idxs:
+        train_y = series[:, last_day - ntrain:last_day].float()                          # [B, ntrain] prices
+        if vol_fn is None:
+            vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters)                    # all series at once
+        else:
+            vol = vol_fn(train_x, train_y)                                               # [B, ntrain-1]
+        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k)
+        if mean != "ewma":
+            cls = {"dewma": DEWMAMean, "tewma": TEWMAMean}[mean]
+            model.mean_module = cls(train_x, train_y[:, 1:].log(), k)
+        vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters)
+        vmod.eval()
+        pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous()   # [B,S,H]
+        z = torch.randn(B, nsample, H, device=dev, generator=generator)
+        latent = train_y.log().mean(-1) if theta is not None else None                   # rollout_utils.py:60-63
+        samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
+                                                      _MODES[mean], k, latent_mean=latent, theta=theta)
+        last = samples.cpu()
+        if save:
+            for b, name in enumerate(names):
+                path = path_fn(name, last_day)
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                torch.save(last[b], path)
+    return last
+
+
 def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=20, train_iters=400, nsample=1000,
                                   ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=None,
                                   vol_iters=None, par_dir="./saved-outputs/", generator=None):
@@ -48,7 +83,7 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
     dev = closes.device
     lo, hi = shard_range(len(tickers))
     tickers, closes = list(tickers)[lo:hi], closes[lo:hi]
-    B, T = closes.shape
+    T = closes.shape[1]
     if ntimes == -1:
         end_idxs = torch.arange(ntrain, T)
     else:
@@ -56,34 +91,36 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
     dt = 1. / 252
     model_name = "volt_" + mean + str(k) + "_"
     vol_iters = train_iters if vol_iters is None else vol_iters
-    last = None
-    for last_day in end_idxs.tolist():
+    train_x = torch.arange(ntrain - 1, device=dev) * dt                                  # :89
+    test_x = torch.arange(forecast_horizon, device=dev) * dt + train_x[-1] + train_x[1]  # :90
+
+    def path_fn(tckr, last_day):
         date = str(last_day) if dates is None else str(dates[last_day])
-        train_y = closes[:, last_day - ntrain:last_day].float()                       # [B, ntrain] prices
-        train_x = torch.arange(ntrain - 1, device=dev) * dt                             # :89
-        test_x = torch.arange(forecast_horizon, device=dev) * dt + train_x[-1] + train_x[1]     # :90
-        if vol_fn is None:
-            vol = LearnGPCV(train_x, train_y, train_iters=train_iters)                  # :95-96, all tickers at once
-        else:
-            vol = vol_fn(train_x, train_y)                                              # [B, ntrain-1]
-        # data model: all tickers in one batched VoltMagpie (per-ticker noise), :104-108
-        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=train_iters, k=k)
-        if mean != "ewma":
-            cls = {"dewma": DEWMAMean, "tewma": TEWMAMean}[mean]
-            model.mean_module = cls(train_x, train_y[:, 1:].log(), k)
-        # vol forecasters (BM-GP over log-vol, :102), all tickers in one batched model, and their posterior samples
-        # (rollout_utils.py:66)
-        vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters)
-        vmod.eval()
-        pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous()   # [B,S,H]
-        z = torch.randn(B, nsample, forecast_horizon, device=dev, generator=generator)
-        samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
-                                                      _MODES[mean], k)
-        last = samples.cpu()
-        if save:
-            os.makedirs(par_dir, exist_ok=True)
-            for b, tckr in enumerate(tickers):
-                savepath = os.path.join(par_dir, tckr)
-                os.makedirs(savepath, exist_ok=True)
-                torch.save(last[b], os.path.join(savepath, model_name + date + ".pt"))  # :128
-    return last
+        return os.path.join(par_dir, tckr, model_name + date + ".pt")                    # :128
+    return _forecast_windows(tickers, closes, end_idxs.tolist(), ntrain, train_x, test_x, nsample, mean, k,
+                             train_iters, vol_iters, train_iters, None, vol_fn, generator, save, path_fn)
+
+
+def GenerateWindPredictionsBatch(stations, data, forecast_horizon=100, ntrain=400, n_test_times=10, nsample=1000, k=400,
+                                 theta=0.01, gpcv_iters=200, vol_iters=500, data_iters=0, save=False, vol_fn=None,
+                                 par_dir="./saved-outputs/", generator=None):
+    """The ``--kernel volt --mean ewma`` branch of experiments/weather/GPGenerator.py:20-112 for B stations at once:
+    data [B,T] wind speeds (missing = -99 -> 0, then +1 as at :47,55), dt = 1/365 (:38-41), the schedule of test
+    windows of :33-34, GPCV 200 / vol model 500 / data model 0 iterations (:64-67,89-92), EWMA(k=400) mean and
+    mean-reverting rollouts with theta = 0.01 (:96-102), files ``stn<idx>/volt_ema<k>_theta<theta>_<last_day>.pt``
+    (:103-106).  Stations shard across ranks like tickers.  Returns the last window's samples [B_local,S,H] (CPU)."""
+    dev = data.device
+    lo, hi = shard_range(len(stations))
+    stations, data = list(stations)[lo:hi], data[lo:hi].float()
+    data = torch.where(data == -99.0, torch.zeros_like(data), data) + 1                  # :47,55
+    ntime = data.shape[1]
+    step = int((ntime - forecast_horizon - ntrain) / n_test_times)
+    end_idxs = torch.arange(ntrain, ntime - forecast_horizon, step).tolist()            # :33-34
+    train_x = torch.arange(ntrain - 1, device=dev).float() / 365                         # :38
+    test_x = torch.arange(ntrain, ntrain + forecast_horizon, device=dev).float() / 365   # :41 (absolute day index, as written)
+
+    def path_fn(stn, last_day):
+        return os.path.join(par_dir, "stn" + str(stn), "volt_ema" + str(k) + "_theta" + str(theta) + "_" +
+                            str(last_day) + ".pt")
+    return _forecast_windows(stations, data, end_idxs, ntrain, train_x, test_x, nsample, "ewma", k, gpcv_iters,
+                             vol_iters, data_iters, theta, vol_fn, generator, save, path_fn)

@@ -293,4 +293,4 @@ def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, pri
         if printing and i % 50 == 0:
             print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, (total[0] / total[1]).item()))
         optimizer.step()
-    return model, lh, losses.detach()
+    return model, lh, (None if losses is None else losses.detach())      # train_iters = 0 (GPGenerator.py:89-92)
