@@ -978,7 +978,11 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     if (post)
         for (int g = 0; g < G; ++g) post(post_ctx, g * Bg, Bg, grp[g].s);
     for (int g = 1; g < G; ++g) {
-        if ((e = hipEventCreateWithFlags(&join[g], hipEventDisableTiming)) != hipSuccess) return (int)e;
+        if ((e = hipEventCreateWithFlags(&join[g], hipEventDisableTiming)) != hipSuccess) {
+            // out of events: fall back to a host-side join so that the caller's stream semantics still hold
+            (void)hipStreamSynchronize(grp[g].s);
+            continue;
+        }
         (void)hipEventRecord(join[g], grp[g].s);
         (void)hipStreamWaitEvent(s, join[g], 0);
         (void)hipEventDestroy(join[g]);
