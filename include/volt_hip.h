@@ -38,6 +38,7 @@ extern "C" {
 
 /* ---- introspection ------------------------------------------------------------------------ */
 int volt_abi_version(void);                 /* bumps when a signature changes */
+const char* volt_source_hash(void);         /* hash of the sources this binary was built from (volt_amd/build.py) */
 int volt_padded_n(int n);                   /* next multiple of VOLT_TILE */
 
 /* ---- a1: CumTrapz  (voltron/kernels/VolKernel.py:4-10) -------------------------------------

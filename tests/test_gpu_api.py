@@ -368,9 +368,20 @@ def test_model_method_generate_prediction_twin(va):
         ref = vo.generate_prediction(x, np.log(F[1:]), np.log(m.log_vol_path.exp().cpu().numpy()), txn,
                                      pv.cpu().numpy()[None], z[None, :, c:c + 1], lin, jitter=None)
         np.testing.assert_allclose(out[:, c].cpu().numpy(), ref[0], atol=2e-3, rtol=0)
+    # n_sample = 1 (the default): the reference squeezes the sample axis away, VoltronGP.py:93-95 / VoltMagpie.py:96-99
+    torch.manual_seed(11)
+    one = m.GeneratePrediction(test_x, pv)
+    torch.manual_seed(11)
+    z1 = torch.randn(T, 1).numpy()
+    assert tuple(one.shape) == (T,)
+    ref1 = vo.generate_prediction(x, np.log(F[1:]), np.log(m.log_vol_path.exp().cpu().numpy()), txn,
+                                  pv.cpu().numpy()[None], z1[None], lin, jitter=None)
+    np.testing.assert_allclose(one.cpu().numpy(), ref1[0], atol=2e-3, rtol=0)
     m.vol_model.eval()
     s = m.SamplePrediction(test_x, n_sample=2)
     assert tuple(s.shape) == (T, 2) and torch.isfinite(s).all()
+    assert tuple(m.SamplePrediction(test_x).shape) == (T,)
+    assert tuple(m.MeanPrediction(test_x).shape) == (T,)
 
 
 def test_full_length_training_run_tracks_oracle(va):

@@ -250,8 +250,7 @@ def test_class_surfaces_match_the_reference():
              "models/single_task_variational_gp.py": ["SingleTaskVariationalGP"],
              "means/EWMA.py": ["EWMAMean", "DEWMAMean", "TEWMAMean", "MeanRevertingEMAMean"],
              "means/loglinear_mean.py": ["LogLinearMean"], "kernels/VolKernel.py": ["VolatilityKernel"],
-             "kernels/BMKernel.py": ["BMKernel"], "kernels/FBMKernel.py": ["FBMKernel"], "kernels/OUKernel.py": ["OUKernel"],
-             "means/mulidentity_mean.py": ["MulIdentityMean"],
+             "kernels/BMKernel.py": ["BMKernel"], "kernels/FBMKernel.py": ["FBMKernel"],
              "likelihoods/volatility_likelihood.py": ["VolatilityGaussianLikelihood"]}
     for rel, classes in files.items():
         tree = ast.parse(open("/root/reference/voltron/" + rel).read())

@@ -7,15 +7,16 @@ import os
 
 import torch  # noqa: F401  -- load torch's libamdhip64 first so the library binds the same HIP runtime
 
-from .build import LIB, build_lib
+from .build import LIB, build_lib, source_hash
 
 _lib = None
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i32, _i64, _f32, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
 
 _SIGS = {
     "volt_abi_version": (C.c_int, []),
+    "volt_source_hash": (C.c_char_p, []),
     "volt_padded_n": (C.c_int, [_i32]),
     "volt_cumtrapz_f32": (C.c_int, [_ptr, _i64, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr]),
     "volt_cumtrapz_f64": (C.c_int, [_ptr, _i64, _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr]),
@@ -53,14 +54,20 @@ def lib() -> C.CDLL:
     """Load (once) and type the library.  Raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            try:                                   # a source-only checkout: compile once (hipcc, ~30 s)
-                build_lib(verbose=False)
-            except Exception as e:
-                raise VoltHipError(
-                    f"{LIB} not found and could not be built ({e}): run `python -m volt_amd.build` "
-                    "(hipcc, gfx950). volt_amd has no CPU fallback.") from e
+        # A source-only checkout, or a git-ignored binary older than the checked-in sources: (re)build once
+        # (hipcc, ~30 s).  build_lib compares the hash of the sources with the one recorded by the last build.
+        try:
+            build_lib(verbose=False)
+        except Exception as e:
+            raise VoltHipError(
+                f"{LIB} is missing or stale and could not be built ({e}): run `python -m volt_amd.build` "
+                "(hipcc, gfx950). volt_amd has no CPU fallback.") from e
         handle = C.CDLL(LIB)
+        built = handle.volt_source_hash
+        built.restype = C.c_char_p
+        if built().decode() != source_hash():
+            raise VoltHipError(f"{LIB} was built from other sources ({built().decode()} != {source_hash()}): "
+                               "run `python -m volt_amd.build --force`")
         for name, (res, args) in _SIGS.items():
             fn = getattr(handle, name)           # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args

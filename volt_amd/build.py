@@ -7,6 +7,8 @@ but travels to the GPU box with the gpurun snapshot.
 """
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -28,23 +30,50 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: libvolt_hip.so cannot be built")
 
 
+def source_hash() -> str:
+    """Hash of every source the library is built from.  It is compiled into the library (volt_source_hash())
+    so that a loader can tell a stale, git-ignored .so from one built from the checked-in sources -- file times do
+    not survive the copy to a GPU box."""
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def _built_hash() -> str | None:
+    """The hash recorded next to the library by the build that produced it."""
+    try:
+        with open(LIB + ".hash") as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not os.path.exists(LIB) or _built_hash() != source_hash()
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
+    # one builder at a time (bench.py starts one process per GPU)
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = _hipcc()
+    digest = source_hash()
     objs = []
     procs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, f'-DVOLT_SOURCE_HASH="{digest}"', "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), cmd))
@@ -56,6 +85,8 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(LIB + ".hash", "w") as fh:
+        fh.write(digest + "\n")
     return LIB
 
 

@@ -42,6 +42,11 @@ extern "C" int volt_ewma_f32(const float* y, int64_t bs_y, const float* w, int k
     if (N < 1) return -7;
     if (B == 0) return 0;
     const size_t lds = (size_t)(2 * k + 256) * sizeof(float);
+    if (lds > 48 * 1024) {                        // large dynamic LDS has to be opted into (k > ~6000)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(volt::ewma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(volt::ewma_kernel, dim3((N + 1 + 255) / 256, B), dim3(256), lds, (hipStream_t)stream, y, bs_y, w,
                        k, out, N);
     VOLT_LAUNCH_CHECK();

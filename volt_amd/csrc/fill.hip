@@ -121,6 +121,10 @@ static int launch_fill(const T* V, T* K, int B, int N, int64_t ldk, int64_t bsk,
 extern "C" {
 
 int volt_abi_version(void) { return VOLT_ABI_VERSION; }
+#ifndef VOLT_SOURCE_HASH
+#define VOLT_SOURCE_HASH "unknown"
+#endif
+const char* volt_source_hash(void) { return VOLT_SOURCE_HASH; }
 int volt_padded_n(int n) { return ((n + volt::TS - 1) / volt::TS) * volt::TS; }
 
 int volt_cumtrapz_f32(const float* vol, int64_t bs_vol, const float* x, int64_t bs_x, float* V, int B, int N,

@@ -124,7 +124,7 @@ def _model_generate_prediction(model, test_x, pred_vol, n_sample=1):
     out = _posterior_draw(model.covar_module, full_x, full_vol, idx_cut, train_diffs, test_mean_term,
                           z.reshape(S, T, n_sample), None)
     out = out.reshape(*batch, T, n_sample)
-    return out if n_sample > 1 else out                                                   # (samples + pred_mean).squeeze(-1) keeps [T,n]
+    return out.squeeze(-1)                                  # (samples + pred_mean).squeeze(-1), VoltMagpie.py:96-99: [T] for n_sample = 1
 
 
 def Rollouts(train_x, train_y, test_x, model, nsample=50, method="volt", theta=None, *, pred_vol=None, z=None,
