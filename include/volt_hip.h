@@ -81,14 +81,27 @@ int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
  * the diagonal are never touched. */
 int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream);
 
+/* fp64 twins on v_mfma_f64_16x16x4_f64 (the reference keeps the caller's dtype, VolKernel.py:28-33; the
+ * noise-free train block of rollout_utils.py:35 has condition number 1e6 (N = 400) .. 1e8 (N = 4096), beyond
+ * fp32).  Same layout and semantics as the fp32 pair; sigma2 [B] and jitter are doubles. */
+int volt_prepare_f64(const double* K, int64_t ldk, int64_t bsk, const double* sigma2, double jitter,
+                     double* A, int B, int N, void* stream);
+int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stream);
+
 /* ---- a5/a6: triangular solves with one right-hand side  (torch.cholesky_solve at
  * rollout_utils.py:36,44; gpytorch inv_quad) ------------------------------------------------
- * rhs/out [B,Np] contiguous (pad with zeros).  `scratch` [B,Np] floats.  lower: out = L^-1 rhs;
- * lower_t: out = L^-T rhs.  rhs and out may alias. */
+ * rhs/out [B,Np] contiguous (pad with zeros).  `scratch` [B,Np] elements.  lower: out = L^-1 rhs;
+ * lower_t: out = L^-T rhs.  rhs and out may alias.  ONE launch per solve: one workgroup per 128-block,
+ * chained through release/acquire flags kept in `scratch`; an internal time-out (never expected) turns the
+ * affected blocks into NaN instead of hanging. */
 int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out,
                         float* scratch, int B, int Np, void* stream);
 int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, float* out,
                           float* scratch, int B, int Np, void* stream);
+int volt_trsv_lower_f64(const double* A, const double* Winv, const double* rhs, double* out,
+                        double* scratch, int B, int Np, void* stream);
+int volt_trsv_lower_t_f64(const double* A, const double* Winv, const double* rhs, double* out,
+                          double* scratch, int B, int Np, void* stream);
 
 /* ---- a5: triangular inverse for the noise gradient  (replaces autograd cholesky_backward) ---
  * Y = L^-T (upper triangular, row-major [B,Np,Np]); tr(K_s^-1) = ||Y||_F^2. */
@@ -101,10 +114,12 @@ int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, v
  * family mean of the appended point (mean_mode 0 ewma / 1 dewma / 2 tewma / 3 meanrevert, EWMA.py),
  * optional mean reversion (:41-42), jitter ladder of psd_safe_cholesky(pred_cov, jitter) (:46).
  * G series x S samples x H steps (H <= 256).  hist_* [G,k] are the last k values of the (padded)
- * train series / its EMA / EMA(EMA); acc0 [G] the fp64 CumTrapz running sum through the last train
- * point.  pred_vol, z, samples [G,S,H]; info [G,S] (0, or the 1-based step of a non-positive pivot). */
+ * train series / its EMA / EMA(EMA); acc0 [G] the CumTrapz running sum through the last train
+ * point; rho, tau, acc0 are fp64 (the kernel works with acc - rho, which fp32 operands would cancel away).  pred_vol, z, samples [G,S,H]; info [G,S]: 0; +step (1-based) of the first non-positive pivot of the
+ * per-sample factor (a local jitter was applied); -step if the predictive variance stayed <= 0 after the
+ * jitter ladder (the reference's psd_safe_cholesky raises NotPSDError there). */
 size_t volt_rollout_scratch_bytes(int G, int S, int H);
-int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* acc0, const float* dx,
+int volt_rollout_bordered_f32(const double* rho, const double* tau, const double* acc0, const float* dx,
                               const float* hist_y, const float* hist_e1, const float* hist_e2,
                               const float* ema_prev, const float* mr_latent, const float* latent,
                               const float* w, const float* pred_vol, const float* z, float* samples,

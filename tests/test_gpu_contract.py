@@ -1,0 +1,250 @@
+"""BASELINE.json's own sizes through the C ABI (needs an MI355X), plus the fp64 factor / solve path.
+
+  * metric size: MLL+grad of 2 x 4096 against the fp64 oracle (tolerances of test_gpu_kernels: MLL 2e-5 rel,
+    d/d sigma2 1e-3 rel, alpha 1e-4 rel-to-max);
+  * C2: ONE series of N = 4096 (the small-batch schedule) against the fp64 oracle;
+  * C4's per-GPU share: 32 x 4096 through the grouped schedule -- per-series properties + 2 series vs the oracle;
+  * C5's per-GPU share: 8 series x 10,000 paths x 256 steps at N = 4096 -- every path against the exact fp64
+    conditional, per-step sample statistics against Monte-Carlo error, and NO non-positive pivot;
+  * fp64: volt_potrf_f64 / volt_trsv_*_f64 against the reference-generated fixture tests/golden/chol64.npz and
+    numpy LAPACK; the one-launch TRSV in both precisions.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import volt_oracle as vo
+from volt_amd.synthetic import rollout_inputs, sde_batch, sde_series
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from volt_amd import ops as _ops
+    return _ops
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda()
+
+
+SIG2 = float(vo.noise_from_raw(1e-5))
+
+
+def _series_problem(B, n, seed=2019):
+    x, F, vol = sde_batch(B, n, seed)
+    y = np.log(F[:, 1:])
+    mean = np.stack([vo.ewma_mean(x, x, y[b], 25) for b in range(B)])
+    return x, vol, y.astype(np.float32), mean.astype(np.float32)
+
+
+def _check_vs_oracle(K_rows, y, mean, raw, out, alpha, rows):
+    """fp32 step vs the fp64 closed form for the series in `rows`."""
+    o = vo.mll_and_grads(K_rows, y[rows], mean[rows], raw)
+    n = y.shape[-1]
+    dsig = 0.5 * (o["aa"] - o["trinv"]) / n
+    out = out[rows].astype(np.float64)
+    assert np.abs(out[:, 0] / o["mll"] - 1).max() < 2e-5
+    assert np.abs(out[:, 1] / dsig - 1).max() < 1e-3
+    assert np.abs(out[:, 4] / o["trinv"] - 1).max() < 1e-4
+    assert np.abs(alpha[rows] - o["alpha"]).max() <= 1e-4 * np.abs(o["alpha"]).max()
+
+
+# ------------------------------------------------------------------ metric size and C2
+@pytest.mark.parametrize("B", [2, 1])
+def test_mll_step_vs_fp64_oracle_at_4096(ops, B):
+    """B = 2: the accuracy table's row as a test; B = 1: BASELINE config 2 (one series, small-batch schedule)."""
+    n = 4096
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    out, alpha, info = ops.mll_step(K, dev(y - mean), torch.full((B,), SIG2, device="cuda"))
+    assert int(info.abs().sum()) == 0
+    _check_vs_oracle(K.cpu().numpy(), y, mean, 1e-5, out.cpu().numpy(), alpha.cpu().numpy(), list(range(B)))
+    # forward-only path (potrf + one-launch TRSV) agrees with the gradient path
+    o1 = out.clone()
+    o0, _, _ = ops.mll_step(K, dev(y - mean), torch.full((B,), SIG2, device="cuda"), want_grad=False)
+    assert torch.allclose(o1[:, 0], o0[:, 0], rtol=1e-5)
+    assert torch.allclose(o1[:, 2], o0[:, 2], rtol=1e-4)
+
+
+# ------------------------------------------------------------------ C4's per-GPU share
+def test_c4_share_32x4096(ops):
+    """Wind config: 256 stations of N = 4096 over 8 GPUs = 32 per GPU (dt = 1/365, GPGenerator.py:39)."""
+    from volt_amd.synthetic import DT_WIND
+    B, n = 32, 4096
+    x, F, vol = sde_batch(B, n, dt=DT_WIND)
+    y = np.log(F[:, 1:]).astype(np.float32)
+    mean = np.stack([vo.ewma_mean(x, x, y[b], 25) for b in range(B)]).astype(np.float32)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    s2v = torch.linspace(0.4, 0.9, B, device="cuda")
+    s2v[0] = s2v[B - 1] = SIG2
+    r = dev(y - mean)
+    o, a, info = ops.mll_step(K, r, s2v, want_grad=True)
+    o, a = o.clone(), a.clone()
+    assert int(info.abs().sum()) == 0 and bool(torch.isfinite(o).all())
+    rd, ad = r.double(), a.double()
+    back = torch.empty_like(rd)
+    for b0 in range(0, B, 8):
+        sl = slice(b0, b0 + 8)
+        back[sl] = (K[sl].double() @ ad[sl].unsqueeze(-1)).squeeze(-1) + s2v[sl].double().unsqueeze(-1) * ad[sl]
+    assert float(((back - rd).norm(dim=-1) / rd.norm(dim=-1)).max()) < 2e-3
+    quad = (rd * ad).sum(-1)
+    assert float(((o[:, 2].double() - quad).abs() / quad.abs()).max()) < 1e-4
+    assert torch.unique(o[:, 0]).numel() == B                       # no group of the split dropped or duplicated
+    rows = [0, B - 1]                                               # first series of the first group, last of the last
+    _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, o.cpu().numpy(), a.cpu().numpy(), rows)
+
+
+# ------------------------------------------------------------------ C5's per-GPU share
+def _exact_conditional_all_paths(logy, samples, pv, z, k, dx):
+    """fp64 exact one-step conditional for EVERY path, vectorised on the device (independent of the HIP kernels):
+    sample_i = (y_last - ema_last) + ema_new + sqrt(dx/2 pv_i^2) z_i  with the EWMA mean over the path's own history
+    (EWMA.py:20-37).  Returns the reference values given the engine's own earlier draws."""
+    G, S, H = samples.shape
+    w = torch.tensor(vo.ewma_weights(k), device=samples.device, dtype=torch.float64)
+    tail = logy[:, -(k + 1):].double()                                      # [G,k+1]
+    hist = torch.cat((tail[:, None, :].expand(G, S, k + 1), samples.double()), -1)     # [G,S,k+1+H]
+    ref = torch.empty(G, S, H, dtype=torch.float64, device=samples.device)
+    for i in range(H):
+        win_last = hist[..., i:i + k]                  # the k values before the last known point
+        win_new = hist[..., i + 1:i + 1 + k]           # the k values before the new point
+        ema_last = (win_last * w).sum(-1)
+        ema_new = (win_new * w).sum(-1)
+        y_last = hist[..., i + k]
+        sd = (0.5 * dx * pv[..., i].double() ** 2).sqrt()
+        ref[..., i] = (y_last - ema_last) + ema_new + sd * z[..., i].double()
+    return ref
+
+
+def test_c5_share_rollouts_8x10k_x256_at_4096(ops):
+    from volt_amd import rollout_engine as re_
+    G, n, S, H, k = 8, 4096, 10000, 256, 25
+    x, F, vol = sde_batch(G, n)
+    pv, z = rollout_inputs(vol[:, -1], S, H, seed=3)
+    tx = dev(x)
+    test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
+    logy = torch.log(dev(F[:, 1:]))
+    pvd, zd = dev(pv), dev(z)
+    samples, info = re_.rollout_series(tx, logy, torch.log(dev(vol)), test_x, pvd, zd, 0, k)
+    assert tuple(samples.shape) == (G, S, H) and bool(torch.isfinite(samples).all())
+    assert int((info != 0).sum()) == 0                                        # no non-positive pivot, no jitter
+    dx = float(x[1] - x[0])
+    ref = _exact_conditional_all_paths(logy, samples, pvd, zd, k, dx)
+    err = (samples.double() - ref).abs()
+    assert float(err.max()) < 5e-4, float(err.max())                          # values ~2.3 (log prices), fp32 engine
+    # the same for a handful of paths with the CPU oracle's own EWMA, python loop
+    out = samples[:, :2].cpu().numpy()
+    for g in range(2):
+        ly = np.log(F[g, 1:]).astype(np.float32)
+        for s in range(2):
+            ys = ly[-(k + 2):].copy()
+            for i in range(H):
+                full = vo.ewma(ys[-(k + 2):], k)
+                val = (ys[-1] - full[-2]) + full[-1] + np.sqrt(0.5 * dx * float(pv[g, s, i]) ** 2) * z[g, s, i]
+                assert abs(val - out[g, s, i]) < 5e-4, (g, s, i)
+                ys = np.append(ys, np.float32(out[g, s, i]))
+    # per-step statistics with the path-specific scale divided out: (sample - conditional mean) / sd is the draw
+    sd = (0.5 * dx * pvd.double() ** 2).sqrt()
+    innov = (samples.double() - (ref - sd * zd.double())) / sd                 # [G,S,H], should be N(0,1) per step
+    m, v = innov.mean(1), innov.std(1)
+    assert float(m.abs().max()) < 5.0 / np.sqrt(S) + 1e-2
+    assert float((v - 1).abs().max()) < 5.0 / np.sqrt(2 * S) + 1e-2
+    # the general route (fp64 factorisation of the noise-free train block + two fp64 solves) gives the same rho / tau
+    U = ops.cumtrapz(torch.cat((dev(vol[:2]), dev(vol[:2, -1:])), -1),
+                     torch.cat((tx, test_x[:1])), square=True)[:, :n].contiguous()
+    r_tr = (logy[:2] - ops.ewma(logy[:2], k)[:, :-1]).contiguous()
+    rho_c, tau_c = re_.train_block_terms(U, r_tr, "closed")
+    rho_f, tau_f = re_.train_block_terms(U, r_tr, "factor")
+    assert float(((rho_f - rho_c).abs() / rho_c.abs()).max()) < 1e-6           # cond 1e8 x eps64
+    assert float((tau_f - tau_c).abs().max()) < 1e-6 * float(r_tr.abs().max()) + 1e-7
+
+
+def test_rollouts_factor_route_matches_closed_form(ops):
+    """At the reference's default size the engine fed by the fp64 factorisation reproduces the closed-form engine."""
+    from volt_amd import rollout_engine as re_
+    n, S, H, k = 399, 64, 40, 25
+    F, vol = sde_series(n, 11)
+    pv, z = rollout_inputs(vol[-1], S, H, seed=5)
+    tx = torch.arange(n, device="cuda") / 252.
+    test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
+    args = (tx, torch.log(dev(F)[1:])[None], torch.log(dev(vol))[None], test_x, dev(pv)[None], dev(z)[None], 0, k)
+    a, ia = re_.rollout_series(*args, solve="closed")
+    b, ib = re_.rollout_series(*args, solve="factor")
+    assert int((ia != 0).sum()) == 0 and int((ib != 0).sum()) == 0
+    assert float((a - b).abs().max()) < 1e-5
+
+
+# ------------------------------------------------------------------ fp64 factor / solve
+def test_potrf_and_solve_f64_golden(ops, golden):
+    g = golden("chol64")
+    n = g["x"].shape[0]
+    K = ops.fill(ops.cumtrapz(dev(g["vol"]), dev(g["x"]), square=True))
+    assert K.dtype == torch.float64
+    f = ops.potrf(K.unsqueeze(0))
+    assert int(f.info.abs().sum()) == 0 and f.A.dtype == torch.float64
+    Lref = np.zeros((n, n))
+    Lref[np.tril_indices(n)] = g["L_packed"]
+    np.testing.assert_allclose(f.L[0].cpu().numpy(), Lref, rtol=0, atol=1e-9 * np.abs(Lref).max())
+    sol = ops.cholesky_solve(f, dev(g["rhs"]).unsqueeze(0))[0].cpu().numpy()
+    np.testing.assert_allclose(sol, g["sol"], rtol=0, atol=1e-7 * np.abs(g["sol"]).max())   # cond 4e6
+
+
+@pytest.mark.parametrize("B,n,noise", [(2, 256, 0.0), (3, 300, 0.0), (1, 1000, 0.0), (2, 640, 0.3)])
+def test_potrf_trsv_f64_vs_lapack(ops, B, n, noise):
+    x, F, vol = sde_batch(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol).double(), dev(x).double(), square=True))
+    s2 = torch.full((B,), noise, device="cuda", dtype=torch.float64) if noise else None
+    f = ops.potrf(K, s2)
+    assert int(f.info.abs().sum()) == 0
+    Kc = K.cpu().numpy() + noise * np.eye(n)
+    Lr = np.linalg.cholesky(Kc)
+    assert np.abs(f.L.cpu().numpy() - Lr).max() <= 1e-9 * np.abs(Lr).max()
+    rng = np.random.RandomState(0)
+    rhs = rng.normal(size=(B, n))
+    z = ops.trsv(f, dev(rhs)).cpu().numpy()
+    zr = np.stack([np.linalg.solve(Lr[b], rhs[b]) for b in range(B)])
+    assert np.abs(z - zr).max() <= 1e-8 * np.abs(zr).max()
+    xs = ops.trsv(f, dev(rhs), transpose=True).cpu().numpy()
+    xr = np.stack([np.linalg.solve(Lr[b].T, rhs[b]) for b in range(B)])
+    assert np.abs(xs - xr).max() <= 1e-7 * np.abs(xr).max()
+
+
+def test_potrf_f64_reports_failure_and_psd_safe_cholesky_keeps_dtype(ops):
+    from volt_amd import gp
+    n = 200
+    A = torch.eye(n, device="cuda", dtype=torch.float64).repeat(2, 1, 1)
+    A[1, 150, 150] = -1.0
+    f = ops.potrf(A)
+    assert f.info.tolist() == [0, 151]
+    x, F, vol = sde_batch(1, 300)
+    K64 = ops.fill(ops.cumtrapz(dev(vol).double(), dev(x).double(), square=True))[0]
+    L = gp.psd_safe_cholesky(K64)
+    assert L.dtype == torch.float64
+    assert float((L @ L.T - K64).abs().max()) < 1e-12 * float(K64.abs().max()) * 300
+    L32 = gp.psd_safe_cholesky(K64.float() + 0.5 * torch.eye(300, device="cuda"))
+    assert L32.dtype == torch.float32
+
+
+@pytest.mark.parametrize("B,n", [(3, 2048), (1, 4096), (5, 130)])
+def test_one_launch_trsv_f32_large(ops, B, n):
+    """The chained one-launch solve at sizes with many dependent blocks (32 hops at N = 4096) and a batch that does not
+    divide the ticket order evenly; rhs and out aliased through cholesky_solve's second call."""
+    x, F, vol = sde_batch(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    f = ops.potrf(K, torch.full((B,), SIG2, device="cuda"))
+    rng = np.random.RandomState(1)
+    rhs = rng.normal(size=(B, n)).astype(np.float32)
+    L = f.L.double()
+    z = ops.trsv(f, dev(rhs)).double()
+    assert float(((L @ z.unsqueeze(-1)).squeeze(-1) - dev(rhs).double()).norm() / np.linalg.norm(rhs)) < 1e-5
+    xs = ops.trsv(f, dev(rhs), transpose=True).double()
+    assert float(((L.transpose(-1, -2) @ xs.unsqueeze(-1)).squeeze(-1) - dev(rhs).double()).norm()
+                 / np.linalg.norm(rhs)) < 1e-5
+    sol = ops.cholesky_solve(f, dev(rhs)).double()
+    back = (K.double() @ sol.unsqueeze(-1)).squeeze(-1) + SIG2 * sol
+    assert float((back - dev(rhs).double()).norm() / np.linalg.norm(rhs)) < 1e-4
+    # twice in a row on the same stream: the flags are re-zeroed per call
+    z2 = ops.trsv(f, dev(rhs)).double()
+    assert torch.equal(z, z2)

@@ -105,3 +105,19 @@ def test_nonvol_rollouts_match_reference_loop(golden, tag, mean, kern):
     out = vo.nonvol_rollouts(d[f"{tag}_train_x"], d[f"{tag}_train_y"], d[f"{tag}_test_x"],
                              lambda a, b: kf(a, b, ls, os_), noise, d[f"{tag}_z"], mean_name=mean, k=int(k))
     assert np.abs(out - d[f"{tag}_samples"]).max() < 5e-5
+
+
+def test_fp64_factor_and_solve_fixture(golden):
+    """tests/golden/chol64.npz (reference's fp64 VolatilityKernel.forward + the ATen calls of rollout_utils.py:35-36):
+    the oracle's fp64 kernel matrix factors and solves to the reference's own numbers."""
+    g = golden("chol64")
+    n = g["x"].shape[0]
+    K = vo.volatility_kernel(g["x"], g["vol"])
+    assert K.dtype == np.float64
+    L, used = vo.psd_safe_cholesky(K, jitter=1e-4)
+    assert used == 0.0
+    Lref = np.zeros((n, n))
+    Lref[np.tril_indices(n)] = g["L_packed"]
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-10 * np.abs(Lref).max())
+    sol = np.linalg.solve(L.T, np.linalg.solve(L, g["rhs"]))
+    np.testing.assert_allclose(sol, g["sol"], rtol=0, atol=1e-8 * np.abs(g["sol"]).max())

@@ -12,7 +12,7 @@ from .build import LIB, build_lib, source_hash
 _lib = None
 ABI_VERSION = 2
 
-_i32, _i64, _f32, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+_i32, _i64, _f32, _f64, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
 _SIGS = {
     "volt_abi_version": (C.c_int, []),
@@ -25,6 +25,10 @@ _SIGS = {
     "volt_ewma_f32": (C.c_int, [_ptr, _i64, _ptr, _i32, _ptr, _i32, _i32, _ptr]),
     "volt_prepare_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _f32, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_prepare_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, _f64, _ptr, _i32, _i32, _ptr]),
+    "volt_potrf_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_trsv_lower_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_trsv_lower_t_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_t_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trtri_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),

@@ -427,86 +427,6 @@ __global__ __launch_bounds__(256, 2) void potrf_trsm_kernel(float* __restrict__ 
             }
 }
 
-// ----------------------------------------------------------------------------- trsv steps
-// 128x128 tile times vector helpers: the tile is staged in LDS with coalesced float4 loads.
-constexpr int VLD = TS + 1;
-
-__device__ __forceinline__ void load_tile_lds(const float* __restrict__ T, int64_t ld, float* s) {
-    for (int e = threadIdx.x; e < TS * TS / 4; e += NT) {
-        const int r = e >> 5, c = (e & 31) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(T + (int64_t)r * ld + c);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[r * VLD + c + q] = v[q];
-    }
-}
-
-// Forward step i: z_i = W_i racc_i ; racc[rows of block i+t] -= L[i+t, i] z_i  (t >= 1).
-// grid.x = (n-i) * B; every workgroup recomputes z_i (64 KB of W_i out of L2) so no workgroup
-// waits on another inside the launch.
-__global__ __launch_bounds__(256) void trsv_fwd_step_kernel(const float* __restrict__ A, const float* __restrict__ Winv,
-                                                            float* __restrict__ racc, float* __restrict__ z, int Np,
-                                                            int i, int B) {
-    __shared__ float s[TS * VLD];
-    __shared__ float v[TS], zi[TS];
-    const int n = Np / TS;
-    int t, b;
-    decode_tile_batch(n - i, B, t, b);
-    const float* Ab = A + (int64_t)b * Np * Np;
-    float* rb = racc + (int64_t)b * Np;
-    const int tid = threadIdx.x;
-    load_tile_lds(Winv + ((int64_t)b * n + i) * TS * TS, TS, s);
-    if (tid < TS) v[tid] = rb[i * TS + tid];
-    __syncthreads();
-    if (tid < TS) {
-        float a = 0.f;
-        for (int p = 0; p <= tid; ++p) a += s[tid * VLD + p] * v[p];
-        zi[tid] = a;
-        if (t == 0) z[(int64_t)b * Np + i * TS + tid] = a;
-    }
-    __syncthreads();
-    if (t == 0) return;
-    load_tile_lds(Ab + (int64_t)(i + t) * TS * Np + (int64_t)i * TS, Np, s);
-    __syncthreads();
-    if (tid < TS) {
-        float a = 0.f;
-        for (int p = 0; p < TS; ++p) a += s[tid * VLD + p] * zi[p];
-        rb[(i + t) * TS + tid] -= a;
-    }
-}
-
-// Backward step i (i = n-1 .. 0): a_i = W_i^T zacc_i ; zacc[block t] -= L[i,t]^T a_i  (t < i).
-// grid.x = (i+1) * B; tile index t == i is the one that writes a_i.
-__global__ __launch_bounds__(256) void trsv_bwd_step_kernel(const float* __restrict__ A, const float* __restrict__ Winv,
-                                                            float* __restrict__ zacc, float* __restrict__ out, int Np,
-                                                            int i, int B) {
-    __shared__ float s[TS * VLD];
-    __shared__ float v[TS], ai[TS];
-    const int n = Np / TS;
-    int t, b;
-    decode_tile_batch(i + 1, B, t, b);
-    const float* Ab = A + (int64_t)b * Np * Np;
-    float* zb = zacc + (int64_t)b * Np;
-    const int tid = threadIdx.x;
-    load_tile_lds(Winv + ((int64_t)b * n + i) * TS * TS, TS, s);
-    if (tid < TS) v[tid] = zb[i * TS + tid];
-    __syncthreads();
-    if (tid < TS) {
-        float a = 0.f;
-        for (int p = tid; p < TS; ++p) a += s[p * VLD + tid] * v[p];   // W^T: column tid
-        ai[tid] = a;
-        if (t == i) out[(int64_t)b * Np + i * TS + tid] = a;
-    }
-    __syncthreads();
-    if (t == i) return;
-    load_tile_lds(Ab + (int64_t)i * TS * Np + (int64_t)t * TS, Np, s);
-    __syncthreads();
-    if (tid < TS) {
-        float a = 0.f;
-        for (int p = 0; p < TS; ++p) a += s[p * VLD + tid] * ai[p];
-        zb[t * TS + tid] -= a;
-    }
-}
-
 // ----------------------------------------------------------------------------- trtri
 // Y = L^-T (upper, row-major).  Block row i of X = L^-1 is block column i of Y:
 //     X[i,j] = -W_i * T ,  T = sum_{m=j}^{i-1} L[i,m] X[m,j]      (j < i),     X[i,i] = W_i
@@ -1079,46 +999,6 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
     if (!launches_host) return -13;
     return volt_internal_factor(K, ldk, bsk, sigma2, 0.f, A, Winv, Y, info, nullptr, nullptr, nullptr, B, N, stream,
                                 ms_host, launches_host, nullptr, nullptr);
-}
-
-int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out, float* scratch, int B,
-                        int Np, void* stream) {
-    if (!A) return -1;
-    if (!Winv) return -2;
-    if (!rhs) return -3;
-    if (!out) return -4;
-    if (!scratch) return -5;
-    if (B < 0) return -6;
-    if (Np < TS || Np % TS) return -7;
-    if (B == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int n = Np / TS;
-    hipError_t e = hipMemcpyAsync(scratch, rhs, sizeof(float) * (size_t)B * Np, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(trsv_fwd_step_kernel, dim3((n - i) * B), dim3(256), 0, s, A, Winv, scratch, out, Np, i, B);
-    VOLT_LAUNCH_CHECK();
-    return 0;
-}
-
-int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, float* out, float* scratch, int B,
-                          int Np, void* stream) {
-    if (!A) return -1;
-    if (!Winv) return -2;
-    if (!rhs) return -3;
-    if (!out) return -4;
-    if (!scratch) return -5;
-    if (B < 0) return -6;
-    if (Np < TS || Np % TS) return -7;
-    if (B == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int n = Np / TS;
-    hipError_t e = hipMemcpyAsync(scratch, rhs, sizeof(float) * (size_t)B * Np, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    for (int i = n - 1; i >= 0; --i)
-        hipLaunchKernelGGL(trsv_bwd_step_kernel, dim3((i + 1) * B), dim3(256), 0, s, A, Winv, scratch, out, Np, i, B);
-    VOLT_LAUNCH_CHECK();
-    return 0;
 }
 
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream) {

@@ -5,9 +5,9 @@
 // Structure used (and only this): the train block of every sample's matrix is the same
 // (train_stack_vol = log_vol_path.repeat(S,1), :72) and the cross block between the train points and
 // the appended points is sample-independent.  So per series the host factors K_NN once (HIP potrf)
-// and solves K_NN x = u once (fp64-refined, volt_amd/rollout_engine.py); with rho = u'x (= q'q,
-// q = L^-1 u) and tau = x'r_tr (= q'z_tr) every sample owns a small dense bordered problem of
-// dimension idx <= H:
+// and solves K_NN x = u once (volt_amd/rollout_engine.py: in closed form, or on the fp64
+// factorisation); with rho = u'x (= q'q, q = L^-1 u) and tau = x'r_tr (= q'z_tr) every sample owns a small dense
+// bordered problem of dimension idx <= H:
 //     S_s   = C_s - rho 11'            (Schur complement of the appended points),  L_s = chol(S_s)
 //     w_s   = L_s^-1 (k*_s - rho 1),   z_s = L_s^-1 (r_s - tau 1)
 //     mean  = tau + w_s'z_s + m(x*),   var = k** - rho - w_s'w_s
@@ -58,8 +58,8 @@ __device__ __forceinline__ float family_mean(int mode, int idx, int k, int lane,
 
 struct RolloutParams {
     // per series g (G series), all device pointers
-    const float* rho;        // [G]   q'q
-    const float* tau;        // [G]   q'z_tr
+    const double* rho;       // [G]   q'q     (fp64: it is subtracted from the CumTrapz sums, see `base` below)
+    const double* tau;       // [G]   q'z_tr
     const double* acc0;      // [G]   fp64 running CumTrapz sum through train point N-1 (full weights)
     const float* dx;         // [G]   x[1]-x[0]
     const float* hist_y;     // [G,k] padded train series tail  Y[N-k .. N-1]
@@ -73,7 +73,8 @@ struct RolloutParams {
     const float* z;          // [G,S,H]
     float* samples;          // [G,S,H]
     float* Ls;               // [G,S,H,H] scratch: rows of the per-sample factor
-    int* info;               // [G,S] 0 or 1-based horizon step of the first non-positive pivot / variance
+    int* info;               // [G,S] 0; +step (1-based) of the first non-positive pivot of L_s (a local jitter was
+                             //       applied); -step if the predictive variance stayed <= 0 after the jitter ladder
     int G, S, H, k;
     int mean_mode;           // 0 ewma, 1 dewma, 2 tewma, 3 meanrevert
     int use_theta;
@@ -101,18 +102,21 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     __syncthreads();
     if (s >= p.S) return;
 
-    const float rho = p.rho[g], tau = p.tau[g], dx = p.dx[g], hdx = dx * 0.5f;
+    const float tau = (float)p.tau[g], dx = p.dx[g], hdx = dx * 0.5f;
     const size_t row = ((size_t)g * p.S + s) * H;
     const float* pv = p.pred_vol + row;
     const float* zz = p.z + row;
     float* out = p.samples + row;
     const int Hs = (H + 3) & ~3;                            // row stride of the factor store (16-byte rows)
     float* Ls = p.Ls + ((size_t)g * p.S + s) * H * Hs;
-    double acc = p.acc0[g];
+    // base = U_s[N+a] - rho, carried in fp64: the entries of the Schur complement S_s = C_s - rho 11' are
+    // ~ dx vol^2 (1e-4 .. 1e-9) on top of rho ~ V[N-1] ~ 1, so forming U_s and rho in fp32 first loses them
+    // (62 of 80,000 paths at N = 4096 lost a pivot that way); the differences themselves are fine in fp32.
+    double base = p.acc0[g] - p.rho[g];
     float ema_prev = (p.mean_mode == 3) ? p.ema_prev[g] : 0.f;
     int bad = 0;
 
-    float U[4] = {0.f, 0.f, 0.f, 0.f};      // U_s[N+a]  for a = 4 lane + t
+    float U[4] = {0.f, 0.f, 0.f, 0.f};      // U_s[N+a] - rho  for a = 4 lane + t
     float rd[4] = {0.f, 0.f, 0.f, 0.f};     // 1 / L_s[a][a]
     float zs[4] = {0.f, 0.f, 0.f, 0.f};     // z_s[a]
     float wv[4];
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     for (int idx = 0; idx < H; ++idx) {
         // ---- w_s = L_s^-1 (U_s - rho): row-oriented forward substitution against stored rows ----
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wv[t] = U[t] - rho;
+        for (int t = 0; t < 4; ++t) wv[t] = U[t];
         // Rows are streamed in groups of 4 with the next group's loads issued before the current
         // group is consumed: the substitution itself is a dependent chain (row a needs w[a-1]), but the
         // addresses are not, so 8 rows per wave stay in flight and the stream runs at memory bandwidth
@@ -179,24 +183,24 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         // ---- conditional and draw (rollout_utils.py:36-53) --------------------------------------
         const float v = pv[idx];
         const float v2 = v * v;
-        const float kss = (float)(acc + (double)__fmul_rn(hdx, v2));       // last CumTrapz weight halved
+        const float kss = (float)(base + (double)__fmul_rn(hdx, v2));      // k** - rho; last CumTrapz weight halved
         float pm = tau + wz + mstar;
         if (p.use_theta) pm -= p.theta * (pm - p.latent[g]);
-        float pvar = kss - rho - ww;
+        float pvar = kss - ww;
         if (!(pvar > 0.f)) {                                 // psd_safe_cholesky(pred_cov, jitter) ladder
             float jit = p.jitter;
             int tries = 0;
             while (!(pvar + jit > 0.f) && tries < 2) { jit *= 10.f; ++tries; }
             if (pvar + jit > 0.f) pvar += jit;
-            else { if (!bad) bad = idx + 1; pvar = 0.f; }
+            else { if (bad >= 0) bad = -(idx + 1); pvar = 0.f; }     // ladder exhausted: the reference raises NotPSDError
         }
         const float smp = sqrtf(pvar) * zz[idx] + pm;
         if (lane == 0) out[idx] = smp;
 
         // ---- append the point to the conditioning set --------------------------------------------
-        acc += (double)__fmul_rn(dx, v2);                    // full weight from now on
-        const float Unew = (float)acc;
-        float d2 = Unew - rho - ww;                          // next pivot of L_s
+        base += (double)__fmul_rn(dx, v2);                   // full weight from now on
+        const float Unew = (float)base;
+        float d2 = Unew - ww;                                // next pivot of L_s
         if (!(d2 > 0.f)) {
             if (!bad) bad = idx + 1;
             d2 = fmaxf(p.jitter, 1e-12f);
@@ -291,7 +295,7 @@ size_t volt_rollout_scratch_bytes(int G, int S, int H) {
     return (size_t)G * S * H * ((H + 3) & ~3) * sizeof(float);      // rows padded to 16 bytes
 }
 
-int volt_rollout_bordered_f32(const float* rho, const float* tau, const double* acc0, const float* dx,
+int volt_rollout_bordered_f32(const double* rho, const double* tau, const double* acc0, const float* dx,
                               const float* hist_y, const float* hist_e1, const float* hist_e2, const float* ema_prev,
                               const float* mr_latent, const float* latent, const float* w, const float* pred_vol,
                               const float* z, float* samples, float* scratch, int* info, int G, int S, int H, int k,

@@ -472,8 +472,12 @@ def psd_safe_cholesky(A, upper=False, out=None, jitter=None, max_tries=3):
 
 
 def _safe_factor(A, jitter=None, max_tries=3):
+    """psd_safe_cholesky's retry policy around the HIP potrf, in A's own dtype (fp32 or fp64; anything else is
+    computed in fp32)."""
     n = A.shape[-1]
-    A3 = A.reshape(-1, n, n).to(torch.float32)
+    A3 = A.reshape(-1, n, n)
+    if A3.dtype != torch.float64:
+        A3 = A3.to(torch.float32)
     f = ops.potrf(A3)
     if not bool((f.info != 0).any().item()):
         return f, 0.0

@@ -98,43 +98,50 @@ class CholeskyFactor:
 
 
 def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0.0) -> CholeskyFactor:
-    """Batched Cholesky of K + (sigma2 + jitter) I.  K [B,N,N] fp32 (only the lower triangle is read)."""
+    """Batched Cholesky of K + (sigma2 + jitter) I.  K [B,N,N] fp32 or fp64 (only the lower triangle is read); the
+    factor keeps K's dtype (fp32: volt_potrf_f32 on v_mfma_f32_32x32x2; fp64: volt_potrf_f64 on v_mfma_f64_16x16x4)."""
     _need_gpu(K, sigma2)
-    if K.dtype != torch.float32 or K.ndim != 3:
-        raise ValueError("potrf expects a [B,N,N] fp32 tensor")
+    if K.dtype not in (torch.float32, torch.float64) or K.ndim != 3:
+        raise ValueError("potrf expects a [B,N,N] fp32 or fp64 tensor")
     if K.stride(-1) != 1:
         K = K.contiguous()
     B, n, _ = K.shape
     Np = padded_n(n)
-    A = torch.empty(B, Np, Np, dtype=torch.float32, device=K.device)
-    Winv = torch.empty(B, Np // TILE, TILE, TILE, dtype=torch.float32, device=K.device)
+    A = torch.empty(B, Np, Np, dtype=K.dtype, device=K.device)
+    Winv = torch.empty(B, Np // TILE, TILE, TILE, dtype=K.dtype, device=K.device)
     info = torch.empty(B, dtype=torch.int32, device=K.device)
     s2 = None
     if sigma2 is not None:
-        s2 = sigma2.to(torch.float32).expand(B).contiguous()
+        s2 = sigma2.to(K.dtype).expand(B).contiguous()
     L = _lib.lib()
     st = _lib.stream_ptr()
-    _lib.check(L.volt_prepare_f32(K.data_ptr(), K.stride(1), K.stride(0), s2.data_ptr() if s2 is not None else None,
-                                  float(jitter), A.data_ptr(), B, n, st), "volt_prepare")
-    _lib.check(L.volt_potrf_f32(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
+    prep, fac = ((L.volt_prepare_f32, L.volt_potrf_f32) if K.dtype == torch.float32
+                 else (L.volt_prepare_f64, L.volt_potrf_f64))
+    _lib.check(prep(K.data_ptr(), K.stride(1), K.stride(0), s2.data_ptr() if s2 is not None else None,
+                    float(jitter), A.data_ptr(), B, n, st), "volt_prepare")
+    _lib.check(fac(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
     return CholeskyFactor(A, Winv, info, n)
 
 
 def _pad_rhs(f: CholeskyFactor, rhs: torch.Tensor) -> torch.Tensor:
     B, Np = f.A.shape[0], f.A.shape[1]
-    out = torch.zeros(B, Np, dtype=torch.float32, device=f.A.device)
+    out = torch.zeros(B, Np, dtype=f.A.dtype, device=f.A.device)
     out[:, : f.n] = rhs.reshape(B, f.n)
     return out
 
 
 def trsv(f: CholeskyFactor, rhs: torch.Tensor, transpose: bool = False) -> torch.Tensor:
-    """L^-1 rhs (or L^-T rhs).  rhs [B,N] -> [B,N]."""
+    """L^-1 rhs (or L^-T rhs) in the factor's dtype.  rhs [B,N] -> [B,N].  One launch (csrc/trsv.hip)."""
     _need_gpu(rhs)
     r = _pad_rhs(f, rhs)
     out = torch.empty_like(r)
     scratch = torch.empty_like(r)
     B, Np = r.shape
-    fn = _lib.lib().volt_trsv_lower_t_f32 if transpose else _lib.lib().volt_trsv_lower_f32
+    L = _lib.lib()
+    if f.A.dtype == torch.float32:
+        fn = L.volt_trsv_lower_t_f32 if transpose else L.volt_trsv_lower_f32
+    else:
+        fn = L.volt_trsv_lower_t_f64 if transpose else L.volt_trsv_lower_f64
     _lib.check(fn(f.A.data_ptr(), f.Winv.data_ptr(), r.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, Np,
                   _lib.stream_ptr()), "volt_trsv")
     return out[:, : f.n]
@@ -146,7 +153,9 @@ def cholesky_solve(f: CholeskyFactor, rhs: torch.Tensor) -> torch.Tensor:
 
 
 def trtri(f: CholeskyFactor) -> torch.Tensor:
-    """Y = L^-T as an upper-triangular [B,N,N] tensor."""
+    """Y = L^-T as an upper-triangular [B,N,N] tensor (fp32 factors only)."""
+    if f.A.dtype != torch.float32:
+        raise ValueError("trtri: the triangular inverse exists for fp32 factors only")
     B, Np = f.A.shape[0], f.A.shape[1]
     Y = torch.empty(B, Np, Np, dtype=torch.float32, device=f.A.device)
     _lib.check(_lib.lib().volt_trtri_f32(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()),

@@ -1,9 +1,10 @@
 """Host side of the bordered rollout engine (csrc/rollout.hip, DESIGN.md "Rollouts").
 
 Per series, once:  U = CumTrapz weights with the LAST train weight un-halved (the halving moves to
-the test point, VolKernel.py:8-9 applied to the stacked path of rollout_utils.py:17-20), K_NN =
-fill(U), L = potrf(K_NN) with the psd_safe_cholesky jitter policy (:35), q = L^-1 u, z_tr = L^-1
-r_tr, rho = q'q, tau = q'z_tr.  Then ONE kernel launch walks all H horizon steps for every sample.
+the test point, VolKernel.py:8-9 applied to the stacked path of rollout_utils.py:17-20), and the two
+scalars the shared train block K_NN = fill(U) contributes to every sample's bordered system,
+rho = u'K_NN^-1 u and tau = u'K_NN^-1 r_tr (train_block_terms).  Then ONE kernel launch walks all H
+horizon steps for every sample.
 """
 from __future__ import annotations
 
@@ -12,7 +13,7 @@ import warnings
 import torch
 
 from . import _lib, ops
-from .gp import NumericalWarning, _safe_factor, _dense as _dense_cov
+from .gp import NotPSDError, NumericalWarning, _safe_factor, _dense as _dense_cov
 from .means import DEWMAMean, EWMAMean, MeanRevertingEMAMean, TEWMAMean
 
 _MODES = {EWMAMean: 0, DEWMAMean: 1, TEWMAMean: 2, MeanRevertingEMAMean: 3}
@@ -57,50 +58,39 @@ def _family_state(log_y, k, mean_mode, mr_theta=0.5, mr_latent=None):
     return m_tr, _tail(log_y.to(f32), k), hist_e1, hist_e2, ema_prev, mrl, w
 
 
-def _refined_solve(K, fct, rhs, jitter_used=0.0, iters=30, tol=1e-12):
-    """x = (K + jitter I)^-1 rhs to fp64 accuracy: conjugate gradients in fp64 on the device,
-    preconditioned by the fp32 HIP Cholesky factor (two triangular solves per iteration; the fp64
-    K p products are plain library matmuls).  With the factor as preconditioner the spectrum of the
-    preconditioned operator is clustered at 1 even when cond(K) eps_32 > 1, so a handful of
-    iterations suffice where plain iterative refinement would stall."""
-    Kd = K.double()
-    b = rhs.double()
+MAX_H = 256          # horizon limit of volt_rollout_bordered_f32 (a lane owns 4 of the <= 256 appended points)
 
-    def matvec(v):
-        out = torch.matmul(Kd, v.unsqueeze(-1)).squeeze(-1)
-        return out + jitter_used * v if jitter_used else out
 
-    def prec(r):
-        scale = r.abs().amax(-1, keepdim=True).clamp_min(1e-300)        # keep fp32 solves in range
-        return ops.cholesky_solve(fct, (r / scale).float()).double() * scale
+def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
+    """rho = u'K^-1 u and tau = u'K^-1 r_tr for the shared train block K = fill(U), in fp64 [G].
 
-    x = prec(b)
-    r = b - matvec(x)
-    zv = prec(r)
-    pdir = zv.clone()
-    rz = (r * zv).sum(-1, keepdim=True)
-    bnorm = b.norm(dim=-1, keepdim=True).clamp_min(1e-300)
-    for _ in range(iters):
-        if bool(((r.norm(dim=-1, keepdim=True) / bnorm) < tol).all()):
-            break
-        Ap = matvec(pdir)
-        alpha = rz / (pdir * Ap).sum(-1, keepdim=True)
-        x = x + alpha * pdir
-        r = r - alpha * Ap
-        zv = prec(r)
-        rz_new = (r * zv).sum(-1, keepdim=True)
-        pdir = zv + (rz_new / rz) * pdir
-        rz = rz_new
-    return x
+    u, the covariance between the train points and ANY appended point, is U itself -- k(x*, x_i) = V[min(i, *)] =
+    U[i] -- which is also the last column of K.  Hence K^-1 u = e_{N-1} exactly and
+        rho = U[N-1],   tau = r_tr[N-1]                                     (solve="closed", the default).
+    solve="factor" takes the general route the reference takes (rollout_utils.py:35-36: factor the train block,
+    two solves) -- in fp64 on volt_potrf_f64 / volt_trsv_*_f64, because the noise-free block has condition number
+    1e6 (N = 400) .. 1e8 (N = 4096) and an fp32 factor cannot carry it; it is what the tests hold the closed form
+    against, and the route to take should a caller ever need jitter on the train block."""
+    U64 = U.double()
+    if solve == "closed":
+        return U64[:, -1].contiguous(), r_tr[:, -1].double().contiguous()
+    if solve != "factor":
+        raise ValueError(f"unknown train-block solve {solve!r}")
+    fct, _ = _safe_factor(ops.fill(U64), jitter)                 # psd_safe_cholesky(K_tr, 1e-4), :35, in fp64
+    q = ops.trsv(fct, U64)                                       # L^-1 u
+    ztr = ops.trsv(fct, r_tr.double())                           # L^-1 r_tr
+    return (q * q).sum(-1).contiguous(), (q * ztr).sum(-1).contiguous()
 
 
 def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode, k, latent_mean=None, theta=None,
-                   mr_theta=0.5, mr_latent=None, jitter=1e-4):
+                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="closed"):
     """Batched engine entry.  train_x [N]; log_y, log_vol_path [G,N]; test_x [H]; pred_vol, z [G,S,H].
     Returns (samples [G,S,H] on the device, info [G,S])."""
     dev = train_x.device
     G, N = log_y.shape
     S, H = pred_vol.shape[-2:]
+    if H > MAX_H:
+        raise ValueError(f"bordered rollouts support horizons up to {MAX_H} steps (got {H}); use engine='dense'")
     f32 = torch.float32
     vol = log_vol_path.exp().to(f32)
     x = train_x.to(f32)
@@ -108,20 +98,15 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
     # U: CumTrapz over [train, first test point] keeps full weight on train point N-1
     xe = torch.cat((x, test_x[:1].to(f32)))
     U = ops.cumtrapz(torch.cat((vol, vol[:, -1:]), -1), xe, square=True)[:, :N].contiguous()
-    wts = torch.full((N,), 1.0, device=dev, dtype=f32) * (x[1] - x[0])
-    wts[0] *= 0.5
-    acc0 = (wts * (vol * vol)).double().sum(-1).contiguous()                  # fp64 running sum through N-1
-    K = ops.fill(U)
-    fct, used = _safe_factor(K, jitter)                                        # psd_safe_cholesky(K_tr, 1e-4), :35
+    # The running sum the appended points continue from is the fp32 entry the train block itself holds for point
+    # N-1 (K's entries ARE these fp32 prefixes); from there on the kernel adds the increments in fp64.
+    acc0 = U[:, -1].double().contiguous()
     # train residuals with the model's mean family
     m_tr, hist_y, hist_e1, hist_e2, ema_prev, mrl, w = _family_state(log_y, k, mean_mode, mr_theta, mr_latent)
     r_tr = (log_y.to(f32) - m_tr).contiguous()
-    # rho = u'K^-1 u and tau = u'K^-1 r_tr enter every sample's Schur complement C_s - rho 11', whose
-    # entries are ~dx vol^2 while rho ~ V[N-1]: they must be accurate far beyond fp32 round-off times
-    # cond(K_NN) (1e6 at N=400, 1e8 at N=4096).  One K^-1 u solve, refined in fp64.
-    xu = _refined_solve(K, fct, U, used)
-    rho = (U.double() * xu).sum(-1).to(f32).contiguous()
-    tau = (r_tr.double() * xu).sum(-1).to(f32).contiguous()
+    # rho = u'K^-1 u and tau = u'K^-1 r_tr enter every sample's Schur complement C_s - rho 11', whose entries are
+    # ~dx vol^2 while rho ~ V[N-1]: fp64, and the kernel keeps (CumTrapz sum - rho) in fp64 too.
+    rho, tau = train_block_terms(U, r_tr, solve, jitter)
     samples = torch.empty(G, S, H, dtype=f32, device=dev)
     info = torch.empty(G, S, dtype=torch.int32, device=dev)
     nbytes = _lib.lib().volt_rollout_scratch_bytes(G, S, H)
@@ -159,8 +144,13 @@ def rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean,
     samples, info = rollout_series(train_x, log_y.unsqueeze(0), model.log_vol_path.unsqueeze(0), test_x,
                                    pred_vol.unsqueeze(0), z.unsqueeze(0), _MODES[type(mm)], mm.k,
                                    latent_mean, theta, **kw)
-    bad = info[0] != 0
-    if bool(bad.any()):
+    if bool((info[0] != 0).any()):
+        exhausted = info[0] < 0
+        if bool(exhausted.any()):           # psd_safe_cholesky(pred_cov, jitter=1e-4) raises here, rollout_utils.py:46
+            raise NotPSDError(f"rollouts: predictive variance not positive after the jitter ladder for "
+                              f"{int(exhausted.sum())} of {S} sample paths (first at horizon step "
+                              f"{int((-info[0][exhausted]).min())})")
+        bad = info[0] > 0
         warnings.warn(f"rollouts: {int(bad.sum())} of {S} sample paths hit a non-positive pivot "
                       f"(first at horizon step {int(info[0][bad].min())}); jitter was applied", NumericalWarning)
     samples = samples[0]

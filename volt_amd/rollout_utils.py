@@ -144,6 +144,8 @@ def Rollouts(train_x, train_y, test_x, model, nsample=50, method="volt", theta=N
     pred_vol = pred_vol.to(train_x.device)
     if z is not None:
         z = z.to(train_x.device)
+    if engine == "bordered" and ntest > 256:
+        engine = "dense"                         # the bordered kernel holds <= 256 appended points per sample
     if engine == "bordered":
         from .rollout_engine import rollouts_bordered
         return rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean, theta)
