@@ -36,21 +36,22 @@ HBM_PEAK_GBS = 8000.0
 
 
 def kernel_class_flops(B: int, Np: int):
-    """ALGORITHMIC flops of each launch class over one factorisation + inverse of B matrices, counted so that the
+    """ALGORITHMIC flops of the two launch classes over one factorisation + inverse of B matrices, counted so that the
     Cholesky parts sum to exactly Np^3/3 and the triangular inverse to Np^3/3 (work the kernels do on structural
     zeros -- the upper half of diagonal tiles, the zero half of triangular operands -- is NOT credited):
-      P1 tile (i,k): 2*128^3*k off the diagonal, 128^3*k on it;  P2: 128^3/3 (factor) and 128^3/3 (inverse, credited
-      to the trtri total);  P3 tile: 128^3;  trtri tile (i,j), i>j: 2*128^3*(i-j)."""
+      panel tile (i,k), i>k: 2*128^3*k (update) + 128^3 (solve against the triangular W_k);  diagonal tile: 128^3*k
+      (update) + 128^3/3 (factor) + 128^3/3 (inverse, credited to the trtri total);  trtri tile (i,j), i>j: 2*128^3*(i-j).
+    Returns [step launches (block columns 0..n-1 with trtri rows 0..n-2 aboard), the trailing trtri row]."""
     n, c = Np // 128, float(128 ** 3)
-    upd = sum((n - k - 1) * k * 2 * c + k * c for k in range(1, n))      # P1
-    chol_diag = n * c / 3                                                # P2, factor part
-    trsm = sum(n - k - 1 for k in range(n)) * c                          # P3
+    upd = sum((n - k - 1) * k * 2 * c + k * c for k in range(1, n))      # panel + diagonal updates
+    chol_diag = n * c / 3
+    trsm = sum(n - k - 1 for k in range(n)) * c
     assert abs(upd + chol_diag + trsm - Np ** 3 / 3) < 1e-6 * Np ** 3
     row = lambda i: sum(2 * c * (i - j) for j in range(i))               # trtri row i (off-diagonal tiles)
-    tri_diag = n * c / 3                                                 # P2, inverse part
+    tri_diag = n * c / 3
     assert abs(sum(row(i) for i in range(n)) + tri_diag - Np ** 3 / 3) < 1e-6 * Np ** 3
-    fused = upd + chol_diag + tri_diag + sum(row(i) for i in range(n - 1))   # factor_step_kernel, steps 0..n-1
-    return [B * fused, 0.0, B * trsm, B * row(n - 1)]
+    step = upd + chol_diag + trsm + tri_diag + sum(row(i) for i in range(n - 1))
+    return [B * step, B * row(n - 1)]
 
 
 def main():
@@ -148,7 +149,8 @@ def main():
     bad = int((info != 0).sum().item())
     loss = float(red[0].item()) / (B * world)
 
-    # ---- roofline leg: per-launch HIP events around each kernel class of one factor+inverse
+    # ---- roofline leg: per-launch HIP events (on the stream each launch goes to) around every launch of one
+    # factor+inverse in the SAME schedule the timed steps use; per class the union of the launch intervals
     roof = None
     extra = {}
     if rank == 0:
@@ -159,27 +161,24 @@ def main():
         Winv = torch.empty(B, Np // 128, 128, 128, device=dev)
         Y = torch.empty(B, Np, Np, device=dev)
         inf = torch.empty(B, dtype=torch.int32, device=dev)
-        ms = (ctypes.c_float * 4)()
-        cnt = (ctypes.c_int * 4)()
-        tot = np.zeros(4)
-        reps = 2
-        for _ in range(reps):
-            _lib.check(L.volt_profile_factor_f32(K.data_ptr(), n, n * n, s2.data_ptr(), A.data_ptr(), Winv.data_ptr(),
-                                                 Y.data_ptr(), inf.data_ptr(), B, n, _lib.stream_ptr(), ms, cnt),
-                       "profile")
-            tot += np.array(list(ms))
-        tot /= reps
-        # class 0 = factor_step_kernel<true> (n-1 launches per factorisation: look-ahead + P1(k) + P2(k) + trtri row k-1,
-        # C tiles read from K); class 1 = factor_diag0_kernel (block column 0); class 3 = the trailing trtri row alone
-        names = ["factor_step_kernel<true>", "potrf_trsm_kernel", "factor_step_kernel<false>(last trtri row)",
-                 "factor_diag0_kernel"]
-        f4 = kernel_class_flops(B, Np)
-        c3 = 2.0 * 128 ** 3 / 3 * B                       # factor + inverse of one 128 block per matrix
-        flops = [f4[0] - c3, f4[2], f4[3], c3]
-        cnt = [cnt[0], cnt[2], cnt[3], cnt[1]]
-        tot = np.array([tot[0], tot[2], tot[3], tot[1]])
-        dom = int(np.argmax(tot))
-        ach = flops[dom] / (tot[dom] * 1e-3) / 1e12
+
+        def profile(groups, reps=3):
+            ms_sum, ms_un, cnt = (ctypes.c_float * 2)(), (ctypes.c_float * 2)(), (ctypes.c_int * 2)()
+            tot_s, tot_u = np.zeros(2), np.zeros(2)
+            for _ in range(reps):
+                _lib.check(L.volt_profile_factor_f32(K.data_ptr(), n, n * n, s2.data_ptr(), A.data_ptr(), Winv.data_ptr(),
+                                                     Y.data_ptr(), inf.data_ptr(), B, n, groups, _lib.stream_ptr(),
+                                                     ms_sum, ms_un, cnt, None), "profile")
+                tot_s += np.array(list(ms_sum))
+                tot_u += np.array(list(ms_un))
+            return tot_s / reps, tot_u / reps, list(cnt)
+
+        names = ["factor_step_kernel<true>", "factor_step_kernel<false>(last trtri row)"]
+        flops = kernel_class_flops(B, Np)
+        sum_t, un_t, cnt = profile(0)                       # the schedule the timed steps ran in
+        sum_1, un_1, cnt1 = profile(1)                      # lockstep: one stream, whole batch per launch
+        dom = int(np.argmax(un_t))
+        ach = flops[dom] / (un_t[dom] * 1e-3) / 1e12
         traffic = None
         try:      # HBM bytes per launch from the PMC passes (scripts/pmc.sh + scripts/pmc_traffic.py), same workload only
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -187,15 +186,22 @@ def main():
                 traffic = round(pj["kernels"][names[dom].split("(")[0]]["bytes_per_launch"])
         except Exception:
             traffic = None
+        ngroups = cnt[0] // max(1, cnt1[0])
         roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
                 "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
-                "launches": int(cnt[dom]), "avg_launch_ms": round(float(tot[dom] / max(1, cnt[dom])), 4),
-                "measured_in": "lockstep schedule (one stream, whole batch per launch): per-launch HIP events; the timed "
-                               "steps overlap 4 groups of 16 series on 4 streams, where launches of different groups "
-                               "share the GPU and per-launch durations are not separable -- see roofline_step"}
-        extra = {"kernel_ms": {nm: round(float(t), 3) for nm, t in zip(names, tot)},
-                 "kernel_tflops": {nm: round(f / (t * 1e-3) / 1e12, 2) for nm, f, t in zip(names, flops, tot)},
-                 "factor_plus_inverse_ms": round(float(tot.sum()), 3),
+                "launches": int(cnt[dom]), "avg_launch_ms": round(float(sum_t[dom] / max(1, cnt[dom])), 4),
+                "class_ms": round(float(un_t[dom]), 3),
+                "measured_in": f"the timed schedule ({ngroups} groups of {B // max(1, ngroups)} series on {ngroups} streams): HIP "
+                               "events on each launch's own stream; achieved = algorithmic flops of the class / the UNION of "
+                               "its launch intervals (class_ms); avg_launch_ms = mean duration of one group's launch while the "
+                               "other groups' launches share the GPU (traffic is per whole-batch launch, lockstep PMC passes)",
+                "lockstep": {"class_ms": round(float(un_1[dom]), 3), "launches": int(cnt1[dom]),
+                             "avg_launch_ms": round(float(sum_1[dom] / max(1, cnt1[dom])), 4),
+                             "achieved": round(flops[dom] / (un_1[dom] * 1e-3) / 1e12, 2),
+                             "frac": round(flops[dom] / (un_1[dom] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
+        extra = {"kernel_ms": {nm: round(float(t), 3) for nm, t in zip(names, un_t)},
+                 "kernel_tflops": {nm: round(f / (t * 1e-3) / 1e12, 2) for nm, f, t in zip(names, flops, un_t)},
+                 "factor_plus_inverse_ms": round(float(un_t.sum()), 3),
                  "fill_ms": round(fill_ms, 3), "fill_GBps": round(fill_gbs, 1),
                  "fill_frac_of_hbm_peak": round(fill_gbs / HBM_PEAK_GBS, 4)}
         if args.no_aux_legs:
@@ -290,7 +296,8 @@ def main():
                               "bound": "mfma", "achieved": round(world * B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
                               "peak": FP32_MFMA_PEAK_TF * world, "unit": "TFLOP/s",
                               "frac": round(B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)},
-            "schedule": {"groups": int(os.environ.get("VOLT_GROUPS", 4)), "streams": "library-internal, forked/joined on the caller's stream"},
+            "schedule": {"groups": (roof or {}).get("launches", 0) // max(1, (roof or {}).get("lockstep", {}).get("launches", 1)),
+                         "streams": "library-internal, forked/joined on the caller's stream"},
             "cpu_baseline": cpu,
         }
         line.update(extra)

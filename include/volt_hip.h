@@ -10,8 +10,11 @@
  *     caller (e.g. torch `tensor.data_ptr()`).  The library never allocates, frees or retains
  *     caller-visible memory; scratch comes from the caller via the *_workspace_bytes queries.
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); work is
- *     enqueued asynchronously and the call returns immediately.  Re-entrant across streams; no
- *     mutable global state.
+ *     enqueued asynchronously and the call returns immediately.  Re-entrant across streams.  Library state:
+ *     one pool of auxiliary streams and fork/join events per device, created on first use and kept for the
+ *     life of the process (the batched factorisation runs groups of matrices on them, forked from and joined
+ *     back into `stream`); calls on one device serialise on the host while they ENQUEUE, never on the device.
+ *     Nothing else is retained between calls.
  *   - Return value: 0 = enqueued; -k = argument k (1-based) is invalid; >0 = hipError_t of a
  *     failed launch.  A matrix that is not positive definite is NOT an error return: LAPACK-style
  *     `info[b]` (0, or the 1-based index of the first non-positive / NaN pivot) is written to a
@@ -75,10 +78,13 @@ int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
 
 /* ---- a5/a6: batched Cholesky  (torch.linalg.cholesky via gpytorch; psd_safe_cholesky at
  * rollout_utils.py:35, VoltronGP.py:83, VoltMagpie.py:87) ------------------------------------
- * In-place lower Cholesky of A [B,Np,Np] (left-looking, 128-wide panels, fp32 MFMA updates).
- * Winv [B, Np/128, 128, 128] receives the inverses of the diagonal blocks (used by the solves).
- * info [B] int32.  Diagonal tiles come back with their strict upper triangle zeroed; tiles above
- * the diagonal are never touched. */
+ * In-place lower Cholesky of A [B,Np,Np] (left-looking, 128-wide panels, fp32 MFMA; ONE launch per block
+ * column: diagonal tile, panel tiles (update + solve), look-ahead).  Winv [B, Np/128, 128, 128] receives the
+ * inverses of the diagonal blocks (used by the solves; while the call runs, the first word of each block is also
+ * the hand-off flag between the diagonal workgroup and the panel tiles of its launch).  info [B] int32: 0, the
+ * 1-based index of the first non-positive / NaN pivot, or INT_MIN for an internal hand-off time-out (never
+ * expected).  Diagonal tiles come back with their strict upper triangle zeroed; tiles above the diagonal are
+ * never touched. */
 int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream);
 
 /* fp64 twins on v_mfma_f64_16x16x4_f64 (the reference keeps the caller's dtype, VolKernel.py:28-33; the
@@ -136,20 +142,23 @@ int volt_rollout_shared_f32(const float* hist_y, const float* hist_e1, const flo
                             int H, int k, int mean_mode, float mr_theta, void* stream);
 
 /* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
- * Runs exactly the factorisation of volt_mll_step_f32 (block column 0 copied from K, the rest read from
- * K inside the panel update; with Y != NULL also the triangular inverse, co-launched with the diagonal
- * blocks) with every launch bracketed by HIP events on `stream`, synchronises, and writes to HOST
- * arrays the summed milliseconds and launch counts per kernel class:
- *   [0] factor_step_kernel (look-ahead + P1(k) + P2(k) + trtri row k-1 in one grid, k >= 1)
- *   [1] factor_diag0_kernel (the diagonal blocks of block column 0)   [2] potrf_trsm (P3)
- *   [3] factor_step_kernel carrying only the last trtri row. */
+ * Runs exactly the factorisation of volt_mll_step_f32 (block column 0 copied from K, the rest read from K inside
+ * the tiles; with Y != NULL also the triangular inverse, co-launched) in the schedule the step uses -- `groups` = 0:
+ * the library's default split of the batch over its streams; 1: one stream, the whole batch per launch -- with every
+ * launch bracketed by HIP events on the stream it is launched on.  Synchronises, and writes to HOST arrays, per
+ * kernel class, the summed launch durations, the length of the UNION of the launch intervals (what the class
+ * occupied of the wall clock when launches of several groups overlap) and the launch counts:
+ *   [0] factor_step_kernel with a factorisation part (diagonal tile + look-ahead + panel tiles (update + solve) +
+ *       trtri row k-1 in one grid, k = 0 .. n-1)          [1] factor_step_kernel carrying only the last trtri row. */
 int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A,
-                            float* Winv, float* Y, int* info, int B, int N, void* stream,
-                            float* ms_host /*[4]*/, int* launches_host /*[4]*/);
+                            float* Winv, float* Y, int* info, int B, int N, int groups, void* stream,
+                            float* ms_sum_host /*[2]*/, float* ms_union_host /*[2]*/, int* launches_host /*[2]*/,
+                            float* per_launch_host /* NULL, or [every launch, in enqueue order] durations in ms */);
 
-/* Tuning hook (scripts/tune_gemm.py): launches the P1 panel-update kernel of step k `reps` times in
- * variant `var` on an already factored A; results are garbage, only the timing matters. */
-int volt_tune_update_f32(float* A, int B, int Np, int k, int var, int reps, void* stream);
+/* Tuning hook (scripts/tune_gemm.py): launches the panel tiles (update + solve, var 0) or the 2x2-wave diagonal
+ * update (var 1) of block column k `reps` times on an already factored A; results are garbage, only the timing
+ * matters. */
+int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream);
 
 /* ---- a5: MLL + gradient  (ExactMarginalLogLikelihood + loss.backward(), train_utils.py:249-250)
  * One "step" of SURVEY 8(d) with K resident:

@@ -23,11 +23,12 @@ for rnd in range(4):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            _lib.check(L.volt_tune_update_f32(A.data_ptr(), B, n, k, var, reps, _lib.stream_ptr()), "tune")
+            _lib.check(L.volt_tune_update_f32(A.data_ptr(), f.Winv.data_ptr(), f.info.data_ptr(), B, n, k, var, reps,
+                                              _lib.stream_ptr()), "tune")
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            fl = B * (n // 128 - k) * k * 2 * 128 ** 3
+            fl = B * (n // 128 - k - 1) * (k + (0.625 if var == 0 else 0)) * 2 * 128 ** 3     # var 0: + the W product (160 of 256 MFMAs)
             if rnd > 0:
                 res.setdefault((var, k), []).append(fl / ms / 1e9)
 for var in variants:

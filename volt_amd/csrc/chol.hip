@@ -18,8 +18,10 @@
 // (factor_step_kernel); P3 is the second.
 #include "common.h"
 #include "../../include/volt_hip.h"
+#include <algorithm>
 #include <mutex>
 #include <stdlib.h>
+#include <utility>
 #include <vector>
 
 namespace volt {
@@ -66,26 +68,34 @@ __global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ 
     }
 }
 
-// ----------------------------------------------------------------------------- P1
-// grid.x = (n-k) * B.  Tile t: rows of block (k+t), columns of block k.
-// The C tile is loaded into registers BEFORE the K loop (its 64 KB per workgroup would otherwise
-// be an un-overlapped read-modify-write at the end: measured 51 -> 83 TF/s at k = 1, 115 -> 125 at
-// k = 16) and only stored in the epilogue.  FROMK: the C tile comes straight from the caller's
-// K (+ sigma2/jitter on the diagonal, identity in the padding) instead of a prepared copy in A, which
-// removes the K -> A copy pass for every block column but the first.
+// ----------------------------------------------------------------------------- panel update (diagonal tiles)
+// C tiles of block columns >= 1 come straight from the caller's K (+ sigma2/jitter on the diagonal, identity in the
+// padding) instead of a prepared copy in A, which removes the K -> A copy pass for every block column but the first.
 struct KSource {
-    const float* K;
+    const float* K;          // nullptr: the working matrix A already holds the input (volt_potrf_f32)
     int64_t ldk, bsk;
     const float* sigma2;
     float jitter;
     int N;
 };
 
-// Tile (rowblk, colblk) of the working matrix:  C <- C0 - sum_{m = kb0}^{kb1-1} L[rowblk, m] L[colblk, m]^T,
-// where C0 is the tile as it stands in A, or -- when `fromk` -- the caller's K (+ sigma2/jitter on the
-// diagonal, identity in the padding).  kb0 > 0 continues an update begun by an earlier launch (diagonal
-// look-ahead, see factor_step_kernel).
-template <bool FROMK>
+// Element (gi, gj) of the input matrix: from K (+ sigma2/jitter on the diagonal, identity in the padding), or from A.
+__device__ __forceinline__ float input_elem(const KSource& src, const float* Kb, float add, const float* Ab, int Np,
+                                            bool usek, int gi, int gj) {
+    if (usek) {
+        float v = (gi < src.N && gj < src.N) ? Kb[(int64_t)gi * src.ldk + gj] : 0.f;
+        if (gi == gj) v = (gi < src.N) ? v + add : 1.f;
+        return v;
+    }
+    return Ab[(int64_t)gi * Np + gj];
+}
+
+// Diagonal tile (kb,kb) of the working matrix:  C <- C0 - sum_{m = kb0}^{kb1-1} L[kb, m] L[kb, m]^T, where C0 is the
+// tile as it stands in A, or -- when `fromk` -- the caller's K.  kb0 > 0 continues an update begun by an earlier
+// launch (diagonal look-ahead, see factor_step_kernel).  The C tile is loaded NEGATED straight into the accumulators
+// before the K loop (acc = -C + sum, C <- -acc): nothing is held back for an epilogue read-modify-write, and no
+// prefetch registers are carried through the loop.
+template <bool FROMK, int ABL = 0>
 __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int rowblk, int colblk, int kb0, int kb1,
                                             bool fromk, int b, const KSource& src, float* smem) {
     float* Ab = A + (int64_t)b * Np * Np;
@@ -94,8 +104,7 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     float* C = Ab + (int64_t)rowblk * TS * Np + (int64_t)colblk * TS;
-    f32x16 acc[4], cpre[4];
-    zero_acc(acc);
+    f32x16 acc[4];
     const bool usek = FROMK && fromk;                      // workgroup-uniform
     const float add = usek ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
     const float* Kb = usek ? src.K + (int64_t)b * src.bsk : nullptr;
@@ -107,16 +116,19 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
             for (int q = 0; q < 16; ++q) {
                 const int r = wr * 64 + tm * 32 + accrow(q, lane);
                 const int c = wc * 64 + tn * 32 + (lane & 31);
-                if (usek) {
-                    const int gi = rowblk * TS + r, gj = colblk * TS + c;
-                    float v = (gi < src.N && gj < src.N) ? Kb[(int64_t)gi * src.ldk + gj] : 0.f;
-                    if (gi == gj) v = (gi < src.N) ? v + add : 1.f;
-                    cpre[tm * 2 + tn][q] = v;
-                } else {
-                    cpre[tm * 2 + tn][q] = C[(int64_t)r * Np + c];
-                }
+                if (ABL & 1) acc[tm * 2 + tn][q] = 0.f;         // ablation (tuning only): no C load
+                else acc[tm * 2 + tn][q] = -input_elem(src, Kb, add, Ab, Np, usek, rowblk * TS + r, colblk * TS + c);
             }
     gemm_nt_128<0>(Arows, Np, Brows, Np, (kb1 - kb0) * (TS / BK), acc, smem);
+    if (ABL & 2) {                                                 // ablation (tuning only): one store per thread
+        float sum = 0.f;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += acc[t4][q];
+        C[(int64_t)(threadIdx.x >> 1) * Np + (threadIdx.x & 1)] = sum;
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -125,7 +137,7 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
             for (int q = 0; q < 16; ++q) {
                 const int r = wr * 64 + tm * 32 + accrow(q, lane);
                 const int c = wc * 64 + tn * 32 + (lane & 31);
-                C[(int64_t)r * Np + c] = cpre[tm * 2 + tn][q] - acc[tm * 2 + tn][q];
+                C[(int64_t)r * Np + c] = -acc[tm * 2 + tn][q];
             }
 }
 
@@ -389,42 +401,29 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         }
     }
     __syncthreads();
+    // W goes out, all but its first word: W[0][0] = 1 / L[0][0] is never 0 (NaN for a failed pivot), so it doubles as
+    // the "W_k is ready" flag the panel tiles of the same launch poll -- published last, behind an agent-scope release.
+    const float w00 = sT[0];
     for (int e = tid; e < TS * TS / 4; e += NT) {
         const int r = e >> 5, c = (e & 31) * 4;
         f32x4 w4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) w4[q] = (c + q <= r) ? sT[r * DT + c + q] : 0.f;
-        *reinterpret_cast<f32x4*>(W + r * TS + c) = w4;
+        if (e == 0) {
+            W[1] = 0.f; W[2] = 0.f; W[3] = 0.f;
+        } else {
+            *reinterpret_cast<f32x4*>(W + r * TS + c) = w4;
+        }
     }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);          // tid 0 sits in wave 0, which tracked the pivots
-}
-
-// ----------------------------------------------------------------------------- P3
-// grid.x = (n-k-1) * B.  L[i,k] = A[i,k] * W_k^T, in place (the tile is fully staged through LDS
-// before the epilogue stores).
-__global__ __launch_bounds__(256, 2) void potrf_trsm_kernel(float* __restrict__ A, const float* __restrict__ Winv,
-                                                           int Np, int k, int B) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    const int n = Np / TS;
-    int t, b;
-    decode_tile_batch(n - k - 1, B, t, b);
-    float* P = A + (int64_t)b * Np * Np + (int64_t)(k + 1 + t) * TS * Np + (int64_t)k * TS;
-    const float* W = Winv + ((int64_t)b * n + k) * TS * TS;
-    f32x16 acc[4];
-    zero_acc(acc);
-    gemm_nt_128<0>(P, Np, W, TS, TS / BK, acc, smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int r = wr * 64 + tm * 32 + accrow(q, lane);
-                const int c = wc * 64 + tn * 32 + (lane & 31);
-                P[(int64_t)r * Np + c] = acc[tm * 2 + tn][q];
-            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int bits = __float_as_int(w00);
+        __hip_atomic_store(reinterpret_cast<int*>(W), bits ? bits : 0x7fc00000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ----------------------------------------------------------------------------- trtri
@@ -432,10 +431,7 @@ __global__ __launch_bounds__(256, 2) void potrf_trsm_kernel(float* __restrict__ 
 //     X[i,j] = -W_i * T ,  T = sum_{m=j}^{i-1} L[i,m] X[m,j]      (j < i),     X[i,i] = W_i
 // Phase 1 (MFMA, K = 128 (i-j)):  T[r][c] = sum_m L[i-rows r, m] * Y[j-rows c, m]   -- both K-contiguous.
 // Phase 2 (MFMA, K = 128):        Y[j-rows c, i-cols r] = - sum_p T[p][c] * W_i[r][p]
-//   With the 1x4 wave layout a wave holds all 128 p for its 32 columns c, and the accumulator
-//   layout of T (lane = c, registers = p) is exactly the A-operand layout of phase 2, so T never
-//   leaves the register file; W_i is staged once in LDS.
-// grid.x = (i+1) * B (tile j = 0..i; j == i copies W_i^T).
+// -- one tri_tile_run (common.h).  grid part: (i+1) * B tiles (j = 0..i; j == i copies W_i^T).
 constexpr int WLD = TS + 4;    // 132-float rows: b128 reads of 16 rows land on 16 distinct slots
 
 // Optional reductions fused into the trtri epilogue (the MLL step needs z = Y'r and ||Y||_F^2; doing
@@ -448,206 +444,174 @@ struct TriReduce {
     int N;
 };
 
-__device__ __forceinline__ void trtri_body(const float* __restrict__ A, const float* __restrict__ Winv,
-                                           float* __restrict__ Y, int Np, int i, int j, int b, TriReduce red,
-                                           float* smem) {
-    const int n = Np / TS;
-    const float* Ab = A + (int64_t)b * Np * Np;
-    float* Yb = Y + (int64_t)b * Np * Np;
-    const float* W = Winv + ((int64_t)b * n + i) * TS * TS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int tile_id = i * (i + 1) / 2 + j;             // upper-tile enumeration (cb = i, jb = j)
-
-    if (j == i) {
-        // diagonal tile: Y[i,i] = W_i^T (transposed through LDS so both sides stay coalesced)
-        for (int e = tid; e < TS * TS / 4; e += NT) {
-            const int r = e >> 5, c = (e & 31) * 4;
-            *reinterpret_cast<f32x4*>(smem + r * WLD + c) = *reinterpret_cast<const f32x4*>(W + r * TS + c);
-        }
-        __syncthreads();
-        float* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
-        for (int e = tid; e < TS * TS; e += NT) {
-            const int c = e >> 7, r = e & 127;          // Y row c, column r
-            Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
-        }
-        if (red.rpad) {
-            float* sred = smem + TS * WLD;               // 128 floats behind the W image
-            float fz = 0.f, ff = 0.f;
-            if (tid < TS) {
-                const float* rv = red.rpad + (int64_t)b * Np + i * TS;
-                for (int c = 0; c <= tid; ++c) {         // column r = tid of Y: entries W[r][c], c <= r
-                    const float y = smem[tid * WLD + c];
-                    fz += y * rv[c];
-                    if (i * TS + c < red.N) ff += y * y;
-                }
-                red.zpart[((int64_t)b * n + i) * Np + i * TS + tid] = fz;
-                sred[tid] = ff;
-            }
-            __syncthreads();
-            if (tid < 64) {
-                const float tot = wave_sum_f(sred[tid] + sred[tid + 64]);
-                if (tid == 0) red.frob[(int64_t)b * (n * (n + 1) / 2) + tile_id] = tot;
-            }
-        }
-        return;
-    }
-
-    // One software pipeline over n1 + 4 chunks: chunks [0,n1) are phase 1 (A = L rows of block i, B = Y
-    // rows of block j, both at K offset 32c), chunks [n1,n1+4) are phase 2, whose B tile is W_i[:, 32tp..]
-    // and whose A operand is T itself, straight out of the accumulator registers -- so W_i streams
-    // through the same double-buffered LDS stage as everything else and there is no staging bubble
-    // between the phases.
-    const int n1 = (i - j) * (TS / BK);
-    const float* Lrows = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;   // L[i, j*128 ...]
-    const float* Yrows = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;   // Y[j, j*128 ...]
-    f32x16 T[4], O[4];
-    zero_acc(T);
-    zero_acc(O);
-    // Two register stage sets (loads issued two chunks ahead of their LDS write), buffer-addressed.
-    StageRegs sr0, sr1;
-    const int srow = tid >> 3, scq = (tid & 7) * 4;
-    const StageAddr sa = stage_addr(Lrows, Np, Yrows, Np);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, TS * TS * 4, 0x00020000);
-    int vw[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) vw[p] = ((srow + 32 * p) * TS + scq) * 4;
-    auto load_chunk = [&](StageRegs& sr, int c) {
-        if (c < n1) {
-            stage_load_buf(sr, sa, c * BK);
-        } else {
-            const int so = __builtin_amdgcn_readfirstlane((c - n1) * BK * 4);
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                sr.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, vw[p], so, 0));
-        }
-    };
-    auto store_chunk = [&](const StageRegs& sr, int c, float* buf) {
-        if (c < n1) {
-            stage_store(sr, buf);
-        } else {
-            float* sB = buf + TS * SLD;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4*>(sB + (srow + 32 * p) * SLD + scq) = sr.b[p];
-        }
-    };
-    const int nall = n1 + 4;                                // >= 5
-    load_chunk(sr0, 0);
-    store_chunk(sr0, 0, smem);
-    load_chunk(sr0, 1);                                     // even-numbered stores use sr1, odd use sr0
-    load_chunk(sr1, 2);
-    __syncthreads();
-    // chunk c lives in buffer c & 1; at its mid-point chunk c+1 is written (from sr0 if c is even, else
-    // sr1) and chunk c+3 is requested into the same set.
-#define VOLT_TRI_STAGE(C)                                                            \
-    {                                                                                \
-        float* nxt_ = smem + (((C) + 1) & 1) * STAGE_FLOATS;                         \
-        if (((C) & 1) == 0) {                                                        \
-            if ((C) + 1 < nall) store_chunk(sr0, (C) + 1, nxt_);                     \
-            if ((C) + 3 < nall) load_chunk(sr0, (C) + 3);                            \
-        } else {                                                                     \
-            if ((C) + 1 < nall) store_chunk(sr1, (C) + 1, nxt_);                     \
-            if ((C) + 3 < nall) load_chunk(sr1, (C) + 3);                            \
-        }                                                                            \
-    }
-    int c = 0;
-    for (; c + 1 < n1; c += 2) {                            // phase 1, two chunks per trip (static set names)
-        mma_chunk<1, 0, BK / 16>(smem, T);
-        VOLT_TRI_STAGE(c)
-        mma_chunk<1, BK / 16, BK / 8>(smem, T);
-        __syncthreads();
-        mma_chunk<1, 0, BK / 16>(smem + STAGE_FLOATS, T);
-        VOLT_TRI_STAGE(c + 1)
-        mma_chunk<1, BK / 16, BK / 8>(smem + STAGE_FLOATS, T);
-        __syncthreads();
-    }
-    // n1 is a multiple of 4 (128-wide blocks of 32-wide chunks), so phase 1 always ends on an even chunk
-    // phase 2: out[cc][r] for cc in this wave's 32 columns, r in 4 blocks of 32.
-    // registers 4g..4g+3 of T[tp] <-> p = tp*32 + 8g + 4*lh + (0..3); B fragment = W[r][p] from the stage.
-#pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-        const int cc = n1 + tp;                             // parity of cc == parity of tp
-        const float* sB = smem + (tp & 1) * STAGE_FLOATS + TS * SLD;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g == 2) {
-                float* nxt_ = smem + ((tp + 1) & 1) * STAGE_FLOATS;
-                if ((tp & 1) == 0) {
-                    if (cc + 1 < nall) store_chunk(sr0, cc + 1, nxt_);
-                    if (cc + 3 < nall) load_chunk(sr0, cc + 3);
-                } else {
-                    if (cc + 1 < nall) store_chunk(sr1, cc + 1, nxt_);
-                    if (cc + 3 < nall) load_chunk(sr1, cc + 3);
-                }
-            }
-            // W_i is lower triangular: W[r][p] = 0 for p > r, so row blocks rb < tp contribute nothing
-            f32x4 w[4];
-#pragma unroll
-            for (int rb = tp; rb < 4; ++rb)
-                w[rb] = *reinterpret_cast<const f32x4*>(sB + (rb * 32 + l31) * SLD + 8 * g + 4 * lh);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float a = T[tp][4 * g + m];
-#pragma unroll
-                for (int rb = tp; rb < 4; ++rb)
-                    O[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w[rb][m], O[rb], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-#undef VOLT_TRI_STAGE
-    // O[rb] element (row = c_local, col = r_local): lane&31 = r, registers = c.  Y = -O.
-    float* Yt = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
+// Out[c][r] = -O: O[rb] element (row = c_local, col = r_local): lane & 31 = r, registers = c.
+__device__ __forceinline__ void tri_store(const f32x16 (&O)[4], float* __restrict__ Out, int64_t ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int c = wave * 32 + accrow(q, lane);
             const int r = rb * 32 + l31;
-            Yt[(int64_t)c * Np + r] = -O[rb][q];
+            Out[(int64_t)c * ldo + r] = -O[rb][q];
         }
+}
+
+// diagonal tile of row i: Y[i,i] = W_i^T (transposed through LDS so both sides stay coalesced)
+__device__ __forceinline__ void trtri_diag_body(const float* __restrict__ Winv, float* __restrict__ Y, int Np, int i,
+                                                int b, TriReduce red, float* smem) {
+    const int n = Np / TS;
+    float* Yb = Y + (int64_t)b * Np * Np;
+    const float* W = Winv + ((int64_t)b * n + i) * TS * TS;
+    const int tid = threadIdx.x;
+    const int tile_id = i * (i + 1) / 2 + i;             // upper-tile enumeration (cb = i, jb = j)
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        *reinterpret_cast<f32x4*>(smem + r * WLD + c) = *reinterpret_cast<const f32x4*>(W + r * TS + c);
+    }
+    __syncthreads();
+    float* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
+    for (int e = tid; e < TS * TS; e += NT) {
+        const int c = e >> 7, r = e & 127;          // Y row c, column r
+        Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
+    }
     if (red.rpad) {
-        // rows of this block row are all < N (only block row n-1 is padded, and that is a diagonal tile)
-        const float* rv = red.rpad + (int64_t)b * Np + j * TS + wave * 32;
-        float rvq[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) rvq[q] = rv[accrow(q, lane)];
-        __syncthreads();                                  // everyone is done reading W from smem
-        float* sz = smem;                                 // [4 waves][128]
-        float ff = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-            float cz = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float y = -O[rb][q];
-                cz += y * rvq[q];
-                ff += y * y;
+        float* sred = smem + TS * WLD;               // 128 floats behind the W image
+        float fz = 0.f, ff = 0.f;
+        if (tid < TS) {
+            const float* rv = red.rpad + (int64_t)b * Np + i * TS;
+            for (int c = 0; c <= tid; ++c) {         // column r = tid of Y: entries W[r][c], c <= r
+                const float y = smem[tid * WLD + c];
+                fz += y * rv[c];
+                if (i * TS + c < red.N) ff += y * y;
             }
-            cz += __shfl_xor(cz, 32);                     // the two lane halves hold different rows of column r
-            if (lh == 0) sz[wave * TS + rb * 32 + l31] = cz;
+            red.zpart[((int64_t)b * n + i) * Np + i * TS + tid] = fz;
+            sred[tid] = ff;
         }
-        ff = wave_sum_f(ff);
-        if (lane == 0) sz[4 * TS + wave] = ff;
         __syncthreads();
-        if (tid < TS)
-            red.zpart[((int64_t)b * n + j) * Np + i * TS + tid] =
-                (sz[tid] + sz[TS + tid]) + (sz[2 * TS + tid] + sz[3 * TS + tid]);
-        if (tid == 0)
-            red.frob[(int64_t)b * (n * (n + 1) / 2) + tile_id] = (sz[4 * TS] + sz[4 * TS + 1]) + (sz[4 * TS + 2] + sz[4 * TS + 3]);
+        if (tid < 64) {
+            const float tot = wave_sum_f(sred[tid] + sred[tid + 64]);
+            if (tid == 0) red.frob[(int64_t)b * (n * (n + 1) / 2) + tile_id] = tot;
+        }
     }
 }
 
-// ----------------------------------------------------------------------------- fused step kernel
-// One launch per block column k carries everything that is ready at that point:
-//   workgroups [0, (n-k)B)          P1 tiles of column k; the workgroup that owns the diagonal tile (t = 0)
-//                                   goes straight on to factor and invert it (P2) -- the 46 us latency chain
-//                                   runs next to the other tiles instead of after them
-//   workgroups [(n-k)B, (n-k)B+kB)  tiles of trtri row k-1 (independent of column k)
-// so every launch has n*B tiles of comparable length, longest first (diagonal, P1 tiles with K = 128k,
-// trtri tiles with K = 128(k-j)), instead of three launches of (n-k)B, B and kB.
-//   k_upd < 0: no P1/P2 part (used for the trailing trtri row and by volt_trtri_f32)
-//   i_tri < 0: no trtri part (forward-only factorisation)
+// z-partials and Frobenius partial of an off-diagonal trtri tile (i, j) from its product O (Y = -O)
+__device__ __forceinline__ void trtri_reduce(const f32x16 (&O)[4], int Np, int i, int j, int b, TriReduce red,
+                                             float* smem) {
+    const int n = Np / TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int tile_id = i * (i + 1) / 2 + j;
+    // rows of this block row are all < N (only block row n-1 is padded, and that is a diagonal tile)
+    const float* rv = red.rpad + (int64_t)b * Np + j * TS + wave * 32;
+    float rvq[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rvq[q] = rv[accrow(q, lane)];
+    float* sz = smem;                                 // [4 waves][128]  (tri_tile_run ended with a barrier)
+    float ff = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        float cz = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float y = -O[rb][q];
+            cz += y * rvq[q];
+            ff += y * y;
+        }
+        cz += __shfl_xor(cz, 32);                     // the two lane halves hold different rows of column r
+        if (lh == 0) sz[wave * TS + rb * 32 + l31] = cz;
+    }
+    ff = wave_sum_f(ff);
+    if (lane == 0) sz[4 * TS + wave] = ff;
+    __syncthreads();
+    if (tid < TS)
+        red.zpart[((int64_t)b * n + j) * Np + i * TS + tid] =
+            (sz[tid] + sz[TS + tid]) + (sz[2 * TS + tid] + sz[3 * TS + tid]);
+    if (tid == 0)
+        red.frob[(int64_t)b * (n * (n + 1) / 2) + tile_id] = (sz[4 * TS] + sz[4 * TS + 1]) + (sz[4 * TS + 2] + sz[4 * TS + 3]);
+}
+
+// ----------------------------------------------------------------------------- panel tile: update + solve in one
+// L[i,k] = (A[i,k] - sum_{m<k} L[i,m] L[k,m]^T) W_k^T  for i > k, as ONE two-phase tile (round 1 ran the update and
+// the solve as two launches per block column, with the tile written to and read back from HBM in between):
+//     T[p][c] = -A[i,k][c][p] + sum_m L[k,m][p] L[i,m][c]          (the NEGATED, TRANSPOSED updated tile)
+//     L[i,k][c][r] = -sum_p T[p][c] W_k[r][p]
+// W_k is produced by the diagonal workgroup of the SAME launch; it is needed only after the long first phase, so the
+// wait (W_k's first word, see diag_body) is normally over before it starts.
+// (the tile is set up in factor_step_kernel: panel and trtri tiles share ONE instance of the two-phase pipeline)
+
+// ----------------------------------------------------------------------------- step kernel
+// ONE launch per block column k carries everything that is ready at that point, in dispatch order:
+//   [0, B)                          the diagonal tile (k,k): apply block m = k-1 (the rest was done one launch earlier by
+//                                   the look-ahead), factor, invert -> W_k, publish
+//   [B, B + npre)                   diagonal look-ahead: A[k+1,k+1] -= sum_{m<k} L[k+1,m] L[k+1,m]^T (does not need
+//                                   column k), so that the next launch's diagonal workgroup starts its 128-pivot chain
+//                                   almost at once
+//   next (n-k-1) B                  panel tiles (i,k), i > k: update + solve (wait for W_k after their long phase)
+//   next k B                        tiles of trtri row k-1 (independent of column k)
+// so every launch has ~n*B tiles of comparable length and the diagonal latency chain (46 us) runs beside them.
+//   k_upd < 0: no factorisation part (the trailing trtri row, volt_trtri_f32);   i_tri < 0: no trtri part
+// What a two-phase tile needs besides its TriTile: where T0 comes from and where the product goes.
+struct TriJob {
+    TriTile t;
+    const float* c0;       // nullptr: T0 = 0 (trtri);  else row `gi` of the input tile, first column of the tile, + 4 (lane >> 5)
+    bool row_ok, vec_ok;   // the row exists in the input (not padding) / 16-byte loads are legal
+    float* out;            // Out[c * Np + r] = -O
+    int i, j, b;           // trtri: tile (i, j) of matrix b (for the reductions);  panel: i = -1
+};
+
+template <bool FROMK>
+__device__ __forceinline__ TriJob panel_job(float* __restrict__ A, const float* __restrict__ Winv, int Np, int i, int k,
+                                            int b, const KSource& src) {
+    const int n = Np / TS;
+    float* Ab = A + (int64_t)b * Np * Np;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const bool usek = FROMK && src.K != nullptr;
+    TriJob jb;
+    jb.t.X = Ab + (int64_t)k * TS * Np;                   // L[k, 0 ...]   (rows p = columns of the tile)
+    jb.t.ldx = Np;
+    jb.t.Z = Ab + (int64_t)i * TS * Np;                   // L[i, 0 ...]   (rows c = rows of the tile)
+    jb.t.ldz = Np;
+    jb.t.n1 = k * (TS / BK);
+    jb.t.W = Winv + ((int64_t)b * n + k) * TS * TS;
+    jb.t.flag = reinterpret_cast<const int*>(jb.t.W);
+    // T0[p][c] = -A[i,k][c][p]: lane owns row c = 32 wave + l31 of the tile; registers 4g..4g+3 of T[tm] are the four
+    // consecutive columns p = 32 tm + 8 g + 4 (lane >> 5) + (0..3): one 16-byte load each.  Column block k <= n-2 lies
+    // wholly inside the matrix; only the rows of the last block row can be padding.
+    const int gi = i * TS + wave * 32 + l31;
+    const int64_t ld = usek ? src.ldk : (int64_t)Np;
+    jb.c0 = (usek ? src.K + (int64_t)b * src.bsk : Ab) + (int64_t)gi * ld + k * TS + 4 * lh;
+    jb.row_ok = !usek || gi < src.N;
+    jb.vec_ok = !usek || (((src.ldk & 3) == 0) && ((src.bsk & 3) == 0) && (((uintptr_t)src.K & 15) == 0));
+    jb.out = Ab + (int64_t)i * TS * Np + (int64_t)k * TS;
+    jb.i = -1;
+    jb.j = 0;
+    jb.b = b;
+    return jb;
+}
+
+__device__ __forceinline__ TriJob trtri_job(const float* __restrict__ A, const float* __restrict__ Winv,
+                                            float* __restrict__ Y, int Np, int i, int j, int b) {
+    const int n = Np / TS;
+    const float* Ab = A + (int64_t)b * Np * Np;
+    float* Yb = Y + (int64_t)b * Np * Np;
+    TriJob jb;
+    jb.t.X = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;   // L[i, j*128 ...]
+    jb.t.ldx = Np;
+    jb.t.Z = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;   // Y[j, j*128 ...]
+    jb.t.ldz = Np;
+    jb.t.n1 = (i - j) * (TS / BK);
+    jb.t.W = Winv + ((int64_t)b * n + i) * TS * TS;
+    jb.t.flag = nullptr;
+    jb.c0 = nullptr;
+    jb.row_ok = jb.vec_ok = true;
+    jb.out = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
+    jb.i = i;
+    jb.j = j;
+    jb.b = b;
+    return jb;
+}
+
 template <bool FROMK>
 __global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                             float* __restrict__ Y, int* __restrict__ info, int Np,
@@ -656,98 +620,177 @@ __global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__
     static_assert(DIAG_LDS_FLOATS <= 2 * STAGE_FLOATS, "diag block must fit the staging area");
     static_assert(TS * WLD + TS <= 2 * STAGE_FLOATS, "W image + reduction scratch must fit");
     const int n = Np / TS;
-    // Diagonal look-ahead: the long part of the update of diagonal tile (k+1,k+1), blocks m < k, does not
-    // need column k, so it is done HERE (one extra workgroup per matrix, first in the grid); the next
-    // launch's diagonal workgroup then only applies block m = k (K = 128) before its 128-pivot chain, and is
-    // no longer the longest workgroup of its launch.
-    const int npre = (k_upd >= 1 && k_upd + 1 < n) ? B : 0;
-    const int nupd = (k_upd >= 0) ? (n - k_upd) * B : 0;
     int w = blockIdx.x;
-    if (w < npre) {
-        update_body<FROMK>(A, Np, k_upd + 1, k_upd + 1, 0, k_upd, true, w, src, smem);
-        return;
-    }
-    w -= npre;
-    if (w < nupd) {
-        int t, b;
-        decode_tile_batch(w, n - k_upd, B, t, b);
-        if (k_upd > 0) {
-            if (t == 0 && k_upd >= 2) update_body<FROMK>(A, Np, k_upd, k_upd, k_upd - 1, k_upd, false, b, src, smem);
-            else update_body<FROMK>(A, Np, k_upd + t, k_upd, 0, k_upd, true, b, src, smem);
-        }
-        if (t == 0) {
-            if (k_upd > 0) {
+    TriJob jb;
+    bool have = false;
+    if (k_upd >= 0) {
+        const int k = k_upd;
+        if (w < B) {                                                      // diagonal tile of matrix w
+            if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, w, src, smem);
+            else if (k == 1) update_body<FROMK>(A, Np, 1, 1, 0, 1, true, w, src, smem);
+            if (k > 0) {
                 __threadfence_block();           // this workgroup's own C-tile stores, re-read below
                 __syncthreads();
             }
-            diag_body(A, Winv, info, Np, k_upd, b, smem);
+            diag_body(A, Winv, info, Np, k, w, smem);
+            return;
         }
-        return;
+        w -= B;
+        const int npre = (k >= 1 && k + 1 < n) ? B : 0;
+        if (w < npre) {
+            update_body<FROMK>(A, Np, k + 1, k + 1, 0, k, true, w, src, smem);
+            return;
+        }
+        w -= npre;
+        const int npan = (n - k - 1) * B;
+        if (w < npan) {
+            int t, b;
+            decode_tile_batch(w, n - k - 1, B, t, b);
+            jb = panel_job<FROMK>(A, Winv, Np, k + 1 + t, k, b, src);
+            have = true;
+        }
+        w -= npan;
     }
-    int j, b;
-    decode_tile_batch(w - nupd, i_tri + 1, B, j, b);
-    trtri_body(A, Winv, Y, Np, i_tri, j, b, red, smem);
+    if (!have) {
+        int j, b;
+        decode_tile_batch(w, i_tri + 1, B, j, b);
+        if (j == i_tri) {
+            trtri_diag_body(Winv, Y, Np, i_tri, b, red, smem);
+            return;
+        }
+        jb = trtri_job(A, Winv, Y, Np, i_tri, j, b);
+    }
+    // ---- the two-phase tile (panel: update + solve; trtri: off-diagonal tile of row i_tri)
+    f32x16 T[4], O[4];
+    if (jb.c0 && jb.row_ok && jb.vec_ok) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(jb.c0 + 32 * tm + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[tm][4 * g + e] = -v[e];
+            }
+    } else if (jb.c0 && jb.row_ok) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) T[tm][q] = -jb.c0[32 * tm + 8 * (q >> 2) + (q & 3)];
+    } else {
+        zero_acc(T);
+    }
+    const bool ok = tri_tile_run(jb.t, T, O, smem);
+    if (threadIdx.x == 0 && !ok) atomicCAS(info + jb.b, 0, (int)0x80000000);   // hand-off timed out: internal error
+    tri_store(O, jb.out, Np);
+    if (jb.i >= 0 && red.rpad) trtri_reduce(O, Np, jb.i, jb.j, jb.b, red, smem);
 }
 
-// P1 alone (tuning hook: no diagonal factorisation, so it can be replayed on a finished factor)
-__global__ __launch_bounds__(256, 2) void tune_update_kernel(float* __restrict__ A, int Np, int k, int B, KSource src) {
+// Clears the first word of every W block: it is the "ready" flag of the block (diag_body / panel_body).
+__global__ void clear_w_flags_kernel(float* __restrict__ Winv, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) reinterpret_cast<int*>(Winv)[(int64_t)i * TS * TS] = 0;
+}
+
+// Panel tiles alone (tuning hook: replayed on a finished factor -- W_k is there, the results are garbage)
+__global__ __launch_bounds__(256, 2) void tune_update_kernel(float* __restrict__ A, const float* __restrict__ Winv,
+                                                            int* __restrict__ info, int Np, int k, int B, KSource src) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     int t, b;
-    decode_tile_batch(Np / TS - k, B, t, b);
-    update_body<false>(A, Np, k + t, k, 0, k, true, b, src, smem);
+    decode_tile_batch(Np / TS - k - 1, B, t, b);
+    const TriJob jb = panel_job<false>(A, Winv, Np, k + 1 + t, k, b, src);
+    f32x16 T[4], O[4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(jb.c0 + 32 * tm + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) T[tm][4 * g + e] = -v[e];
+        }
+    const bool ok = tri_tile_run(jb.t, T, O, smem);
+    if (threadIdx.x == 0 && !ok) atomicCAS(info + jb.b, 0, (int)0x80000000);
+    tri_store(O, jb.out, Np);
 }
-
-// Block column 0: no panel update, just the diagonal blocks of the prepared column.
-__global__ __launch_bounds__(256, 2) void factor_diag0_kernel(float* __restrict__ A, float* __restrict__ Winv,
-                                                             int* __restrict__ info, int Np) {
+// The 2x2-wave update alone (the diagonal look-ahead's product), same grid.  ABL: ablations for the c0 breakdown.
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void tune_update_sq_kernel(float* __restrict__ A, int Np, int k, int B, KSource src) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    diag_body(A, Winv, info, Np, 0, blockIdx.x, smem);
+    int t, b;
+    decode_tile_batch(Np / TS - k - 1, B, t, b);
+    update_body<false, ABL>(A, Np, k + 1 + t, k, 0, k, true, b, src, smem);
 }
+__global__ void tune_empty_kernel(float* A) { if (A == nullptr) A[0] = 0.f; }
 
 }  // namespace volt
 
 using namespace volt;
 
-// Optional per-launch timing (bench only): every launch is bracketed by two events on the same
-// stream; the caller synchronises and sums the intervals per kernel class.
+// Optional per-launch timing (bench only): every launch is bracketed by two events on ITS stream; the caller
+// synchronises, and per kernel class gets the summed launch durations and the length of the UNION of the launch
+// intervals (on one stream the two agree; with the batch cut into groups on several streams the launches of a class
+// overlap, and the union is the time during which that class was running at all).
 struct LaunchTimer {
-    hipStream_t s;
+    hipEvent_t base = nullptr;
     std::vector<hipEvent_t> ev;
     std::vector<int> cls;
-    explicit LaunchTimer(hipStream_t st) : s(st) {}
-    void begin(int c) {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        (void)hipEventRecord(e, s);
+    hipError_t err = hipSuccess;
+    void note(hipError_t e) { if (err == hipSuccess && e != hipSuccess) err = e; }
+    void start(hipStream_t s) {
+        note(hipEventCreate(&base));
+        note(hipEventRecord(base, s));
+    }
+    void begin(int c, hipStream_t s) {
+        hipEvent_t e = nullptr;
+        note(hipEventCreate(&e));
+        note(hipEventRecord(e, s));
         ev.push_back(e);
         cls.push_back(c);
     }
-    void end() {
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        (void)hipEventRecord(e, s);
+    void end(hipStream_t s) {
+        hipEvent_t e = nullptr;
+        note(hipEventCreate(&e));
+        note(hipEventRecord(e, s));
         ev.push_back(e);
     }
-    void collect(float* ms_by_class, int* n_by_class, int nclass) {
-        (void)hipStreamSynchronize(s);
-        for (int c = 0; c < nclass; ++c) { ms_by_class[c] = 0.f; n_by_class[c] = 0; }
+    // call after the device has drained
+    void collect(float* ms_sum, float* ms_union, int* n_by_class, int nclass, float* per_launch = nullptr) {
+        std::vector<std::vector<std::pair<float, float>>> iv(nclass);
+        for (int c = 0; c < nclass; ++c) { ms_sum[c] = ms_union[c] = 0.f; n_by_class[c] = 0; }
         for (size_t i = 0; i < cls.size(); ++i) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
-            ms_by_class[cls[i]] += ms;
+            float t0 = 0.f, t1 = 0.f;
+            note(hipEventElapsedTime(&t0, base, ev[2 * i]));
+            note(hipEventElapsedTime(&t1, base, ev[2 * i + 1]));
+            ms_sum[cls[i]] += t1 - t0;
             n_by_class[cls[i]] += 1;
+            if (per_launch) per_launch[i] = t1 - t0;
+            iv[cls[i]].push_back({t0, t1});
+        }
+        for (int c = 0; c < nclass; ++c) {
+            std::sort(iv[c].begin(), iv[c].end());
+            float lo = 0.f, hi = -1.f;
+            for (auto& x : iv[c]) {
+                if (hi < lo || x.first > hi) {
+                    if (hi >= lo) ms_union[c] += hi - lo;
+                    lo = x.first;
+                    hi = x.second;
+                } else if (x.second > hi) {
+                    hi = x.second;
+                }
+            }
+            if (hi >= lo) ms_union[c] += hi - lo;
         }
         for (auto e : ev) (void)hipEventDestroy(e);
+        if (base) (void)hipEventDestroy(base);
         ev.clear();
         cls.clear();
     }
 };
 
-// One factorisation (+ optional inverse).  Launch sequence per block column k:
-//     factor_step_kernel(k) = [look-ahead for k+1 | P1(k) + P2(k) | trtri row k-1]  ->  P3(k)
+// One factorisation (+ optional inverse).  Launch sequence: for every block column k ONE factor_step_kernel
+//     [diagonal tile (k,k) | look-ahead for (k+1,k+1) | panel tiles (i,k): update + solve | trtri row k-1]
 // and finally the trtri row n-1 alone.
 struct FactorOpts {
-    KSource src;            // src.K != nullptr: block columns >= 1 take their C tiles straight from K
+    KSource src;            // src.K != nullptr: tiles of block columns >= 1 take their input straight from K
     float* Y;               // nullptr: no triangular inverse
     TriReduce red;          // red.rpad != nullptr: fuse z-partials and Frobenius partials into trtri
 };
@@ -763,70 +806,52 @@ struct Group {
     hipStream_t s;
 };
 
-// Timer classes: 0 = factor_step_kernel (P1 + P2 + trtri row k-1), 1 = factor_diag0_kernel (block column 0),
-//                2 = potrf_trsm (P3),
-//                3 = factor_step_kernel carrying only a trtri row (the last row; every row of volt_trtri_f32).
+// Timer classes: 0 = factor_step_kernel with a factorisation part (block columns 0..n-1, trtri row k-1 aboard),
+//                1 = factor_step_kernel carrying only a trtri row (the last row; every row of volt_trtri_f32).
 static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     const int n = Np / TS, B = g.B;
     const TriReduce nored{nullptr, nullptr, nullptr, 0};
     const int itri = (g.o.Y && k > 0) ? k - 1 : -1;
-    // k = 0 has no panel update: only the diagonal blocks of the prepared first column (t = 0 of n tiles
-    // would waste n-1 idle workgroups per matrix, so the grid is cut to the diagonal tile alone)
-    const int nupd = (k == 0) ? B : (n - k) * B;
-    const int npre = (k >= 1 && k + 1 < n) ? B : 0;          // diagonal look-ahead workgroups (factor_step_kernel)
-    if (tm) tm->begin(k == 0 ? 1 : 0);
-    if (k == 0) {
-        // decode_tile_batch(w, n - 0, B) would spread t over n tiles: launch with a private tile count of 1
-        hipLaunchKernelGGL(factor_diag0_kernel, dim3(B), dim3(256), 0, g.s, g.A, g.Winv, g.info, Np);
-    } else if (g.o.src.K) {
-        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(npre + nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
-                           g.A, g.Winv, g.o.Y, g.info, Np, k, itri, B, g.o.src, g.o.Y ? g.o.red : nored);
-    } else {
-        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(npre + nupd + (itri >= 0 ? (itri + 1) * B : 0)), dim3(256), 0, g.s,
-                           g.A, g.Winv, g.o.Y, g.info, Np, k, itri, B, g.o.src, g.o.Y ? g.o.red : nored);
-    }
-    if (tm) tm->end();
-    if (k + 1 < n) {
-        if (tm) tm->begin(2);
-        hipLaunchKernelGGL(potrf_trsm_kernel, dim3((n - k - 1) * B), dim3(256), 0, g.s, g.A, g.Winv, Np, k, B);
-        if (tm) tm->end();
-    }
+    const int npre = (k >= 1 && k + 1 < n) ? B : 0;          // diagonal look-ahead workgroups
+    const int grid = B + npre + (n - k - 1) * B + (itri >= 0 ? (itri + 1) * B : 0);
+    if (tm) tm->begin(0, g.s);
+    if (g.o.src.K)
+        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(grid), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
+                           itri, B, g.o.src, g.o.Y ? g.o.red : nored);
+    else
+        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(grid), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
+                           itri, B, g.o.src, g.o.Y ? g.o.red : nored);
+    if (tm) tm->end(g.s);
     if (k + 1 == n && g.o.Y) {
-        if (tm) tm->begin(3);
+        if (tm) tm->begin(1, g.s);
         hipLaunchKernelGGL(factor_step_kernel<false>, dim3(n * B), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
                            -1, n - 1, B, g.o.src, g.o.red);
-        if (tm) tm->end();
+        if (tm) tm->end(g.s);
     }
 }
 
-static int run_factor(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o,
-                      LaunchTimer* tm) {
-    const int n = Np / TS;
+// info = 0 and every W block's ready flag cleared, on the caller's stream before anything forks from it
+static int begin_factor(float* Winv, int* info, int B, int n, hipStream_t s) {
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
-    const Group g{A, Winv, info, o, B, s};
-    for (int k = 0; k < n; ++k) enqueue_step(g, Np, k, tm);
-    VOLT_LAUNCH_CHECK();
+    hipLaunchKernelGGL(clear_w_flags_kernel, dim3((B * n + 255) / 256), dim3(256), 0, s, Winv, B * n);
     return 0;
 }
 
 // ---- stage barriers vs. asynchrony ------------------------------------------------------------------
-// With the whole batch in lockstep every launch ends in a tail: (n-k)*B tiles rarely fill a whole number of
-// rounds of the 512 resident workgroups (measured: P1 at k = 23 runs 576 tiles = 1.125 rounds at 77 TF/s,
-// k = 24 = 1.0 rounds at 131), and the next stage cannot start before the tail has drained.  A list-
-// scheduling model of the measured tile times puts this at 32.4 ms per step against 26.8 ms for perfect
-// packing.  Cutting the batch into G groups that run the SAME launch sequence on G streams, started a
-// little apart, lets one group's tail overlap another group's next stage (model: 28.6 ms at G = 4).
-// The streams are created once per device (library-lifetime, like a BLAS handle); a call forks from and
-// joins back into the caller's stream with events, so the caller still sees ordinary stream semantics.
-__global__ void delay_kernel(long long cycles) {
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
-}
-
+// With the whole batch in lockstep every launch ends in a tail: its tiles rarely fill a whole number of
+// rounds of the 512 resident workgroups, and the next stage cannot start before the tail has drained.
+// Cutting the batch into G groups that run the SAME launch sequence on G streams lets one group's tail
+// overlap another group's next stage.  The auxiliary streams and the fork / join events are created once per
+// device (library-lifetime, like a BLAS handle's); a call forks from and joins back into the caller's stream
+// with those events, so the caller still sees ordinary stream semantics.  Calls on one device are serialised
+// on the HOST while they enqueue (a mutex around fork .. join: the events are shared), never on the device.
 constexpr int MAX_GROUPS = 8;
 struct StreamPool {
     hipStream_t aux[MAX_GROUPS - 1];
+    hipEvent_t fork, join[MAX_GROUPS - 1];
+    std::mutex mu;
+    int want_groups = 4;                 // VOLT_GROUPS, read once
     bool ok = false;
 };
 static StreamPool* stream_pool() {
@@ -835,18 +860,22 @@ static StreamPool* stream_pool() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     std::call_once(once[dev], [dev]() {
-        bool ok = true;
-        for (int i = 0; i < MAX_GROUPS - 1; ++i)
-            ok = ok && hipStreamCreateWithFlags(&pools[dev].aux[i], hipStreamNonBlocking) == hipSuccess;
-        pools[dev].ok = ok;
+        StreamPool& p = pools[dev];
+        bool ok = hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < MAX_GROUPS - 1; ++i) {
+            ok = ok && hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (const char* e = getenv("VOLT_GROUPS")) p.want_groups = atoi(e);
+        if (p.want_groups < 1) p.want_groups = 1;
+        if (p.want_groups > MAX_GROUPS) p.want_groups = MAX_GROUPS;
+        p.ok = ok;
     });
     return pools[dev].ok ? &pools[dev] : nullptr;
 }
 
-static int pick_groups(int B) {
-    int want = 4;
-    if (const char* e = getenv("VOLT_GROUPS")) want = atoi(e);
-    if (want < 1) want = 1;
+static int pick_groups(const StreamPool* pool, int B, int force) {
+    int want = force > 0 ? force : (pool ? pool->want_groups : 1);
     if (want > MAX_GROUPS) want = MAX_GROUPS;
     while (want > 1 && (B % want != 0 || B / want < 8)) want >>= 1;   // keep whole-XCD groups of >= 8 matrices
     return want;
@@ -854,26 +883,33 @@ static int pick_groups(int B) {
 
 typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
 
+#define VOLT_TRY(call)                              \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
 static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hipStream_t s, const FactorOpts& o,
-                             volt_group_post_fn post = nullptr, void* post_ctx = nullptr) {
+                             volt_group_post_fn post = nullptr, void* post_ctx = nullptr, LaunchTimer* tm = nullptr,
+                             int force_groups = 0) {
     const int n = Np / TS;
-    const int G = pick_groups(B);
-    StreamPool* pool = G > 1 ? stream_pool() : nullptr;
-    if (G == 1 || !pool) {
-        const int rc = run_factor(A, Winv, info, B, Np, s, o, nullptr);
-        if (rc == 0 && post) post(post_ctx, 0, B, s);
-        return rc;
+    StreamPool* pool = stream_pool();
+    const int G = pool ? pick_groups(pool, B, force_groups) : 1;
+    int rc = begin_factor(Winv, info, B, n, s);
+    if (rc) return rc;
+    if (tm) tm->start(s);
+    if (G == 1) {
+        const Group g{A, Winv, info, o, B, s};
+        for (int k = 0; k < n; ++k) enqueue_step(g, Np, k, tm);
+        if (post) post(post_ctx, 0, B, s);
+        VOLT_LAUNCH_CHECK();
+        return tm && tm->err != hipSuccess ? (int)tm->err : 0;
     }
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
-    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lock(pool->mu);
     const int Bg = B / G;
     const int64_t mat = (int64_t)Np * Np;
     Group grp[MAX_GROUPS];
-    hipEvent_t fork, join[MAX_GROUPS];
-    if ((e = hipEventCreateWithFlags(&fork, hipEventDisableTiming)) != hipSuccess) return (int)e;
-    (void)hipEventRecord(fork, s);
-    long long skew = 0;                                    // optional start skew between groups (measured: no effect)
-    if (const char* ev = getenv("VOLT_GROUP_SKEW_US")) skew = (long long)(atof(ev) * 2400.0);
+    VOLT_TRY(hipEventRecord(pool->fork, s));
     for (int g = 0; g < G; ++g) {
         FactorOpts og = o;
         const int b0 = g * Bg;
@@ -888,39 +924,37 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
             og.red.frob += (int64_t)b0 * (n * (n + 1) / 2);
         }
         grp[g] = Group{A + b0 * mat, Winv + (int64_t)b0 * n * TS * TS, info + b0, og, Bg, g == 0 ? s : pool->aux[g - 1]};
-        if (g > 0) {
-            (void)hipStreamWaitEvent(grp[g].s, fork, 0);
-            if (skew > 0) hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, grp[g].s, skew * g);
-        }
+        if (g > 0) VOLT_TRY(hipStreamWaitEvent(grp[g].s, pool->fork, 0));
     }
     for (int k = 0; k < n; ++k)
-        for (int g = 0; g < G; ++g) enqueue_step(grp[g], Np, k, nullptr);
+        for (int g = 0; g < G; ++g) enqueue_step(grp[g], Np, k, tm);
     if (post)
         for (int g = 0; g < G; ++g) post(post_ctx, g * Bg, Bg, grp[g].s);
+    // join: the caller's stream must not run ahead of any group.  If an event call fails the group is joined on the
+    // host instead, so the caller's stream semantics hold either way; the error is still reported.
+    int first_err = 0;
     for (int g = 1; g < G; ++g) {
-        if ((e = hipEventCreateWithFlags(&join[g], hipEventDisableTiming)) != hipSuccess) {
-            // out of events: fall back to a host-side join so that the caller's stream semantics still hold
+        hipError_t e = hipEventRecord(pool->join[g - 1], grp[g].s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, pool->join[g - 1], 0);
+        if (e != hipSuccess) {
             (void)hipStreamSynchronize(grp[g].s);
-            continue;
+            if (!first_err) first_err = (int)e;
         }
-        (void)hipEventRecord(join[g], grp[g].s);
-        (void)hipStreamWaitEvent(s, join[g], 0);
-        (void)hipEventDestroy(join[g]);
     }
-    (void)hipEventDestroy(fork);
+    if (first_err) return first_err;
     VOLT_LAUNCH_CHECK();
-    return 0;
+    return tm && tm->err != hipSuccess ? (int)tm->err : 0;
 }
 
 static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np, hipStream_t s, LaunchTimer* tm) {
     const int n = Np / TS;
     const TriReduce nored{nullptr, nullptr, nullptr, 0};
     for (int i = 0; i < n; ++i) {
-        if (tm) tm->begin(3);
+        if (tm) tm->begin(1, s);
         hipLaunchKernelGGL(factor_step_kernel<false>, dim3((i + 1) * B), dim3(256), 0, s, const_cast<float*>(A),
                            const_cast<float*>(Winv), Y, nullptr, Np, -1, i, B, KSource{nullptr, 0, 0, nullptr, 0.f, 0},
                            nored);
-        if (tm) tm->end();
+        if (tm) tm->end(s);
     }
     VOLT_LAUNCH_CHECK();
     return 0;
@@ -929,18 +963,13 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, float* ms_host, int* launches_host, volt_group_post_fn post, void* post_ctx) {
+                         void* stream, volt_group_post_fn post, void* post_ctx) {
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
-    // block column 0 (no panel update there) is copied; the others are read from K inside P1
+    // block column 0 (its diagonal tile is factored straight out of A) is copied; everything else is read from K
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
     FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}};
-    if (!ms_host) return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
-    LaunchTimer tm(s);
-    const int rc = run_factor(A, Winv, info, B, Np, s, o, &tm);
-    if (rc) return rc;
-    tm.collect(ms_host, launches_host, 4);
-    return 0;
+    return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
 }
 
 extern "C" {
@@ -960,17 +989,25 @@ int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
     return 0;
 }
 
-int volt_tune_update_f32(float* A, int B, int Np, int k, int var, int reps, void* stream) {
+int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream) {
     if (!A) return -1;
-    if (B < 1) return -2;
-    if (Np < TS || Np % TS) return -3;
+    if (!Winv) return -2;
+    if (!info) return -3;
+    if (B < 1) return -4;
+    if (Np < TS || Np % TS) return -5;
     const int n = Np / TS;
-    if (k < 1 || k >= n) return -4;
-    if (var != 0) return -5;
+    if (k < 1 || k + 1 >= n) return -6;
+    if (var < 0 || var > 5) return -7;
     hipStream_t s = (hipStream_t)stream;
     const KSource none{nullptr, 0, 0, nullptr, 0.f, 0};
-    for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(tune_update_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B, none);
+    for (int r = 0; r < reps; ++r) {
+        if (var == 0) hipLaunchKernelGGL(tune_update_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, info, Np, k, B, none);
+        else if (var == 1) hipLaunchKernelGGL(tune_update_sq_kernel<0>, dim3((n - k - 1) * B), dim3(256), 0, s, A, Np, k, B, none);
+        else if (var == 2) hipLaunchKernelGGL(tune_update_sq_kernel<1>, dim3((n - k - 1) * B), dim3(256), 0, s, A, Np, k, B, none);
+        else if (var == 3) hipLaunchKernelGGL(tune_update_sq_kernel<2>, dim3((n - k - 1) * B), dim3(256), 0, s, A, Np, k, B, none);
+        else if (var == 4) hipLaunchKernelGGL(tune_update_sq_kernel<3>, dim3((n - k - 1) * B), dim3(256), 0, s, A, Np, k, B, none);
+        else hipLaunchKernelGGL(tune_empty_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A);
+    }
     VOLT_LAUNCH_CHECK();
     return 0;
 }
@@ -987,7 +1024,8 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
 }
 
 int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv,
-                            float* Y, int* info, int B, int N, void* stream, float* ms_host, int* launches_host) {
+                            float* Y, int* info, int B, int N, int groups, void* stream, float* ms_sum_host,
+                            float* ms_union_host, int* launches_host, float* per_launch_host) {
     if (!K) return -1;
     if (ldk < N) return -2;
     if (!A) return -5;
@@ -995,10 +1033,21 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
     if (!info) return -8;
     if (B < 1) return -9;
     if (N < 1) return -10;
-    if (!ms_host) return -12;
-    if (!launches_host) return -13;
-    return volt_internal_factor(K, ldk, bsk, sigma2, 0.f, A, Winv, Y, info, nullptr, nullptr, nullptr, B, N, stream,
-                                ms_host, launches_host, nullptr, nullptr);
+    if (groups < 0 || groups > MAX_GROUPS) return -11;
+    if (!ms_sum_host) return -13;
+    if (!ms_union_host) return -14;
+    if (!launches_host) return -15;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, 0.f, A, N, Np, 1);
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{nullptr, nullptr, nullptr, N}};
+    LaunchTimer tm;
+    const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, nullptr, nullptr, &tm, groups);
+    hipError_t e = hipStreamSynchronize(s);            // the groups have joined into s
+    tm.collect(ms_sum_host, ms_union_host, launches_host, 2, per_launch_host);
+    if (rc) return rc;
+    if (e != hipSuccess) return (int)e;
+    return tm.err != hipSuccess ? (int)tm.err : 0;
 }
 
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream) {

@@ -114,57 +114,120 @@ __device__ __forceinline__ void stage_load_buf(StageRegs& s, const StageAddr& sa
     }
 }
 
-template <int WL, int KK0 = 0, int KK1 = BK / 8>
-__device__ __forceinline__ void mma_chunk(const float* __restrict__ buf, f32x16 (&acc)[4]) {
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+}
+
+// ---- the K loop: fragments double-buffered in registers ---------------------------------------------------------
+// A chunk is 4 K steps of 8; step kk+1's fragments are requested BEFORE step kk's 16 MFMAs, into a second register
+// set, and the chunk's barrier sits before its last step, so the first fragments of the next chunk are in flight
+// during that step's MFMAs as well.  (Round 1 re-used ONE fragment set: the ds_reads of a step could only be issued
+// behind the 15th MFMA of the previous one, their latency was exposed once per step, and a lone wave per SIMD reached
+// 81 % MFMA duty -- ISA inspection; 132 -> 137 TF/s at k = 16, 120 -> 136 at k = 28 for the panel update alone.)
+template <int WL> struct Frag;
+template <> struct Frag<0> { f32x4 a0, a1, b0, b1; };
+template <> struct Frag<1> { f32x4 a[4], b0; };
+
+template <int WL>
+__device__ __forceinline__ void frag_load(Frag<WL>& f, const float* __restrict__ buf, int kk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const float* sA = buf;
     const float* sB = buf + TS * SLD;
+    const int ko = kk * 8 + 4 * lh;
+    if constexpr (WL == 0) {
+        const int wr = wave >> 1, wc = wave & 1;
+        f.a0 = *reinterpret_cast<const f32x4*>(sA + (wr * 64 + l31) * SLD + ko);
+        f.b0 = *reinterpret_cast<const f32x4*>(sB + (wc * 64 + l31) * SLD + ko);
+        f.b1 = *reinterpret_cast<const f32x4*>(sB + (wc * 64 + 32 + l31) * SLD + ko);
+        f.a1 = *reinterpret_cast<const f32x4*>(sA + (wr * 64 + 32 + l31) * SLD + ko);
+    } else {
+        f.b0 = *reinterpret_cast<const f32x4*>(sB + (wave * 32 + l31) * SLD + ko);
 #pragma unroll
-    for (int kk = KK0; kk < KK1; ++kk) {
-        const int ko = kk * 8 + 4 * lh;
-        if (WL == 0) {
-            const int wr = wave >> 1, wc = wave & 1;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sA + (wr * 64 + l31) * SLD + ko);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sA + (wr * 64 + 32 + l31) * SLD + ko);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB + (wc * 64 + l31) * SLD + ko);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sB + (wc * 64 + 32 + l31) * SLD + ko);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b1[m], acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b0[m], acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m], acc[3], 0, 0, 0);
-            }
-        } else {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sB + (wave * 32 + l31) * SLD + ko);
-            f32x4 a[4];
-#pragma unroll
-            for (int tm = 0; tm < 4; ++tm)
-                a[tm] = *reinterpret_cast<const f32x4*>(sA + (tm * 32 + l31) * SLD + ko);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-                    acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][m], b0[m], acc[tm], 0, 0, 0);
-            }
-        }
+        for (int tm = 0; tm < 4; ++tm) f.a[tm] = *reinterpret_cast<const f32x4*>(sA + (tm * 32 + l31) * SLD + ko);
     }
 }
 
-// acc += A[0:128, 0:32*nchunks] * B[0:128, 0:32*nchunks]^T ; smem = GEMM_LDS_BYTES, 16-B aligned.
-// Ends with a barrier: smem is free for reuse on return.
-// The staging traffic rides in the shadow of the MFMAs: the LDS write of chunk c+1 and the global
-// loads of chunk c+2 are issued half-way through the 64 MFMAs of chunk c (a 32x32x2 MFMA holds the
-// pipe for 64 cycles; an in-order wave can slip a dozen other instructions behind each), so the
-// only thing left at the per-chunk barrier is the barrier.
+// the 4 MFMAs of K sub-step m (of 4) of a fragment set
 template <int WL>
-__device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t lda,
-                                               const float* __restrict__ B, int64_t ldb, int nchunks,
-                                               f32x16 (&acc)[4], float* smem) {
+__device__ __forceinline__ void frag_mma_m(const Frag<WL>& f, int m, f32x16 (&acc)[4]) {
+    if constexpr (WL == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[m], f.b0[m], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[m], f.b1[m], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[m], f.b0[m], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[m], f.b1[m], acc[3], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][m], f.b0[m], acc[tm], 0, 0, 0);
+    }
+}
+template <int WL>
+__device__ __forceinline__ void frag_mma(const Frag<WL>& f, f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) frag_mma_m<WL>(f, m, acc);
+}
+
+#define VOLT_SB() __builtin_amdgcn_sched_barrier(0)
+
+// piece p (of 4) of a staging action: one row group of A and of B
+__device__ __forceinline__ void stage_store_piece(const StageRegs& s, float* __restrict__ buf, int p) {
+    const int t = threadIdx.x;
+    const int row = t >> 3, cq = (t & 7) * 4;
+    *reinterpret_cast<f32x4*>(buf + (row + 32 * p) * SLD + cq) = s.a[p];
+    *reinterpret_cast<f32x4*>(buf + TS * SLD + (row + 32 * p) * SLD + cq) = s.b[p];
+}
+__device__ __forceinline__ void stage_load_piece(StageRegs& s, const StageAddr& sa, int so, int p) {
+    s.a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sa.ra, sa.va[p], so, 0));
+    s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(sa.rb, sa.vb[p], so, 0));
+}
+
+// One chunk of the v2 pipeline.  On entry F0 holds K step 0 of `cur`; on exit F0 holds step 0 of `nxt` (if `more`).
+// The order below is PINNED with sched_barriers (left alone, the machine scheduler sinks every ds_read to just
+// before its first use): each step's fragment reads are issued a full step (16 MFMAs = 1024 cycles) ahead, and the
+// staging traffic -- LDS write of chunk c+1 behind step 1 (`st`, if do_st), global loads of chunk c+3 behind step 2
+// (`ld`, if do_ld) -- goes out two instructions at a time between groups of four MFMAs.
+template <int WL, bool STEADY>
+__device__ __forceinline__ void chunk_run(const float* cur, float* nxt, bool more_, Frag<WL>& F0, Frag<WL>& F1,
+                                         f32x16 (&acc)[4], StageRegs& s, bool do_st_, bool do_ld_, const StageAddr& sa,
+                                         int k_ld) {
+    // STEADY: everything is on (compile-time), so the loop body is one basic block
+    const bool more = STEADY || more_, do_st = STEADY || do_st_, do_ld = STEADY || do_ld_;
+    frag_load<WL>(F1, cur, 1);
+    VOLT_SB();
+    frag_mma<WL>(F0, acc);
+    VOLT_SB();
+    frag_load<WL>(F0, cur, 2);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        frag_mma_m<WL>(F1, m, acc);
+        if (do_st) stage_store_piece(s, nxt, m);
+        VOLT_SB();
+    }
+    frag_load<WL>(F1, cur, 3);
+    VOLT_SB();
+    const int so = __builtin_amdgcn_readfirstlane(k_ld * 4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        frag_mma_m<WL>(F0, m, acc);
+        if (do_ld) stage_load_piece(s, sa, so, m);
+        VOLT_SB();
+    }
+    __syncthreads();
+    if (more) frag_load<WL>(F0, nxt, 0);
+    VOLT_SB();
+    frag_mma<WL>(F1, acc);
+    VOLT_SB();
+}
+
+template <int WL>
+__device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                               int64_t ldb, int nchunks, f32x16 (&acc)[4], float* smem) {
     if (nchunks <= 0) return;
-    // Two register stage sets: a chunk's loads are issued two chunks (128 MFMAs per wave) before its LDS
-    // write, so a late HBM/L2 return no longer stalls the wave at the write (measured +x % at k = 16).
     StageRegs s0, s1;
     const StageAddr sa = stage_addr(A, lda, B, ldb);
     stage_load_buf(s0, sa, 0);
@@ -172,25 +235,229 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
     if (nchunks > 1) stage_load_buf(s0, sa, BK);
     if (nchunks > 2) stage_load_buf(s1, sa, 2 * BK);
     __syncthreads();
+    Frag<WL> F0, F1;
+    frag_load<WL>(F0, smem, 0);
+    float* b0 = smem;
+    float* b1 = smem + STAGE_FLOATS;
     int c = 0;
-    for (; c + 1 < nchunks; c += 2) {
-        float* b0 = smem;                      // chunk c (even) lives in buffer 0
-        float* b1 = smem + STAGE_FLOATS;
-        mma_chunk<WL, 0, BK / 16>(b0, acc);
-        stage_store(s0, b1);                                            // chunk c+1
-        if (c + 3 < nchunks) stage_load_buf(s0, sa, (c + 3) * BK);
-        mma_chunk<WL, BK / 16, BK / 8>(b0, acc);
-        __syncthreads();
-        mma_chunk<WL, 0, BK / 16>(b1, acc);
-        if (c + 2 < nchunks) stage_store(s1, b0);                       // chunk c+2
-        if (c + 4 < nchunks) stage_load_buf(s1, sa, (c + 4) * BK);
-        mma_chunk<WL, BK / 16, BK / 8>(b1, acc);
+    for (; c + 4 < nchunks; c += 2) {           // steady state: every load / store / next-chunk read exists
+        chunk_run<WL, true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
+        chunk_run<WL, true>(b1, b0, true, F0, F1, acc, s1, true, true, sa, (c + 4) * BK);
+    }
+    for (; c + 1 < nchunks; c += 2) {           // the last <= 4 chunks
+        // chunk c (b0): write chunk c+1 (s0) into b1, request chunk c+3 into s0
+        chunk_run<WL, false>(b0, b1, true, F0, F1, acc, s0, true, c + 3 < nchunks, sa, (c + 3) * BK);
+        // chunk c+1 (b1): write chunk c+2 (s1) into b0, request chunk c+4 into s1
+        chunk_run<WL, false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
+    }
+    if (c < nchunks) chunk_run<WL, false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
+    __syncthreads();                           // smem is free for reuse on return
+}
+
+// ---- two-phase tile:  T += X Z^T  (K = 32 n1), then  O[c][r] = sum_p T[p][c] W[r][p]  --------------------------------
+// The shape shared by a row tile of the triangular inverse (X = L[i,:], Z = Y[j,:], W = W_i) and by the fused
+// panel-update + panel-solve tile of the factorisation (X = L[k,:], Z = L[i,:], T0 = -A[i,k]^T, W = W_k).  Waves side
+// by side (WL = 1: a wave owns all 128 p for its 32 columns c), so the accumulator layout of T (lane = c, registers
+// = p) IS the A-operand layout of the second product and T never leaves the register file; W streams through the
+// same double-buffered LDS stage as 4 more chunks of ONE pipeline (B operand only), and its row blocks above the
+// diagonal (W lower triangular) are skipped.  `flag` (optional) is the word that says W has been published by
+// another workgroup of the same launch: polled by one lane before the first W load is issued, then one agent-scope
+// acquire; the chunk barriers that follow cover the workgroup.
+struct TriTile {
+    const float* X;  int64_t ldx;      // 128 rows p, K contiguous
+    const float* Z;  int64_t ldz;      // 128 rows c
+    int n1;                            // K / 32 (multiple of 4, may be 0)
+    const float* W;                    // [128][128] row-major, lower triangular
+    const int* flag;                   // nullptr, or W's ready flag
+};
+
+// One per-lane byte offset per operand (row t >> 3, 16-byte column t & 7); the row group p (32 rows further down) and
+// the K offset of the chunk are wave-uniform and ride in the instruction's SGPR offset.
+struct TriSrc {
+    __amdgpu_buffer_rsrc_t ra, rb, rw;
+    int va, vb, vw;
+    int pa, pb;                        // byte stride of a row group: 32 ldx * 4, 32 ldz * 4  (W: 32 * 128 * 4)
+    int n1, nall;
+};
+
+__device__ __forceinline__ void tri_load_piece(StageRegs& s, const TriSrc& ts, int c, int p) {
+    if (c < ts.n1) {
+        const int sa = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pa);
+        const int sb = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pb);
+        s.a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.ra, ts.va, sa, 0));
+        s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rb, ts.vb, sb, 0));
+    } else {
+        const int so = __builtin_amdgcn_readfirstlane((c - ts.n1) * BK * 4 + p * (32 * TS * 4));
+        s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rw, ts.vw, so, 0));
+    }
+}
+__device__ __forceinline__ void tri_store_piece(const StageRegs& s, float* __restrict__ buf, const TriSrc& ts, int c, int p) {
+    const int t = threadIdx.x;
+    const int row = t >> 3, cq = (t & 7) * 4;
+    if (c < ts.n1) *reinterpret_cast<f32x4*>(buf + (row + 32 * p) * SLD + cq) = s.a[p];
+    *reinterpret_cast<f32x4*>(buf + TS * SLD + (row + 32 * p) * SLD + cq) = s.b[p];
+}
+
+// phase-1 chunk `c` living in `cur`: stores chunk c+1 (from `s`) into `nxt`, requests chunk c+3 into `s`
+template <bool STEADY>
+__device__ __forceinline__ void tri_chunk_p1(const float* cur, float* nxt, int c, Frag<1>& F0, Frag<1>& F1,
+                                             f32x16 (&T)[4], StageRegs& s, const TriSrc& ts) {
+    const bool more = STEADY || (c + 1 < ts.n1);               // is the next chunk a phase-1 chunk (Frag<1> reads)?
+    const bool do_st = STEADY || (c + 1 < ts.nall), do_ld = STEADY || (c + 3 < ts.nall);
+    frag_load<1>(F1, cur, 1);
+    VOLT_SB();
+    frag_mma<1>(F0, T);
+    VOLT_SB();
+    frag_load<1>(F0, cur, 2);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        frag_mma_m<1>(F1, m, T);
+        if (do_st) tri_store_piece(s, nxt, ts, c + 1, m);
+        VOLT_SB();
+    }
+    frag_load<1>(F1, cur, 3);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        frag_mma_m<1>(F0, m, T);
+        if (do_ld) tri_load_piece(s, ts, c + 3, m);
+        VOLT_SB();
+    }
+    __syncthreads();
+    if (more) frag_load<1>(F0, nxt, 0);
+    VOLT_SB();
+    frag_mma<1>(F1, T);
+    VOLT_SB();
+}
+
+// W fragments of K step g (8 values of p) for the row blocks rb >= tp
+struct FragW { f32x4 w[4]; };
+__device__ __forceinline__ void fragw_load(FragW& f, const float* __restrict__ buf, int tp, int g) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    const float* sB = buf + TS * SLD;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+        if (rb >= tp) f.w[rb] = *reinterpret_cast<const f32x4*>(sB + (rb * 32 + l31) * SLD + 8 * g + 4 * lh);
+}
+// registers 4g..4g+3 of T[tp] <-> p = 32 tp + 8g + 4 lh + (0..3)
+__device__ __forceinline__ void fragw_mma_m(const FragW& f, const f32x16& Ttp, int tp, int g, int m, f32x16 (&O)[4]) {
+    const float a = Ttp[4 * g + m];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+        if (rb >= tp) O[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.w[rb][m], O[rb], 0, 0, 0);
+}
+
+// phase-2 chunk tp (compile-time: the triangular skip makes the MFMA count depend on it) living in `cur`
+template <int TP>
+__device__ __forceinline__ void tri_chunk_p2(const float* cur, float* nxt, f32x16 (&T)[4], f32x16 (&O)[4],
+                                             StageRegs& s, const TriSrc& ts) {
+    const int c = ts.n1 + TP;
+    FragW G0, G1;
+    fragw_load(G0, cur, TP, 0);
+    fragw_load(G1, cur, TP, 1);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fragw_mma_m(G0, T[TP], TP, 0, m, O);
+    VOLT_SB();
+    fragw_load(G0, cur, TP, 2);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        fragw_mma_m(G1, T[TP], TP, 1, m, O);
+        if (TP < 3) tri_store_piece(s, nxt, ts, c + 1, m);
+        VOLT_SB();
+    }
+    fragw_load(G1, cur, TP, 3);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        fragw_mma_m(G0, T[TP], TP, 2, m, O);
+        if (TP == 0) tri_load_piece(s, ts, c + 3, m);           // only chunk n1+3 is still to be requested
+        VOLT_SB();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fragw_mma_m(G1, T[TP], TP, 3, m, O);
+    VOLT_SB();
+}
+
+__device__ __forceinline__ bool flag_wait_one_lane(const int* flag) {
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { ok = false; break; }      // seconds: only a bug can get here
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    return ok;       // meaningful in thread 0 only
+}
+__device__ __forceinline__ void flag_publish(int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // restate the wait the compiler may drop
+        __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// T holds T0 on entry; O (zeroed here) holds the product on exit.  Returns false (thread 0) if the flag timed out.
+__device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f32x16 (&O)[4], float* smem) {
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, scq = (tid & 7) * 4;
+    TriSrc ts;
+    ts.ra = __builtin_amdgcn_make_buffer_rsrc((void*)t.X, 0, 0x7fffffff, 0x00020000);
+    ts.rb = __builtin_amdgcn_make_buffer_rsrc((void*)t.Z, 0, 0x7fffffff, 0x00020000);
+    ts.rw = __builtin_amdgcn_make_buffer_rsrc((void*)t.W, 0, TS * TS * 4, 0x00020000);
+    ts.va = (int)(((int64_t)srow * t.ldx + scq) * 4);
+    ts.vb = (int)(((int64_t)srow * t.ldz + scq) * 4);
+    ts.vw = (srow * TS + scq) * 4;
+    ts.pa = (int)(32 * t.ldx * 4);
+    ts.pb = (int)(32 * t.ldz * 4);
+    ts.n1 = t.n1;
+    ts.nall = t.n1 + 4;
+    zero_acc(O);
+    bool ok = true;
+    if (t.flag && t.n1 == 0) {                       // no phase 1 to hide behind: W is the first thing needed
+        ok = flag_wait_one_lane(t.flag);
         __syncthreads();
     }
-    if (c < nchunks) {                         // odd tail: chunk c sits in buffer 0
-        mma_chunk<WL, 0, BK / 8>(smem, acc);
-        __syncthreads();
+    StageRegs s0, s1;
+    float* b0 = smem;
+    float* b1 = smem + STAGE_FLOATS;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_load_piece(s0, ts, 0, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_store_piece(s0, b0, ts, 0, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_load_piece(s0, ts, 1, p);     // odd chunks travel in s0, even ones in s1
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_load_piece(s1, ts, 2, p);
+    __syncthreads();
+    int c = 0;
+    if (t.n1 > 0) {
+        Frag<1> F0, F1;
+        frag_load<1>(F0, b0, 0);
+        for (; c + 4 < t.n1; c += 2) {               // steady state: phase-1 chunks whose prefetches are phase-1 too
+            tri_chunk_p1<true>(b0, b1, c, F0, F1, T, s0, ts);
+            tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
+        }
+        for (; c < t.n1; c += 2) {                   // last 4 chunks of phase 1: the W chunks come into view
+            if (t.flag && c == t.n1 - 4) ok = flag_wait_one_lane(t.flag);   // barriers below order the acquire
+            tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
+            tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
+        }
     }
+    // phase 2: chunks n1 .. n1+3 (n1 is even: chunk n1 sits in buffer 0)
+    tri_chunk_p2<0>(b0, b1, T, O, s0, ts);
+    tri_chunk_p2<1>(b1, b0, T, O, s1, ts);
+    tri_chunk_p2<2>(b0, b1, T, O, s0, ts);
+    tri_chunk_p2<3>(b1, b0, T, O, s1, ts);
+    __syncthreads();                                 // smem is free for reuse on return
+    return ok;
 }
 
 // sum over the 64 lanes (DPP inside 16-lane rows, then four readlanes), result in every lane
@@ -209,13 +476,6 @@ __device__ __forceinline__ float wave_sum_f(float x) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32));
     const float r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
     return (r0 + r1) + (r2 + r3);
-}
-
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 }
 
 }  // namespace volt

@@ -155,7 +155,7 @@ using namespace volt;
 typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, float* ms_host, int* launches_host, volt_group_post_fn post, void* post_ctx);
+                         void* stream, volt_group_post_fn post, void* post_ctx);
 
 namespace {
 struct TailCtx {
@@ -220,8 +220,7 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
     TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
-                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, nullptr, nullptr,
-                                   mll_tail, &ctx)))
+                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx)))
         return rc > 0 ? rc : -1;
     VOLT_LAUNCH_CHECK();
     return 0;
