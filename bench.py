@@ -6,12 +6,14 @@
 A *step* is one pass of the training-loop body of voltron/train_utils.py:243-254 over a batch of
 independent series with K (train_cov) already resident: residual y - EWMA mean -> K + sigma^2 I
 -> blocked Cholesky -> L^-T -> MLL and its gradient wrt raw_noise -> Adam update of raw_noise ->
-(N>1) one RCCL all-reduce of the summed loss/grad scalars.  Series shard across ranks (weak
-scaling: 64 series per GPU), no data-path collective.
+(N>1) one RCCL all-reduce of the summed loss/grad scalars.  Series shard across ranks, no data-path
+collective.  --scaling weak (default): 64 series per GPU; --scaling strong: 64 series in total, split
+evenly over the ranks (BASELINE.json's metric reads "N=4096, batch=64; 1/2/4/8 GPU").
 
 Rank 0 prints ONE JSON line.  `value` = batch-of-64 steps per second summed over ranks, inputs
-resident in HBM.  `roofline` is for the dominant kernel (per-launch HIP events, live);
-`cpu_baseline` times the torch-CPU restatement of the gpytorch path on a bounded sample.
+resident in HBM.  `roofline` is for the dominant kernel (per-launch HIP events in the timed schedule);
+`cpu_baseline` times the torch-CPU restatement of the gpytorch path on a bounded sample (and real
+gpytorch beside it where it is importable); `rollouts` times BASELINE config 5's per-GPU share.
 """
 from __future__ import annotations
 
@@ -57,8 +59,11 @@ def kernel_class_flops(B: int, Np: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)       # ~4.6 s of GPU time: long enough for external samplers
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch series per GPU; strong: --batch series in total, split over the ranks")
+    ap.add_argument("--no-rollouts", action="store_true", help="skip the config-5 rollout leg")
     ap.add_argument("--n", type=int, default=N_SERIES)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,6 +96,10 @@ def main():
     from volt_amd.synthetic import sde_batch
 
     n, B = args.n, args.batch
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"--scaling strong: batch {B} does not divide over {world} ranks")
+        B //= world                                                  # this rank's share of the fixed total
     x, F, vol = sde_batch(B, n, seed=2019, first=rank * B)          # this rank's shard of series
     xd, vold = torch.tensor(x, device=dev), torch.tensor(vol, device=dev)
     y = torch.log(torch.tensor(F[:, 1:], device=dev))
@@ -242,69 +251,170 @@ def main():
                                   "Cholesky, N^3/3 flop each) / 64; ms_per_mll_forward adds the forward solve and log-det")
         del A, Winv, Y, f
 
-    # ---- CPU baseline leg (rank 0, N=1 only): torch-CPU restatement of the gpytorch path
+    # ---- rollouts leg (rank 0): BASELINE config 5's per-GPU share -- 8 series x 10,000 paths x 256 steps at this N
+    roll = None
+    if rank == 0 and not args.no_rollouts and not args.no_aux_legs:
+        roll = rollout_leg(x, F, vol, dev, n)
+
+    # ---- CPU baseline leg (rank 0, N=1 only): torch-CPU restatement of the gpytorch path (+ real gpytorch if present)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import torch_cpu_path as tp
-        ncpu = os.cpu_count() or 1
-        bs = 4 if n >= 4096 else 8
-        Kc = K[:bs].cpu()
-        yc = y[:bs].cpu()
-        mc = ops.ewma(y[:bs], EWMA_K)[..., :-1].cpu()
-        # LAPACK/MKL does not scale to every core of a big host at this size (256 threads ran 2.7x slower than
-        # 8 here): calibrate the thread count on one series and report the baseline at its best setting.
-        best_t, best_c = None, None
-        for t_ in sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu}):
-            torch.set_num_threads(t_)
-            r1 = torch.full((1,), 1e-5, requires_grad=True)
-            tp.mll_step(Kc[:1], yc[:1], mc[:1], r1)
-            t1 = time.perf_counter()
-            tp.mll_step(Kc[:1], yc[:1], mc[:1], r1)
-            c_ = time.perf_counter() - t1
-            if best_c is None or c_ < best_c:
-                best_t, best_c = t_, c_
-        cores = best_t
-        torch.set_num_threads(cores)
-        rawc = torch.full((bs,), 1e-5, requires_grad=True)
-        tp.mll_step(Kc, yc, mc, rawc)                    # warm-up
-        reps = 2
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            mll_c, g_c = tp.mll_step(Kc, yc, mc, rawc)
-        tc = (time.perf_counter() - t1) / reps
-        cpu = {"value": round(1.0 / (tc / bs * B), 5), "unit": "steps/s", "cores": cores, "kind": "port",
-               "sample": f"{bs} of {B} series x {reps} steps at N={n} (torch-CPU fp32 cholesky+autograd, "
-                         f"{tc:.2f} s per {bs}-series step), scaled x{B // bs} to the batch; threads calibrated over "
-                         f"8..{ncpu} on one series, best = {cores} of {ncpu} host cores",
-               "note": "gpytorch absent -- baseline is a torch-only restatement (oracle/torch_cpu_path.py)"}
+        cpu = cpu_baseline_leg(K, y, ops.ewma(y, EWMA_K)[..., :-1], n, args.batch)
 
     if rank == 0:
-        steps_per_s = world * args.steps / dt
+        per_step_series = world * B
+        steps_per_s = per_step_series / args.batch * args.steps / dt
         line = {
             "metric": "mll_grad_steps_per_s", "value": round(steps_per_s, 4),
-            "unit": f"steps/s (1 step = MLL+grad over {B} series of N={n})",
+            "unit": f"steps/s (1 step = MLL+grad over {args.batch} series of N={n})",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"MLL+grad step, N={n}, batch={B} series per GPU, Volatility kernel + EWMA(k={EWMA_K}) mean",
-                       "series_total": B * world, "parallelism": f"series-sharded x{world}",
+                       "series_total": per_step_series, "parallelism": f"series-sharded x{world}",
                        "collective": "all_reduce(2 floats)/step" if world > 1 else "none"},
-            "step_tflops": round(world * B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
+            "step_tflops": round(per_step_series * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
             "loss": round(loss, 6), "not_pd": bad,
             "roofline": roof,
-            "roofline_step": {"what": "whole step as timed (4-stream schedule): algorithmic 2N^3/3 flop per series / ms_per_step",
-                              "bound": "mfma", "achieved": round(world * B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
+            "roofline_step": {"what": "whole step as timed: algorithmic 2N^3/3 flop per series / ms_per_step",
+                              "bound": "mfma", "achieved": round(per_step_series * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
                               "peak": FP32_MFMA_PEAK_TF * world, "unit": "TFLOP/s",
                               "frac": round(B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)},
             "schedule": {"groups": (roof or {}).get("launches", 0) // max(1, (roof or {}).get("lockstep", {}).get("launches", 1)),
                          "streams": "library-internal, forked/joined on the caller's stream"},
             "cpu_baseline": cpu,
+            "rollouts": roll,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()                       # rank 0 ran the roofline legs: leave together
         dist.destroy_process_group()
+
+
+def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
+    """BASELINE config 5 (10k sample paths x 256-step horizon, 64 series over 8 GPUs) at its per-GPU share: 8 series.
+    Times the whole engine call (host preparation + the one kernel launch) and the kernel alone (events on the
+    launch stream).  The kernel is HBM-bound: every step streams the sample's stored factor rows,
+    H^3/6 * 4 bytes per sample in total."""
+    from volt_amd import rollout_engine as re_
+    from volt_amd.synthetic import rollout_inputs
+    G = min(G, F.shape[0])
+    pv, z = rollout_inputs(vol[:G, -1], S, H, seed=3)
+    tx = torch.tensor(x, device=dev)
+    test_x = torch.arange(H, device=dev) / 252. + tx[-1] + tx[1]
+    logy = torch.log(torch.tensor(F[:G, 1:], device=dev))
+    lv = torch.log(torch.tensor(vol[:G], device=dev))
+    pvd, zd = torch.tensor(pv, device=dev), torch.tensor(z, device=dev)
+    best_total, best_kernel, info = None, None, None
+    for rep in range(3):
+        tm = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        samples, info = re_.rollout_series(tx, logy, lv, test_x, pvd, zd, 0, EWMA_K, timing=tm)
+        torch.cuda.synchronize()
+        tot = time.perf_counter() - t0
+        ker = tm["start"].elapsed_time(tm["stop"]) * 1e-3
+        if rep and (best_total is None or tot < best_total):
+            best_total, best_kernel = tot, ker
+    alg = G * S * H ** 3 / 6 * 4
+    out = {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5, per-GPU share)",
+           "total_s": round(best_total, 4), "kernel_ms": round(best_kernel * 1e3, 2),
+           "sample_steps_per_s": round(G * S * H / best_total),
+           "non_pd_paths": int((info != 0).sum().item()),
+           "roofline": {"kernel": "rollout_bordered_kernel", "bound": "hbm", "achieved": round(alg / best_kernel / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / best_kernel / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_GB": round(alg / 1e9, 1)}}
+    del samples
+    return out
+
+
+def cpu_baseline_leg(K, y, mean, n, batch):
+    """The CPU path timed on this box's host cores on a bounded sample of the same workload: the torch-only
+    restatement of gpytorch's dense step (kind "port"), and real gpytorch under max_cholesky_size(N+1) when it is
+    importable -- reported, never the optimisation target."""
+    from oracle import torch_cpu_path as tp
+    ncpu = os.cpu_count() or 1
+    bs = 8 if n >= 4096 else 16
+    bs = min(bs, K.shape[0])
+    Kc, yc, mc = K[:bs].cpu(), y[:bs].cpu(), mean[:bs].cpu()
+    # LAPACK/MKL does not scale to every core of a big host at this size (256 threads ran 2.7x slower than
+    # 8 here): calibrate the thread count on one series and report the baseline at its best setting.
+    best_t, best_c = None, None
+    for t_ in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+        torch.set_num_threads(t_)
+        r1 = torch.full((1,), 1e-5, requires_grad=True)
+        tp.mll_step(Kc[:1], yc[:1], mc[:1], r1)
+        t1 = time.perf_counter()
+        tp.mll_step(Kc[:1], yc[:1], mc[:1], r1)
+        c_ = time.perf_counter() - t1
+        if best_c is None or c_ < best_c:
+            best_t, best_c = t_, c_
+    cores = best_t
+    torch.set_num_threads(cores)
+    rawc = torch.full((bs,), 1e-5, requires_grad=True)
+    tp.mll_step(Kc, yc, mc, rawc)                    # warm-up
+    reps = 3
+    times = []
+    for _ in range(reps):
+        t1 = time.perf_counter()
+        tp.mll_step(Kc, yc, mc, rawc)
+        times.append(time.perf_counter() - t1)
+    tc = float(np.median(times))
+    cpu = {"value": round(1.0 / (tc / bs * batch), 5), "unit": "steps/s", "cores": cores, "kind": "port",
+           "sample": f"{bs} of {batch} series x {reps} steps at N={n} (torch-CPU fp32 cholesky+autograd, median "
+                     f"{tc:.2f} s per {bs}-series step, min {min(times):.2f} max {max(times):.2f}), scaled x{batch / bs:g} to the "
+                     f"batch; threads calibrated over 8..{ncpu} on one series, best = {cores} of {ncpu} host cores"}
+    cpu["gpytorch"] = gpytorch_leg(Kc, yc, mc, n, batch, cores)
+    if cpu["gpytorch"].get("value") is None:
+        cpu["note"] = "gpytorch absent -- baseline is a torch-only restatement (oracle/torch_cpu_path.py)"
+    return cpu
+
+
+def gpytorch_leg(Kc, yc, mc, n, batch, cores):
+    """Real gpytorch, if this box has it (it is not in the build image): the reference's own step
+    ``loss = -mll(model(x), y); loss.backward()`` (voltron/train_utils.py:243-250) with the cached train_cov as the
+    model's covariance, one series at a time as the reference trains, Cholesky path forced by
+    max_cholesky_size(N+1).  Returns {"value": None, "reason": ...} when it cannot run."""
+    try:
+        import gpytorch
+    except Exception as e:                                  # noqa: BLE001 -- absent or broken: report, do not fail
+        return {"value": None, "reason": f"import gpytorch failed: {type(e).__name__}: {e}"[:200]}
+    try:
+        class _Cached(gpytorch.models.ExactGP):
+            def __init__(self, tx, ty, lik, mean, cov):
+                super().__init__(tx, ty, lik)
+                self._m, self._c = mean, cov
+
+            def forward(self, x):
+                return gpytorch.distributions.MultivariateNormal(self._m, self._c)
+
+        torch.set_num_threads(cores)
+        ns = min(2, Kc.shape[0])
+        tx = torch.arange(n, dtype=torch.float32) / 252.
+        times, vals = [], []
+        with gpytorch.settings.max_cholesky_size(n + 1):
+            for b in range(ns):
+                lik = gpytorch.likelihoods.GaussianLikelihood()
+                lik.raw_noise.data = torch.tensor([1e-5])                       # train_utils.py:222
+                model = _Cached(tx, yc[b], lik, mc[b], Kc[b])
+                model.train(); lik.train()
+                mll = gpytorch.mlls.ExactMarginalLogLikelihood(lik, model)
+                for rep in range(2):
+                    lik.zero_grad()
+                    t1 = time.perf_counter()
+                    loss = -mll(model(tx), yc[b])
+                    loss.backward()
+                    if rep:
+                        times.append(time.perf_counter() - t1)
+                vals.append(float(-loss))
+        tc = float(np.median(times))
+        return {"value": round(1.0 / (tc * batch), 5), "unit": "steps/s", "cores": cores, "kind": "reference",
+                "version": getattr(gpytorch, "__version__", "?"), "mll_first_series": vals[0],
+                "sample": f"{ns} of {batch} series x 1 step at N={n} (gpytorch ExactMarginalLogLikelihood + backward under "
+                          f"max_cholesky_size(N+1), {tc:.2f} s per series), scaled x{batch} to the batch"}
+    except Exception as e:                                  # noqa: BLE001
+        return {"value": None, "reason": f"gpytorch present but the leg failed: {type(e).__name__}: {e}"[:300]}
 
 
 if __name__ == "__main__":

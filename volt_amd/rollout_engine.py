@@ -83,9 +83,9 @@ def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
 
 
 def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode, k, latent_mean=None, theta=None,
-                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="closed"):
+                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="closed", timing=None):
     """Batched engine entry.  train_x [N]; log_y, log_vol_path [G,N]; test_x [H]; pred_vol, z [G,S,H].
-    Returns (samples [G,S,H] on the device, info [G,S])."""
+    Returns (samples [G,S,H] on the device, info [G,S]).  `timing` (a dict) receives events bracketing the kernel."""
     dev = train_x.device
     G, N = log_y.shape
     S, H = pred_vol.shape[-2:]
@@ -119,10 +119,16 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
 
     def P(t):
         return None if t is None else t.data_ptr()
+    if timing is not None:
+        timing["start"] = torch.cuda.Event(enable_timing=True)
+        timing["stop"] = torch.cuda.Event(enable_timing=True)
+        timing["start"].record()
     _lib.check(_lib.lib().volt_rollout_bordered_f32(
         P(rho), P(tau), P(acc0), P(dx), P(hist_y), P(hist_e1), P(hist_e2), P(ema_prev), P(mrl), P(lat), P(w),
         P(pv), P(zz), P(samples), P(scratch), P(info), G, S, H, k, mean_mode, int(theta is not None),
         float(theta or 0.0), float(mr_theta), float(jitter), _lib.stream_ptr()), "volt_rollout_bordered")
+    if timing is not None:
+        timing["stop"].record()
     return samples, info
 
 
