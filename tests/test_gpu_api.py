@@ -341,6 +341,50 @@ def test_batched_forecast_driver_writes_reference_layout(va, tmp_path):
     assert float((out[:, :, 0].mean(1) - closes[:, ntrain * 0 + T - 1 - ((T - ntrain) % 3) * 0 - 1].log().cpu()).abs().max()) < 0.5
 
 
+@pytest.mark.parametrize("mean", ["ewma", "dewma", "constant", "loglinear"])
+def test_batched_driver_matches_per_series_functions(va, mean):
+    """the batched driver's samples equal what the reference's per-ticker body produces with the same
+    vol path, vol-forecast sample and N(0,1) draws -- Rollouts for the EWMA family (GenerateMultiMeanPreds.py:110-112),
+    one multi-point GeneratePrediction for a standard mean (:113-119)."""
+    from volt_amd import gp
+    from volt_amd.forecast import GenerateStockPredictionsBatch, realised_vol
+    from volt_amd.means import DEWMAMean, LogLinearMean
+    from volt_amd.models import VoltMagpie
+    from volt_amd.rollout_utils import GeneratePrediction, Rollouts
+    B, T, ntrain, H, S, k = 3, 90, 80, 6, 7, 10
+    x, F, vol = sde_batch(B, T - 1, seed=91)
+    closes = dev(F)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    dbg = {}
+    out = GenerateStockPredictionsBatch(["A", "B", "C"], closes, forecast_horizon=H, train_iters=5, nsample=S,
+                                        ntrain=ntrain, mean=mean, k=k, ntimes=1, vol_iters=2, vol_fn=realised_vol,
+                                        generator=g, debug=dbg)
+    assert tuple(out.shape) == (B, S, H) and torch.isfinite(out).all()
+    train_x = torch.arange(ntrain - 1, device="cuda") / 252.
+    test_x = torch.arange(H, device="cuda") / 252. + train_x[-1] + train_x[1]
+    for b in range(B):
+        ty = dbg["train_y"][b]                                            # [ntrain] prices of the last window
+        m = VoltMagpie(train_x, ty[1:].log(), gp.GaussianLikelihood().cuda(), dbg["vol"][b], k=k)
+        if mean == "dewma":
+            m.mean_module = DEWMAMean(train_x, ty[1:].log(), k)
+        if mean in ("ewma", "dewma"):
+            ref = Rollouts(train_x, ty, test_x, m, nsample=S, pred_vol=dbg["pred_vol"][b], z=dbg["z"][b])
+        else:
+            bm = dbg["model"].mean_module
+            if mean == "constant":
+                m.mean_module = gp.ConstantMean().cuda()
+                m.mean_module.constant.data = bm.constant.data[b].clone()
+            else:
+                m.mean_module = LogLinearMean(1).cuda()
+                m.mean_module.weights.data = bm.weights.data[b].clone()
+                m.mean_module.bias.data = bm.bias.data[b].clone()
+            ref = GeneratePrediction(train_x, ty, test_x, dbg["pred_vol"][b], m, z=dbg["z"][b]).detach().cpu()      # :118
+        np.testing.assert_allclose(out[b].numpy(), ref.numpy(), atol=2e-4, rtol=0)
+    if mean in ("constant", "loglinear"):                                # the per-series mean parameters were trained
+        p0 = [p for p in dbg["model"].mean_module.parameters()][0]
+        assert p0.shape[0] == B and float(p0.detach().std()) > 0
+
+
 def test_model_method_generate_prediction_twin(va):
     """VoltronGP.GeneratePrediction(test_x, pred_vol, n_sample) (VoltronGP.py:62-95, the notebook's cell 15):
     H-point joint prediction with n_sample draws, checked against the oracle's GeneratePrediction restatement

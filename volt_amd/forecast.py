@@ -21,10 +21,11 @@ import torch
 
 from . import rollout_engine
 from .distributed import shard_range
-from .means import EWMAMean, DEWMAMean, TEWMAMean
+from .rollout_utils import _posterior_draw
 from .train_utils import LearnGPCV, TrainVoltMagpieBatch, TrainVolModelBatch
 
 _MODES = {"ewma": 0, "dewma": 1, "tewma": 2}
+_STANDARD = ("constant", "loglinear", "linear")
 
 
 def realised_vol(train_x, prices, span=20, floor=1e-3):
@@ -37,10 +38,31 @@ def realised_vol(train_x, prices, span=20, floor=1e-3):
     return v.clamp_min(floor)
 
 
+def _standard_mean_prediction(model, train_x, log_y, vol, test_x, pred_vol, z):
+    """"VOLT + standard mean" (GenerateMultiMeanPreds.py:113-119): ONE joint draw over the whole horizon per path,
+    GeneratePrediction(train_x, train_y, test_x, predvol, voltron) with predvol [S,H] -- rollout_utils.py:6-53 -- for
+    every series of the batched model in turn (each is its own GP; the S systems of a series run batched on the
+    device exactly as in the per-series function).  pred_vol, z [B,S,H] -> samples [B,S,H]."""
+    B, S, H = pred_vol.shape
+    N = train_x.numel()
+    full_x = torch.cat((train_x, test_x))
+    with torch.no_grad():
+        m_tr = model.mean_module(train_x.unsqueeze(-1)).reshape(B, N)
+        m_te = model.mean_module(test_x.unsqueeze(-1)).reshape(B, H)
+    out = torch.empty(B, S, H, device=train_x.device)
+    for b in range(B):
+        full_vol = torch.cat((vol[b].unsqueeze(0).expand(S, N), pred_vol[b]), -1)        # :17-20
+        draw = _posterior_draw(model.covar_module, full_x, full_vol, N, (log_y[b] - m_tr[b]).reshape(1, N, 1),
+                               m_te[b].reshape(1, H, 1), z[b].reshape(S, H, 1), 1e-4)      # :26-53
+        out[b] = draw.squeeze(-1)
+    return out
+
+
 def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample, mean, k, gpcv_iters, vol_iters,
-                      data_iters, theta, vol_fn, generator, save, path_fn):
+                      data_iters, theta, vol_fn, generator, save, path_fn, debug=None):
     """One batched pass per window: GPCV -> data model -> vol forecasters -> rollouts, every stage for all series of
-    this rank at once.  series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e]."""
+    this rank at once.  series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e].
+    ``debug`` (a dict) receives the last window's intermediates (vol, pred_vol, z, model) for tests."""
     dev = series.device
     B = series.shape[0]
     H = test_x.numel()
@@ -51,18 +73,20 @@ def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample,
             vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters)                    # all series at once
         else:
             vol = vol_fn(train_x, train_y)                                               # [B, ntrain-1]
-        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k)
-        if mean != "ewma":
-            cls = {"dewma": DEWMAMean, "tewma": TEWMAMean}[mean]
-            model.mean_module = cls(train_x, train_y[:, 1:].log(), k)
+        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean)
         vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters)
         vmod.eval()
-        pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous()   # [B,S,H]
+        pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous().detach()   # [B,S,H]
         z = torch.randn(B, nsample, H, device=dev, generator=generator)
         latent = train_y.log().mean(-1) if theta is not None else None                   # rollout_utils.py:60-63
-        samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
-                                                      _MODES[mean], k, latent_mean=latent, theta=theta)
-        last = samples.cpu()
+        if mean in _MODES:                                                               # Rollouts, :110-112
+            samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
+                                                          _MODES[mean], k, latent_mean=latent, theta=theta)
+        else:                                                                            # VOLT + standard mean, :113-119
+            samples = _standard_mean_prediction(model, train_x, train_y[:, 1:].log(), vol, test_x, pred_vol, z)
+        if debug is not None:
+            debug.update(vol=vol, pred_vol=pred_vol, z=z, model=model, train_y=train_y)
+        last = samples.detach().cpu()                                                    # .detach(): :118
         if save:
             for b, name in enumerate(names):
                 path = path_fn(name, last_day)
@@ -73,13 +97,15 @@ def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample,
 
 def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=20, train_iters=400, nsample=1000,
                                   ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=None,
-                                  vol_iters=None, par_dir="./saved-outputs/", generator=None):
+                                  vol_iters=None, par_dir="./saved-outputs/", generator=None, debug=None):
     """closes [B, T] prices for B tickers on a common calendar (device tensor).  Same window schedule,
-    model name and file layout as GenerateStockPredictions (GenerateMultiMeanPreds.py:69-83,128).
+    model name and file layout as GenerateStockPredictions (GenerateMultiMeanPreds.py:69-83,128); ``mean`` in
+    ewma / dewma / tewma takes the Rollouts branch (:110-112), constant / loglinear / linear the "VOLT + standard
+    mean" branch (:113-119: one multi-point GeneratePrediction per path).
     Under torch.distributed each rank takes a contiguous shard of the tickers.  Returns the samples of
     the last window, [B_local, nsample, forecast_horizon] on the CPU."""
-    if mean not in _MODES:
-        raise NotImplementedError("the batched driver covers the EWMA mean family (Rollouts path, :110-112)")
+    if mean not in _MODES and mean not in _STANDARD:
+        raise ValueError(f"unknown mean {mean!r}: one of {sorted(_MODES) + list(_STANDARD)}")
     dev = closes.device
     lo, hi = shard_range(len(tickers))
     tickers, closes = list(tickers)[lo:hi], closes[lo:hi]
@@ -98,7 +124,7 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
         date = str(last_day) if dates is None else str(dates[last_day])
         return os.path.join(par_dir, tckr, model_name + date + ".pt")                    # :128
     return _forecast_windows(tickers, closes, end_idxs.tolist(), ntrain, train_x, test_x, nsample, mean, k,
-                             train_iters, vol_iters, train_iters, None, vol_fn, generator, save, path_fn)
+                             train_iters, vol_iters, train_iters, None, vol_fn, generator, save, path_fn, debug)
 
 
 def GenerateWindPredictionsBatch(stations, data, forecast_horizon=100, ntrain=400, n_test_times=10, nsample=1000, k=400,

@@ -171,6 +171,8 @@ def _dense(c):
 
 class Mean(Module):
     def __call__(self, x):
+        if x.ndimension() == 1:          # gpytorch.means.Mean.__call__ adds the feature dimension to 1-D inputs
+            x = x.unsqueeze(1)
         res = self.forward(x)
         return res
 

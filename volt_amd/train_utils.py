@@ -263,21 +263,45 @@ def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_it
 
 
 def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, printing=False, process_group=None,
-                         shared_noise=False):
+                         shared_noise=False, mean_func="ewma", theta=0.5):
     """B independent series in one batched model (train_y [B,N] raw prices[1:], vol_path [B,N]).
     Per-series raw_noise by default (each series is its own GP, as in the reference's Python loop over
     tickers); ``shared_noise`` ties one likelihood across series AND ranks, whose gradient is then
-    all-reduced.  Returns (model, likelihood, last per-series losses)."""
+    all-reduced.  ``mean_func`` as in TrainVoltMagpieModel (train_utils.py:199-219): the EWMA family has
+    no trainable parameters; 'constant' / 'loglinear' / 'linear' get one parameter set PER SERIES (batch_shape [B]),
+    trained with the noise like the reference's grad_flags say.  Returns (model, likelihood, last per-series losses)."""
     from . import distributed as vdist
     B = train_y.shape[0]
-    lh = GaussianLikelihood(batch_shape=torch.Size() if shared_noise else torch.Size([B])).to(train_x.device)
-    model = VoltMagpie(train_x, train_y.log(), lh, vol_path, k=k).to(train_x.device)
+    dev = train_x.device
+    lh = GaussianLikelihood(batch_shape=torch.Size() if shared_noise else torch.Size([B])).to(dev)
+    model = VoltMagpie(train_x, train_y.log(), lh, vol_path, k=k).to(dev)
+    mf = mean_func.lower()
+    trainable = []
+    if mf == "dewma":
+        model.mean_module = DEWMAMean(train_x, train_y.log(), k).to(dev)
+    elif mf == "tewma":
+        model.mean_module = TEWMAMean(train_x, train_y.log(), k).to(dev)
+    elif mf == "meanrevert":
+        model.mean_module = MeanRevertingEMAMean(train_x, train_y.log(), k, theta).to(dev)
+    elif mf == "constant":
+        model.mean_module = gp.ConstantMean(batch_shape=torch.Size([B])).to(dev)
+    elif mf == "loglinear":
+        model.mean_module = LogLinearMean(1, batch_shape=torch.Size([B])).to(dev)
+        model.mean_module.initialize_from_data(train_x, train_y.log())
+    elif mf == "linear":
+        model.mean_module = gp.LinearMean(1, batch_shape=torch.Size([B])).to(dev)
+    elif mf != "ewma":
+        raise ValueError(f"unknown mean_func {mean_func!r}")
     lh.raw_noise.data.fill_(1e-5)
     for p in model.parameters():
         p.requires_grad = False
     lh.raw_noise.requires_grad = True
+    if mf in ("constant", "loglinear", "linear"):
+        trainable = list(model.mean_module.parameters())
+        for p in trainable:
+            p.requires_grad = True
     model.train()
-    optimizer = torch.optim.Adam([lh.raw_noise], lr=0.1)
+    optimizer = torch.optim.Adam([lh.raw_noise] + trainable, lr=0.1)
     mll = ExactMarginalLogLikelihood(lh, model)
     losses = None
     for i in range(train_iters):
