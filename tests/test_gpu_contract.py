@@ -248,3 +248,20 @@ def test_one_launch_trsv_f32_large(ops, B, n):
     # twice in a row on the same stream: the flags are re-zeroed per call
     z2 = ops.trsv(f, dev(rhs)).double()
     assert torch.equal(z, z2)
+
+
+@pytest.mark.parametrize("B,n", [(3, 1500), (12, 1100), (5, 4096)])
+def test_small_batch_split_schedules(ops, B, n):
+    """Small batches cut every long product into K-slices (B < 8 on one stream, 10 <= B < 16 as two split groups): the
+    result agrees with the fp64 oracle, and -- the slabs are summed in slice order whoever arrives last -- two runs are
+    bitwise identical."""
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    s2 = torch.full((B,), SIG2, device="cuda")
+    out, alpha, info = ops.mll_step(K, dev(y - mean), s2)
+    out, alpha = out.clone(), alpha.clone()
+    assert int(info.abs().sum()) == 0
+    rows = [0, B - 1]
+    _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out.cpu().numpy(), alpha.cpu().numpy(), rows)
+    out2, alpha2, _ = ops.mll_step(K, dev(y - mean), s2)
+    assert torch.equal(out, out2) and torch.equal(alpha, alpha2)

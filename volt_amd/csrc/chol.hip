@@ -685,6 +685,189 @@ __global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__
     if (jb.i >= 0 && red.rpad) trtri_reduce(O, Np, jb.i, jb.j, jb.b, red, smem);
 }
 
+// ----------------------------------------------------------------------------- small batches: split-K step kernel
+// With fewer than ~16 matrices a launch has far fewer tiles than the chip has workgroup slots, and its duration is
+// that of its LONGEST tile (K = 128 k) running on one CU: one series of N = 4096 spent 3.4 of its 4.5 ms that way.
+// Here every long product is cut into S K-slices, one workgroup each; a slice dumps its partial accumulators (64 KB)
+// into a slab, and the LAST slice of a tile to arrive (one atomic ticket per tile) adds the slabs up IN SLICE ORDER --
+// the sum does not depend on who is last -- and carries on: the W product for panel / trtri tiles, the store for the
+// diagonal look-ahead.  (A first attempt at this in round 1 used fp32 atomics on the panel update only and gained
+// nothing: the trtri tiles of the same launch are just as long.  All three products are split here.)
+constexpr int VOLT_SPLITK_SLABS = 64;    // the split-K slab of a workspace holds 64 (n+1) tiles of 128 x 128 floats
+struct SplitK {
+    float* slab;         // [tiles of one launch][S][128*128]
+    int* count;          // [n launches][tiles of one launch] arrival counters, zeroed per call
+    int S;               // slice slots per tile in the grid
+    int L;               // K blocks (of 128) per slice: a tile of kb blocks is cut into min(S, ceil(kb / L)) slices
+    int cap;             // tile-slab rows ((n+1) tiles each) this group may use: S * B <= cap
+};
+
+// Slabs are stored WRITE-THROUGH (sc1): the data goes to memory without a release fence.  A release
+// (buffer_wbl2) writes back every dirty line of the XCD's L2 -- with hundreds of slices arriving per launch, each
+// behind its own release, the split schedule ran SLOWER the more slices there were (B = 8: S = 2 5.1 ms, S = 8 9.0 ms).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void slab_dump(const f32x16 (&acc)[4], float* __restrict__ slab) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, TS * TS * 4, 0x00020000);
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[t4][4 * g + e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((t4 * 4 + g) * NT + (int)threadIdx.x) * 16, 0,
+                                                   16 /* sc1 */);
+        }
+}
+__device__ __forceinline__ void slab_sum(f32x16 (&acc)[4], const float* __restrict__ slabs, int nsl) {
+    zero_acc(acc);
+    for (int sidx = 0; sidx < nsl; ++sidx) {
+        const f32x4* in = reinterpret_cast<const f32x4*>(slabs + (int64_t)sidx * TS * TS);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = in[(t4 * 4 + g) * NT + threadIdx.x];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t4][4 * g + e] += v[e];
+            }
+    }
+}
+// true in every thread of the LAST workgroup of the tile to get here; that workgroup may then read every slab
+__device__ __forceinline__ bool splitk_arrive(int* counter, int nsl) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wave's write-through slab stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == nsl - 1);
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
+template <bool FROMK>
+__global__ __launch_bounds__(256, 2) void factor_step_split_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                                  float* __restrict__ Y, int* __restrict__ info, int Np,
+                                                                  int k_upd, int i_tri, int B, KSource src, TriReduce red,
+                                                                  SplitK sk) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    const int n = Np / TS, S = sk.S;
+    int w = blockIdx.x;
+    const int k = k_upd;                                     // k >= 0 always here (the trailing trtri row passes k = n)
+    // ---- diagonal tiles: as in factor_step_kernel
+    if (k < n && w < B) {
+        if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, w, src, smem);
+        else if (k == 1) update_body<FROMK>(A, Np, 1, 1, 0, 1, true, w, src, smem);
+        if (k > 0) {
+            __threadfence_block();
+            __syncthreads();
+        }
+        diag_body(A, Winv, info, Np, k, w, smem);
+        return;
+    }
+    if (k < n) w -= B;
+    int* count = sk.count + (int64_t)k * B * (n + 1);        // this launch's counters
+    const int npre = (k >= 1 && k + 1 < n) ? B : 0;
+    // ---- diagonal look-ahead, split: tile index = matrix
+    if (w < npre * S) {
+        const int b = w / S, sl = w % S;
+        const int kb = k;
+        int nsl = (kb + sk.L - 1) / sk.L;
+        nsl = nsl < 1 ? 1 : (nsl > S ? S : nsl);
+        if (sl >= nsl) return;
+        const int b0 = sl * kb / nsl, b1 = (sl + 1) * kb / nsl;
+        float* Ab = A + (int64_t)b * Np * Np;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+        f32x16 acc[4];
+        zero_acc(acc);
+        gemm_nt_128<0>(Ab + (int64_t)(k + 1) * TS * Np + (int64_t)b0 * TS, Np, Ab + (int64_t)(k + 1) * TS * Np + (int64_t)b0 * TS, Np,
+                       (b1 - b0) * (TS / BK), acc, smem);
+        if (nsl > 1) {
+            float* slabs = sk.slab + (int64_t)b * S * TS * TS;
+            slab_dump(acc, slabs + (int64_t)sl * TS * TS);
+            if (!splitk_arrive(count + b, nsl)) return;
+            slab_sum(acc, slabs, nsl);
+        }
+        const bool usek = FROMK && src.K != nullptr;
+        const float add = usek ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
+        const float* Kb = usek ? src.K + (int64_t)b * src.bsk : nullptr;
+        float* C = Ab + (int64_t)(k + 1) * TS * Np + (int64_t)(k + 1) * TS;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                    const int c = wc * 64 + tn * 32 + (lane & 31);
+                    C[(int64_t)r * Np + c] = input_elem(src, Kb, add, Ab, Np, usek, (k + 1) * TS + r, (k + 1) * TS + c)
+                                             - acc[tm * 2 + tn][q];
+                }
+        return;
+    }
+    w -= npre * S;
+    // ---- panel and trtri tiles, split: two-phase tiles whose first phase is cut into slices
+    TriJob jb;
+    int tile, kb;                                            // tile index within the launch (after the B look-ahead tiles), K blocks
+    const int npan = (k < n) ? (n - k - 1) * B : 0;
+    const int sl = w % S;
+    int wt = w / S;
+    if (wt < npan) {
+        int t, b;
+        decode_tile_batch(wt, n - k - 1, B, t, b);
+        jb = panel_job<FROMK>(A, Winv, Np, k + 1 + t, k, b, src);
+        tile = B + wt;
+        kb = k;
+    } else {
+        wt -= npan;
+        int j, b;
+        decode_tile_batch(wt, i_tri + 1, B, j, b);
+        if (j == i_tri) {
+            if (sl == 0) trtri_diag_body(Winv, Y, Np, i_tri, b, red, smem);
+            return;
+        }
+        jb = trtri_job(A, Winv, Y, Np, i_tri, j, b);
+        tile = B + npan + wt;
+        kb = i_tri - j;
+    }
+    int nsl = (kb + sk.L - 1) / sk.L;
+    nsl = nsl < 1 ? 1 : (nsl > S ? S : nsl);
+    if (sl >= nsl) return;
+    const int b0 = sl * kb / nsl, b1 = (sl + 1) * kb / nsl;
+    f32x16 T[4], O[4];
+    if (sl == 0 && jb.c0 && jb.row_ok && jb.vec_ok) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(jb.c0 + 32 * tm + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[tm][4 * g + e] = -v[e];
+            }
+    } else if (sl == 0 && jb.c0 && jb.row_ok) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) T[tm][q] = -jb.c0[32 * tm + 8 * (q >> 2) + (q & 3)];
+    } else {
+        zero_acc(T);
+    }
+    gemm_nt_128<1>(jb.t.X + (int64_t)b0 * TS, jb.t.ldx, jb.t.Z + (int64_t)b0 * TS, jb.t.ldz, (b1 - b0) * (TS / BK), T, smem);
+    if (nsl > 1) {
+        float* slabs = sk.slab + (int64_t)tile * S * TS * TS;
+        slab_dump(T, slabs + (int64_t)sl * TS * TS);
+        if (!splitk_arrive(count + tile, nsl)) return;
+        slab_sum(T, slabs, nsl);
+    }
+    jb.t.n1 = 0;                                             // phase 1 is done: the W product alone
+    const bool ok = tri_tile_run(jb.t, T, O, smem);
+    if (threadIdx.x == 0 && !ok) atomicCAS(info + jb.b, 0, (int)0x80000000);
+    tri_store(O, jb.out, Np);
+    if (jb.i >= 0 && red.rpad) trtri_reduce(O, Np, jb.i, jb.j, jb.b, red, smem);
+}
+
 // Clears the first word of every W block: it is the "ready" flag of the block (diag_body / panel_body).
 __global__ void clear_w_flags_kernel(float* __restrict__ Winv, int count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -793,6 +976,7 @@ struct FactorOpts {
     KSource src;            // src.K != nullptr: tiles of block columns >= 1 take their input straight from K
     float* Y;               // nullptr: no triangular inverse
     TriReduce red;          // red.rpad != nullptr: fuse z-partials and Frobenius partials into trtri
+    SplitK sk;              // sk.slab != nullptr and sk.S > 1: small-batch launches cut their long products into K-slices
 };
 
 // Everything one group of matrices needs: the batch is cut into contiguous groups that run the same
@@ -814,6 +998,37 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     const int itri = (g.o.Y && k > 0) ? k - 1 : -1;
     const int npre = (k >= 1 && k + 1 < n) ? B : 0;          // diagonal look-ahead workgroups
     const int grid = B + npre + (n - k - 1) * B + (itri >= 0 ? (itri + 1) * B : 0);
+    if (g.o.sk.slab && g.o.sk.S > 1) {                       // small batch: every long product in K-slices
+        // slices of about equal length: L blocks each, so that the launch has ~`target` of them (g.o.sk.S carries it)
+        const int kk = k < n ? k : n - 1;
+        const double blocks = (double)B * ((double)(n - kk - 1) * kk + 0.5 * kk * (kk - 1) + kk);   // panel + trtri + look-ahead
+        int L = (int)(blocks / (double)g.o.sk.S + 0.999);
+        if (L < 2) L = 2;
+        int S = (kk + L - 1) / L;
+        if (S < 1) S = 1;
+        if (S > 8) S = 8;
+        if (S * B > g.o.sk.cap) S = g.o.sk.cap / B;
+        if (S < 1) S = 1;
+        SplitK sk = g.o.sk;
+        sk.S = S;
+        sk.L = L;
+        const int gs = B + S * (npre + (n - k - 1) * B + (itri >= 0 ? (itri + 1) * B : 0));
+        if (tm) tm->begin(0, g.s);
+        if (g.o.src.K)
+            hipLaunchKernelGGL(factor_step_split_kernel<true>, dim3(gs), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
+                               k, itri, B, g.o.src, g.o.Y ? g.o.red : nored, sk);
+        else
+            hipLaunchKernelGGL(factor_step_split_kernel<false>, dim3(gs), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
+                               k, itri, B, g.o.src, g.o.Y ? g.o.red : nored, sk);
+        if (tm) tm->end(g.s);
+        if (k + 1 == n && g.o.Y) {                           // the trailing trtri row: k = n (no factorisation part)
+            if (tm) tm->begin(1, g.s);
+            hipLaunchKernelGGL(factor_step_split_kernel<false>, dim3(S * n * B), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y,
+                               g.info, Np, n, n - 1, B, g.o.src, g.o.red, sk);
+            if (tm) tm->end(g.s);
+        }
+        return;
+    }
     if (tm) tm->begin(0, g.s);
     if (g.o.src.K)
         hipLaunchKernelGGL(factor_step_kernel<true>, dim3(grid), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
@@ -831,9 +1046,13 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
 }
 
 // info = 0 and every W block's ready flag cleared, on the caller's stream before anything forks from it
-static int begin_factor(float* Winv, int* info, int B, int n, hipStream_t s) {
+static int begin_factor(float* Winv, int* info, int B, int n, hipStream_t s, int* sk_count = nullptr) {
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
+    if (sk_count) {                                          // split-K arrival counters: [n+1 launches][B (n+1) tiles]
+        e = hipMemsetAsync(sk_count, 0, sizeof(int) * (size_t)(n + 1) * (n + 1) * B, s);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(clear_w_flags_kernel, dim3((B * n + 255) / 256), dim3(256), 0, s, Winv, B * n);
     return 0;
 }
@@ -894,12 +1113,26 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
                              int force_groups = 0) {
     const int n = Np / TS;
     StreamPool* pool = stream_pool();
-    const int G = pool ? pick_groups(pool, B, force_groups) : 1;
-    int rc = begin_factor(Winv, info, B, n, s);
+    int G = pool ? pick_groups(pool, B, force_groups) : 1;
+    // Small batches: cut the long products into K-slices so that a launch has ~`target` workgroups (measured, N = 4096,
+    // ms/step unsplit -> split: B = 1 4.5 -> 2.0, 2 4.6 -> 2.6, 4 4.7 -> 3.4, 6 4.7 -> 4.4; from B = 8 on a launch has a
+    // tile per CU and splitting on ONE stream stops paying: B = 8 stays unsplit, 4.8 ms).  10 <= B < 16: two split groups
+    // on two streams (B = 12: 8.4 -> 6.1 ms).
+    static const int target = getenv("VOLT_SPLITK_TARGET") ? atoi(getenv("VOLT_SPLITK_TARGET")) : 512;
+    static const int split_groups = getenv("VOLT_SPLITK_GROUPS") ? atoi(getenv("VOLT_SPLITK_GROUPS")) : 2;
+    const bool can_split = o.sk.slab && o.sk.count && force_groups == 0 && target > 1;
+    FactorOpts o1 = o;
+    o1.sk.S = 1;                                             // > 1: the split schedule, and the slices wanted per launch
+    if (can_split && G == 1 && B < 8) o1.sk.S = target;
+    if (can_split && G == 1 && B >= 10 && B < 16 && pool && split_groups > 1 && B % split_groups == 0) {
+        G = split_groups;
+        o1.sk.S = target / G;
+    }
+    int rc = begin_factor(Winv, info, B, n, s, o1.sk.S > 1 ? o1.sk.count : nullptr);
     if (rc) return rc;
     if (tm) tm->start(s);
     if (G == 1) {
-        const Group g{A, Winv, info, o, B, s};
+        const Group g{A, Winv, info, o1, B, s};
         for (int k = 0; k < n; ++k) enqueue_step(g, Np, k, tm);
         if (post) post(post_ctx, 0, B, s);
         VOLT_LAUNCH_CHECK();
@@ -911,8 +1144,13 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     Group grp[MAX_GROUPS];
     VOLT_TRY(hipEventRecord(pool->fork, s));
     for (int g = 0; g < G; ++g) {
-        FactorOpts og = o;
+        FactorOpts og = o1;
         const int b0 = g * Bg;
+        if (og.sk.S > 1) {                                   // each group its own share of the slab and of the counters
+            og.sk.slab += (int64_t)g * (VOLT_SPLITK_SLABS / G) * (n + 1) * TS * TS;
+            og.sk.count += (int64_t)g * (n + 1) * (n + 1) * Bg;
+            og.sk.cap = VOLT_SPLITK_SLABS / G;
+        }
         if (og.src.K) {
             og.src.K += (int64_t)b0 * og.src.bsk;
             if (og.src.sigma2) og.src.sigma2 += b0;
@@ -963,12 +1201,12 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, volt_group_post_fn post, void* post_ctx) {
+                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count) {
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
     // block column 0 (its diagonal tile is factored straight out of A) is copied; everything else is read from K
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
-    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}};
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}, SplitK{sk_slab, sk_count, 1, 1, VOLT_SPLITK_SLABS}};
     return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
 }
 
@@ -1019,7 +1257,8 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
     if (B < 0) return -4;
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
-    FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}};
+    FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0},
+                 SplitK{nullptr, nullptr, 1, 1, 0}};
     return run_factor_groups(A, Winv, info, B, Np, (hipStream_t)stream, o);
 }
 
@@ -1040,7 +1279,7 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, 0.f, A, N, Np, 1);
-    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{nullptr, nullptr, nullptr, N}};
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{nullptr, nullptr, nullptr, N}, SplitK{nullptr, nullptr, 1, 1, 0}};
     LaunchTimer tm;
     const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, nullptr, nullptr, &tm, groups);
     hipError_t e = hipStreamSynchronize(s);            // the groups have joined into s

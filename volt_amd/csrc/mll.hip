@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
 }
 
 struct MllWs {
-    float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob;
+    float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob, *sk_slab;
+    int* sk_count;
     size_t bytes;
 };
 
@@ -141,6 +142,14 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
     } else {
         w.Y = w.zpart = w.frob = nullptr;
     }
+    // split-K scratch of the small-batch schedule (chol.hip): 64 (n+1) tile-slabs + arrival counters
+    if (B < 16) {
+        w.sk_slab = take((size_t)64 * (n + 1) * TS * TS);
+        w.sk_count = reinterpret_cast<int*>(take((size_t)(n + 1) * (n + 1) * B));
+    } else {
+        w.sk_slab = nullptr;
+        w.sk_count = nullptr;
+    }
     w.bytes = off;
     return w;
 }
@@ -155,7 +164,7 @@ using namespace volt;
 typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, volt_group_post_fn post, void* post_ctx);
+                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count);
 
 namespace {
 struct TailCtx {
@@ -220,7 +229,8 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
     TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
-                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx)))
+                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx, w.sk_slab,
+                                   w.sk_count)))
         return rc > 0 ? rc : -1;
     VOLT_LAUNCH_CHECK();
     return 0;
