@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch series per GPU; strong: --batch series in total, split over the ranks")
     ap.add_argument("--no-rollouts", action="store_true", help="skip the config-5 rollout leg")
-    ap.add_argument("--n", type=int, default=N_SERIES)
+    ap.add_argument("--n", "--series-len", dest="n", type=int, default=N_SERIES)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux-legs", action="store_true",
