@@ -173,21 +173,176 @@ __global__ __launch_bounds__(256) void trsm64_kernel(double* __restrict__ A, con
 }
 
 // ----------------------------------------------------------------------------- P2
-// One workgroup per matrix: the 128x128 diagonal block lives in an LDS image (row stride 129 doubles: a column
-// walk hits 32 distinct bank pairs).  Right-looking factorisation with ONE barrier per pivot: the rank-1 update
-// of pivot j uses the still unscaled column j (a_rj a_cj / d_j), the columns are scaled in one pass at the end.
-// Then W = L^-1 in place from the last column to the first (LAPACK trti2, lower):
-//     W[j][j] = 1 / L[j][j],   W[r][j] = -W[j][j] sum_{m=j+1}^{r} W[r][m] L[m][j]      (r > j)
-// where W[r][m], m > j, is already final and column j of L is still the original.
+// One workgroup per matrix factors the 128x128 diagonal block and inverts it, blocked by 32 in an LDS image (row
+// stride 129 doubles) -- the structure of the fp32 diag_body (chol.hip):
+//   chol32   the 32x32 diagonal sub-block, all 256 threads: thread (ty, tx) keeps the 2x2 cyclic elements
+//            (ty + 16 a, tx + 16 c) in registers; per pivot the owners publish the still unscaled column to a
+//            double-buffered LDS vector (ONE barrier per pivot), everyone applies a_rc -= a_rj a_cj / d_j
+//   inv32    X = L_kk^-1 by forward substitution, one column per lane of one wave, fully unrolled; X replaces L_kk
+//            in the image (the panel solve, the trailing updates and the blocked inverse only ever need X)
+//   panel    L[i,kb] = A[i,kb] X_kb^T and trailing updates A[i,j] -= L[i,kb] L[j,kb]^T: 32x32x32 products on
+//            v_mfma_f64_16x16x4_f64 straight from the image, one wave per block
+//   W = L^-1 blocked: W[i,j] = -X_i sum_{m=j}^{i-1} L[i,m] W[m,j], wave j owns block column j; the W[m,j] it
+//            produced stay in its accumulators and are fed back as MFMA B operands FROM REGISTERS (accumulator
+//            register q of lane l holds row (l >> 4) + 4 q of a 16-row tile: exactly the k index step q wants from
+//            that lane)
+// Round-2 first version (unblocked LDS loops): 650 us per block; this one: see DESIGN 4.8.
 constexpr int DT64 = TS + 1;
-constexpr int DIAG64_LDS_BYTES = (TS * DT64 + 2 * TS) * 8;
+constexpr int DIAG64_LDS_BYTES = (TS * DT64 + 2 * 32 + 32) * 8;
+
+// acc[tr*2+tc] (16x16 tile at rows 16 tr, cols 16 tc of a 32x32 block) += sign * A[32x32] * B[32x32]^T, A and B row-major
+// blocks of the image:  C[r][c] = sum_p A[r][p] B[c][p]
+template <bool NEG>
+__device__ __forceinline__ void mm64_nt(f64x4 (&acc)[4], const double* __restrict__ A, const double* __restrict__ B) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        double a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a[t] = A[(t * 16 + l15) * DT64 + 4 * st + lk];
+            b[t] = B[(t * 16 + l15) * DT64 + 4 * st + lk];
+            if (NEG) a[t] = -a[t];
+        }
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+                acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], b[tc], acc[tr * 2 + tc], 0, 0, 0);
+    }
+}
+// acc += A[32x32] (image block, row-major) * Breg, Breg = a 32x32 block held as 4 accumulator tiles [tp*2+tc]
+__device__ __forceinline__ void mm64_lds_reg(f64x4 (&acc)[4], const double* __restrict__ A, const f64x4 (&Breg)[4]) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double a[2];
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr) a[tr] = A[(tr * 16 + l15) * DT64 + tp * 16 + 4 * q + lk];
+#pragma unroll
+            for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc)
+                    acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], Breg[tp * 2 + tc][q], acc[tr * 2 + tc], 0, 0, 0);
+        }
+}
+// acc += A[32x32] * B[32x32] (both image blocks, row-major):  C[r][c] = sum_p A[r][p] B[p][c]
+__device__ __forceinline__ void mm64_nn(f64x4 (&acc)[4], const double* __restrict__ A, const double* __restrict__ B) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        double a[2], b[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a[t] = A[(t * 16 + l15) * DT64 + 4 * st + lk];
+            b[t] = B[(4 * st + lk) * DT64 + t * 16 + l15];
+        }
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+                acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], b[tc], acc[tr * 2 + tc], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void acc64_zero(f64x4 (&acc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t][q] = 0.0;
+}
+// element (r, c) of accumulator register q of tile (tr, tc) inside a 32x32 block
+#define VOLT_BLK64_RC(tr, tc, q)                                  \
+    const int r = (tr) * 16 + ((threadIdx.x & 63) >> 4) + 4 * (q); \
+    const int c = (tc) * 16 + (threadIdx.x & 15);
+__device__ __forceinline__ void acc64_load(f64x4 (&acc)[4], const double* __restrict__ C) {
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_BLK64_RC(tr, tc, q)
+                acc[tr * 2 + tc][q] = C[r * DT64 + c];
+            }
+}
+__device__ __forceinline__ void acc64_store(const f64x4 (&acc)[4], double* __restrict__ C, double sign) {
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_BLK64_RC(tr, tc, q)
+                C[r * DT64 + c] = sign * acc[tr * 2 + tc][q];
+            }
+}
+
+// 32x32 Cholesky of the image block at (32 kb, 32 kb), all 256 threads; L (lower, zeros above) replaces the block.
+__device__ __forceinline__ void chol32_f64(double* __restrict__ sT, double* __restrict__ colbuf, int kb, int& bad) {
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    double* D = sT + (32 * kb) * DT64 + 32 * kb;
+    double a[2][2];
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ic = 0; ic < 2; ++ic) a[ia][ic] = D[(ty + 16 * ia) * DT64 + tx + 16 * ic];
+    for (int j = 0; j < 32; ++j) {
+        double* cb = colbuf + (j & 1) * 32;
+        const int jc = j >> 4, jx = j & 15;                    // column j lives in threads tx == jx, slot ic == jc
+        if (tx == jx) {
+#pragma unroll
+            for (int ia = 0; ia < 2; ++ia) cb[ty + 16 * ia] = a[ia][jc];          // unscaled column (row j holds d_j)
+        }
+        __syncthreads();
+        const double d = cb[j];
+        if (!(d > 0.0) && bad == 0) bad = 32 * kb + j + 1;     // uniform: every thread reads the same pivot
+        const double dinv = 1.0 / d, rs = 1.0 / sqrt(d);
+#pragma unroll
+        for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+            for (int ic = 0; ic < 2; ++ic) {
+                const int r = ty + 16 * ia, c = tx + 16 * ic;
+                if (c > j && r >= c) a[ia][ic] -= cb[r] * cb[c] * dinv;
+                else if (c == j && r >= j) a[ia][ic] = (r == j) ? sqrt(d) : a[ia][ic] * rs;   // column j becomes L
+            }
+    }
+#pragma unroll
+    for (int ia = 0; ia < 2; ++ia)
+#pragma unroll
+        for (int ic = 0; ic < 2; ++ic) {
+            const int r = ty + 16 * ia, c = tx + 16 * ic;
+            D[r * DT64 + c] = (c <= r) ? a[ia][ic] : 0.0;
+        }
+}
+
+// X = L^-1 for the 32x32 lower block at (32 kb, 32 kb), by lanes 0..31 of wave 0 (one column each, registers);
+// X replaces L in the image.  Call with the block complete in LDS; ends WITHOUT a barrier.
+__device__ __forceinline__ void inv32_f64(double* __restrict__ sT, int kb) {
+    double* D = sT + (32 * kb) * DT64 + 32 * kb;
+    const int c = threadIdx.x;
+    if (c < 32) {
+        double x[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            double acc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < r; ++m) acc -= D[r * DT64 + m] * x[m];      // x[m] == 0 for m < c
+            x[r] = acc / D[r * DT64 + r];
+        }
+        // every lane has read all of L it needs (its own column's rows >= c only use L, never X): write after a wave barrier
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 32; ++r) D[r * DT64 + c] = x[r];
+    }
+}
 
 __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, double* __restrict__ Winv,
                                                      int* __restrict__ info, int Np, int k) {
     extern __shared__ __attribute__((aligned(16))) double sT[];
-    double* dj = sT + TS * DT64;           // pivots d_j
-    double* col = dj + TS;                 // new column of W before it replaces column j
-    const int n = Np / TS, b = blockIdx.x, tid = threadIdx.x;
+    double* colbuf = sT + TS * DT64;       // 2 x 32 doubles
+    const int n = Np / TS, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     double* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     double* W = Winv + ((int64_t)b * n + k) * TS * TS;
     for (int e = tid; e < TS * TS; e += NT) {
@@ -196,44 +351,82 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, dou
     }
     __syncthreads();
     int bad = 0;
-    const int tr = tid >> 4, tc = tid & 15;
-    for (int j = 0; j < TS; ++j) {
-        const double d = sT[j * DT64 + j];
-        if (!(d > 0.0) && bad == 0) bad = j + 1;            // uniform: every thread reads the same pivot
-        const double dinv = 1.0 / d;
-        for (int r = j + 1 + tr; r < TS; r += 16) {
-            const double lr = sT[r * DT64 + j] * dinv;
-            for (int c = j + 1 + tc; c <= r; c += 16) sT[r * DT64 + c] -= lr * sT[c * DT64 + j];
+    for (int kb = 0; kb < 4; ++kb) {
+        chol32_f64(sT, colbuf, kb, bad);
+        __syncthreads();
+        // L_kk out (zeros above the diagonal), then X_kb replaces it in the image
+        for (int e = tid; e < 32 * 32; e += NT) {
+            const int r = e >> 5, c = e & 31;
+            D[(int64_t)(32 * kb + r) * Np + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
         }
-        if (tid == 0) dj[j] = d;
+        __syncthreads();
+        inv32_f64(sT, kb);
+        __syncthreads();
+        if (kb == 3) break;
+        // panel: L[i,kb] = A[i,kb] X_kb^T, block row i = kb+1+wave
+        if (kb + 1 + wave <= 3) {
+            const int i = kb + 1 + wave;
+            double* P = sT + (32 * i) * DT64 + 32 * kb;
+            f64x4 acc[4];
+            acc64_zero(acc);
+            mm64_nt<false>(acc, P, sT + (32 * kb) * DT64 + 32 * kb);
+            __builtin_amdgcn_wave_barrier();
+            acc64_store(acc, P, 1.0);
+        }
+        __syncthreads();
+        // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to the 4 waves
+        int cnt = 0;
+        for (int i = kb + 1; i <= 3; ++i)
+            for (int j = kb + 1; j <= i; ++j) {
+                if (wave == (cnt++ & 3)) {
+                    double* C = sT + (32 * i) * DT64 + 32 * j;
+                    f64x4 acc[4];
+                    acc64_load(acc, C);
+                    mm64_nt<true>(acc, sT + (32 * i) * DT64 + 32 * kb, sT + (32 * j) * DT64 + 32 * kb);
+                    acc64_store(acc, C, 1.0);
+                }
+            }
         __syncthreads();
     }
-    // scale the columns: L[r][j] = a_rj / sqrt(d_j), L[j][j] = sqrt(d_j); L goes out (zeros above the diagonal)
+    // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal
     for (int e = tid; e < TS * TS; e += NT) {
         const int r = e >> 7, c = e & 127;
-        double v = 0.0;
-        if (c <= r) {
-            const double s = sqrt(dj[c]);
-            v = (c == r) ? s : sT[r * DT64 + c] / s;
-            sT[r * DT64 + c] = v;
+        if ((r >> 5) != (c >> 5)) D[(int64_t)r * Np + c] = (c < r) ? sT[r * DT64 + c] : 0.0;
+    }
+    // ---- W = L^-1, blocked by 32: wave j < 3 owns block column j (the diagonal blocks of W are the X_kb in place)
+    f64x4 Wr[3][4];
+    if (wave < 3) {
+        const int j = wave;
+#pragma unroll
+        for (int di = 1; di <= 3; ++di) {
+            const int i = j + di;
+            if (i <= 3) {                                                     // wave-uniform
+                f64x4 S[4];
+                acc64_zero(S);
+                mm64_nn(S, sT + (32 * i) * DT64 + 32 * j, sT + (32 * j) * DT64 + 32 * j);            // L[i,j] X_j
+#pragma unroll
+                for (int dm = 1; dm < di; ++dm)
+                    mm64_lds_reg(S, sT + (32 * i) * DT64 + 32 * (j + dm), Wr[dm - 1]);              // L[i,m] W[m,j]
+                f64x4 R[4];
+                acc64_zero(R);
+                mm64_lds_reg(R, sT + (32 * i) * DT64 + 32 * i, S);                                   // X_i S
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Wr[di - 1][t][q] = -R[t][q];
+            }
         }
-        D[(int64_t)r * Np + c] = v;
+    }
+    __syncthreads();                                                          // every L block has been consumed
+    if (wave < 3) {
+        const int j = wave;
+#pragma unroll
+        for (int di = 1; di <= 3; ++di) {
+            const int i = j + di;
+            if (i <= 3) acc64_store(Wr[di - 1], sT + (32 * i) * DT64 + 32 * j, 1.0);
+        }
     }
     __syncthreads();
-    // W = L^-1 in place, last column first.  Threads r > j take one row each (128 threads; the row walk of
-    // thread r and the column walk over m are both conflict free with the odd stride).
-    for (int j = TS - 1; j >= 0; --j) {
-        const double wjj = 1.0 / sT[j * DT64 + j];
-        if (tid > j && tid < TS) {
-            double a = 0.0;
-            for (int m = j + 1; m <= tid; ++m) a += sT[tid * DT64 + m] * sT[m * DT64 + j];
-            col[tid] = -a * wjj;
-        }
-        __syncthreads();
-        if (tid > j && tid < TS) sT[tid * DT64 + j] = col[tid];
-        if (tid == j) sT[j * DT64 + j] = wjj;
-        __syncthreads();
-    }
     for (int e = tid; e < TS * TS; e += NT) {
         const int r = e >> 7, c = e & 127;
         W[r * TS + c] = (c <= r) ? sT[r * DT64 + c] : 0.0;

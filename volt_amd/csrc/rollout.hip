@@ -72,7 +72,7 @@ struct RolloutParams {
     const float* pred_vol;   // [G,S,H]
     const float* z;          // [G,S,H]
     float* samples;          // [G,S,H]
-    float* Ls;               // [G,S,H,H] scratch: rows of the per-sample factor
+    float* Ls;               // [G,S,rollout_sample_floats(H)] scratch: packed strictly-lower rows of the per-sample factor
     int* info;               // [G,S] 0; +step (1-based) of the first non-positive pivot of L_s (a local jitter was
                              //       applied); -step if the predictive variance stayed <= 0 after the jitter ladder
     int G, S, H, k;
@@ -80,6 +80,21 @@ struct RolloutParams {
     int use_theta;
     float theta, mr_theta, jitter;
 };
+
+// The strictly-lower rows of a sample's factor are stored PACKED: row a (a entries; its diagonal lives in registers)
+// takes ceil(a/4) 16-byte slots right behind row a-1.  With one row per KiB (round 2's first layout) every row read
+// fetched whole 128-byte lines of its own -- 1.18x the algorithmic bytes (PMC: 8.25e9 read requests, all 128-B) --
+// and the store was twice as large.  row_off(a) = 4 * sum_{m<a} ceil(m/4) floats.
+__device__ __forceinline__ int row_off(int a) {
+    const int m = a - 1;                       // sum_{i=1}^{m} ceil(i/4) with m = 4 q + r:  (q+1)(2q + r)
+    if (m <= 0) return 0;
+    const int q = m >> 2, r = m & 3;
+    return 4 * (q + 1) * (2 * q + r);
+}
+__host__ __device__ inline size_t rollout_sample_floats(int H) {
+    const int m = H - 1, q = m >> 2, r = m & 3;
+    return m <= 0 ? 4 : (size_t)4 * (q + 1) * (2 * q + r) + 4;    // rows 1 .. H-1 (+ one slot of slack)
+}
 
 __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -107,8 +122,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     const float* pv = p.pred_vol + row;
     const float* zz = p.z + row;
     float* out = p.samples + row;
-    const int Hs = (H + 3) & ~3;                            // row stride of the factor store (16-byte rows)
-    float* Ls = p.Ls + ((size_t)g * p.S + s) * H * Hs;
+    float* Ls = p.Ls + ((size_t)g * p.S + s) * rollout_sample_floats(H);
     // base = U_s[N+a] - rho, carried in fp64: the entries of the Schur complement S_s = C_s - rho 11' are
     // ~ dx vol^2 (1e-4 .. 1e-9) on top of rho ~ V[N-1] ~ 1, so forming U_s and rho in fp32 first loses them
     // (62 of 80,000 paths at N = 4096 lost a pivot that way); the differences themselves are fine in fp32.
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
             for (int r = 0; r < 4; ++r) {
                 const int a = a0 + r;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a < idx && 4 * lane < a) v = *reinterpret_cast<const f32x4*>(Ls + (size_t)a * Hs + 4 * lane);
+                if (a < idx && 4 * lane < a) v = *reinterpret_cast<const f32x4*>(Ls + row_off(a) + 4 * lane);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dst[r][t] = (4 * lane + t < a) ? v[t] : 0.f;   // beyond b < a: never written
             }
@@ -207,8 +221,8 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         }
         const float ell = sqrtf(d2), rell = 1.f / ell;
         const float znew = ((smp - mstar) - tau - wz) * rell;
-        // row idx of L_s = [w_s, ell]
-        float* Lrow = Ls + (size_t)idx * Hs;
+        // row idx of L_s = [w_s, ell]: the off-diagonal part goes to the packed store, ell stays in registers (rd)
+        float* Lrow = Ls + row_off(idx);
         f32x4 rowv;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -220,7 +234,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
                 zs[t] = znew;
             }
         }
-        if (4 * lane <= idx) *reinterpret_cast<f32x4*>(Lrow + 4 * lane) = rowv;
+        if (4 * lane < idx) *reinterpret_cast<f32x4*>(Lrow + 4 * lane) = rowv;
         if (lane == 0) {
             hy[k + idx] = smp;
             he1[k + idx] = ma1;
@@ -292,7 +306,7 @@ extern "C" {
 
 size_t volt_rollout_scratch_bytes(int G, int S, int H) {
     if (G <= 0 || S <= 0 || H <= 0) return 0;
-    return (size_t)G * S * H * ((H + 3) & ~3) * sizeof(float);      // rows padded to 16 bytes
+    return (size_t)G * S * volt::rollout_sample_floats(H) * sizeof(float);      // packed strictly-lower rows, 16-byte slots
 }
 
 int volt_rollout_bordered_f32(const double* rho, const double* tau, const double* acc0, const float* dx,
