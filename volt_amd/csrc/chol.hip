@@ -1070,7 +1070,7 @@ struct StreamPool {
     hipStream_t aux[MAX_GROUPS - 1];
     hipEvent_t fork, join[MAX_GROUPS - 1];
     std::mutex mu;
-    int want_groups = 4;                 // VOLT_GROUPS, read once
+    int want_groups = 2;                 // VOLT_GROUPS, read once (measured with the one-launch-per-column kernels: 2 >= 4 > 8)
     bool ok = false;
 };
 static StreamPool* stream_pool() {
@@ -1116,15 +1116,19 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     int G = pool ? pick_groups(pool, B, force_groups) : 1;
     // Small batches: cut the long products into K-slices so that a launch has ~`target` workgroups (measured, N = 4096,
     // ms/step unsplit -> split: B = 1 4.5 -> 2.0, 2 4.6 -> 2.6, 4 4.7 -> 3.4, 6 4.7 -> 4.4; from B = 8 on a launch has a
-    // tile per CU and splitting on ONE stream stops paying: B = 8 stays unsplit, 4.8 ms).  10 <= B < 16: two split groups
-    // on two streams (B = 12: 8.4 -> 6.1 ms).
+    // tile per CU and splitting on ONE stream stops paying: B = 8 stays unsplit, 4.8 ms).  10 <= B <= 20: two split groups
+    // on two streams up to B = 20 (B = 12: 8.4 -> 6.1 ms, 16: 8.4 -> 7.1, 20: 9.6 -> 9.1; no gain from 24 on).
     static const int target = getenv("VOLT_SPLITK_TARGET") ? atoi(getenv("VOLT_SPLITK_TARGET")) : 512;
     static const int split_groups = getenv("VOLT_SPLITK_GROUPS") ? atoi(getenv("VOLT_SPLITK_GROUPS")) : 2;
+    static const int split_maxb = getenv("VOLT_SPLITK_MAXB") ? atoi(getenv("VOLT_SPLITK_MAXB")) : 22;
     const bool can_split = o.sk.slab && o.sk.count && force_groups == 0 && target > 1;
     FactorOpts o1 = o;
     o1.sk.S = 1;                                             // > 1: the split schedule, and the slices wanted per launch
-    if (can_split && G == 1 && B < 8) o1.sk.S = target;
-    if (can_split && G == 1 && B >= 10 && B < 16 && pool && split_groups > 1 && B % split_groups == 0) {
+    if (can_split && B < 8) {
+        G = 1;
+        o1.sk.S = target;
+    }
+    if (can_split && B >= 10 && B < split_maxb && pool && split_groups > 1 && B % split_groups == 0) {
         G = split_groups;
         o1.sk.S = target / G;
     }

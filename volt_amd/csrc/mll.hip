@@ -143,7 +143,7 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
         w.Y = w.zpart = w.frob = nullptr;
     }
     // split-K scratch of the small-batch schedule (chol.hip): 64 (n+1) tile-slabs + arrival counters
-    if (B < 16) {
+    if (B < 32) {
         w.sk_slab = take((size_t)64 * (n + 1) * TS * TS);
         w.sk_count = reinterpret_cast<int*>(take((size_t)(n + 1) * (n + 1) * B));
     } else {
