@@ -109,12 +109,14 @@ def main():
     K = ops.fill(V)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(3):
+    fills = []
+    for _ in range(7):
+        e0.record()
         K = ops.fill(V)
-    e1.record()
-    torch.cuda.synchronize()
-    fill_ms = e0.elapsed_time(e1) / 3
+        e1.record()
+        torch.cuda.synchronize()
+        fills.append(e0.elapsed_time(e1))
+    fill_ms = float(np.median(fills))
     fill_gbs = B * n * n * 4 / (fill_ms * 1e-3) / 1e9
 
     raw_noise = torch.full((B,), 1e-5, device=dev, requires_grad=True)   # train_utils.py:222

@@ -1,0 +1,22 @@
+for rows in 2 4 8; do
+  sed -i "s/^#define VOLT_FILL_ROWS .*/#define VOLT_FILL_ROWS $rows/" volt_amd/csrc/fill.hip
+  python -m volt_amd.build > /dev/null 2>&1
+  python - <<PY
+import torch, sys
+sys.path.insert(0, ".")
+from volt_amd import ops
+from volt_amd.synthetic import sde_batch
+x, F, vol = sde_batch(64, 4096)
+V = ops.cumtrapz(torch.tensor(vol).cuda(), torch.tensor(x).cuda(), square=True)
+K = ops.fill(V); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+best = 1e9
+for rep in range(5):
+    e0.record()
+    for _ in range(5): K = ops.fill(V)
+    e1.record(); torch.cuda.synchronize()
+    best = min(best, e0.elapsed_time(e1) / 5)
+idx = torch.arange(4096, device="cuda"); ok = torch.equal(K[3], V[3][torch.minimum(idx[:, None], idx[None, :])])
+print("rows/thread $rows: %.3f ms  %.1f GB/s  ok=%s" % (best, 64 * 4096 * 4096 * 4 / best / 1e6, ok))
+PY
+done

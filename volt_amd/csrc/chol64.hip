@@ -14,8 +14,7 @@
 // pair and K step of 4; a wave owns 64x64 = 4x4 of them (128 accumulator VGPRs).
 //
 // Used where fp32 cannot carry the conditioning: the rollouts' train-block factor and its rho / tau
-// (volt_amd/rollout_engine.py), and gp.psd_safe_cholesky on fp64 input.  Throughput matters little there
-// (one factorisation per series against H x S sample steps), so P2 is a plain LDS algorithm.
+// (volt_amd/rollout_engine.py), and gp.psd_safe_cholesky on fp64 input.
 #include "common.h"
 #include "../../include/volt_hip.h"
 
@@ -27,34 +26,68 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int SLD64 = SLD / 2;          // 18 doubles per LDS row
 constexpr int BK64 = BK / 2;            // 16 doubles of K per chunk
 
-// acc[mt*4+nt] (16x16 block at rows 16 mt, columns 16 nt of the wave's 64x64) += A rows x B rows^T over the
-// K steps [KK0, KK1) of the staged chunk (4 doubles each).  Lane l supplies A[row = l & 15][k = l >> 4] and
-// B[col = l & 15][k = l >> 4]; accumulator register q of lane l is element (row = (l >> 4) + 4 q, col = l & 15).
-template <int KK0, int KK1>
-__device__ __forceinline__ void mma_chunk64(const float* __restrict__ buf, f64x4 (&acc)[16]) {
+// Fragments of one K step (4 doubles of K) of the staged chunk: lane l supplies A[row = l & 15][k = l >> 4] and
+// B[col = l & 15][k = l >> 4] for the four 16-row / 16-column blocks of the wave's 64x64.
+struct Frag64 { double a[4], b[4]; };
+__device__ __forceinline__ void frag64_load(Frag64& f, const float* __restrict__ buf, int kk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lk = lane >> 4;
     const int wr = wave >> 1, wc = wave & 1;
     const double* sA = reinterpret_cast<const double*>(buf);
     const double* sB = reinterpret_cast<const double*>(buf + TS * SLD);
 #pragma unroll
-    for (int kk = KK0; kk < KK1; ++kk) {
-        double a[4], b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = sA[(wr * 64 + t * 16 + l15) * SLD64 + kk * 4 + lk];
-            b[t] = sB[(wc * 64 + t * 16 + l15) * SLD64 + kk * 4 + lk];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt * 4 + nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], b[nt], acc[mt * 4 + nt], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) {
+        f.a[t] = sA[(wr * 64 + t * 16 + l15) * SLD64 + kk * 4 + lk];
+        f.b[t] = sB[(wc * 64 + t * 16 + l15) * SLD64 + kk * 4 + lk];
     }
 }
+// accumulator register q of lane l of block (mt, nt) is element (row = 16 mt + (l >> 4) + 4 q, col = 16 nt + (l & 15))
+__device__ __forceinline__ void frag64_mma_row(const Frag64& f, int mt, f64x4 (&acc)[16]) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+        acc[mt * 4 + nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[mt], f.b[nt], acc[mt * 4 + nt], 0, 0, 0);
+}
+__device__ __forceinline__ void frag64_mma(const Frag64& f, f64x4 (&acc)[16]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) frag64_mma_row(f, mt, acc);
+}
 
-// acc += A[0:128, 0:16 nchunks] * B[0:128, 0:16 nchunks]^T (doubles; lda / ldb in doubles).  Same software pipeline
-// as gemm_nt_128: register-staged prefetch two chunks ahead, double-buffered LDS, one barrier per chunk.
+// One chunk (4 K steps of 4 doubles) of the fp64 K loop, same shape as chunk_run (common.h): fragments
+// double-buffered in registers, the order pinned, staging two instructions at a time between groups of four MFMAs.
+template <bool STEADY>
+__device__ __forceinline__ void chunk64_run(const float* cur, float* nxt, bool more_, Frag64& F0, Frag64& F1, f64x4 (&acc)[16],
+                                            StageRegs& s, bool do_st_, bool do_ld_, const StageAddr& sa, int k_ld) {
+    const bool more = STEADY || more_, do_st = STEADY || do_st_, do_ld = STEADY || do_ld_;
+    frag64_load(F1, cur, 1);
+    VOLT_SB();
+    frag64_mma(F0, acc);
+    VOLT_SB();
+    frag64_load(F0, cur, 2);
+    VOLT_SB();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        frag64_mma_row(F1, m, acc);
+        if (do_st) stage_store_piece(s, nxt, m);
+        VOLT_SB();
+    }
+    frag64_load(F1, cur, 3);
+    VOLT_SB();
+    const int so = __builtin_amdgcn_readfirstlane(k_ld * 4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        frag64_mma_row(F0, m, acc);
+        if (do_ld) stage_load_piece(s, sa, so, m);
+        VOLT_SB();
+    }
+    __syncthreads();
+    if (more) frag64_load(F0, nxt, 0);
+    VOLT_SB();
+    frag64_mma(F1, acc);
+    VOLT_SB();
+}
+
+// acc += A[0:128, 0:16 nchunks] * B[0:128, 0:16 nchunks]^T (doubles; lda / ldb in doubles).  The software pipeline of
+// gemm_nt_128 on the float view of the operands: loads two chunks ahead, double-buffered LDS, one barrier per chunk.
 __device__ __forceinline__ void gemm64_nt_128(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
                                               int64_t ldb, int nchunks, f64x4 (&acc)[16], float* smem) {
     if (nchunks <= 0) return;
@@ -65,25 +98,21 @@ __device__ __forceinline__ void gemm64_nt_128(const double* __restrict__ A, int6
     if (nchunks > 1) stage_load_buf(s0, sa, BK);
     if (nchunks > 2) stage_load_buf(s1, sa, 2 * BK);
     __syncthreads();
+    Frag64 F0, F1;
+    frag64_load(F0, smem, 0);
+    float* b0 = smem;
+    float* b1 = smem + STAGE_FLOATS;
     int c = 0;
+    for (; c + 4 < nchunks; c += 2) {
+        chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
+        chunk64_run<true>(b1, b0, true, F0, F1, acc, s1, true, true, sa, (c + 4) * BK);
+    }
     for (; c + 1 < nchunks; c += 2) {
-        float* b0 = smem;
-        float* b1 = smem + STAGE_FLOATS;
-        mma_chunk64<0, 2>(b0, acc);
-        stage_store(s0, b1);
-        if (c + 3 < nchunks) stage_load_buf(s0, sa, (c + 3) * BK);
-        mma_chunk64<2, 4>(b0, acc);
-        __syncthreads();
-        mma_chunk64<0, 2>(b1, acc);
-        if (c + 2 < nchunks) stage_store(s1, b0);
-        if (c + 4 < nchunks) stage_load_buf(s1, sa, (c + 4) * BK);
-        mma_chunk64<2, 4>(b1, acc);
-        __syncthreads();
+        chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 3 < nchunks, sa, (c + 3) * BK);
+        chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
     }
-    if (c < nchunks) {
-        mma_chunk64<0, 4>(smem, acc);
-        __syncthreads();
-    }
+    if (c < nchunks) chunk64_run<false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
+    __syncthreads();
 }
 
 __device__ __forceinline__ void zero_acc64(f64x4 (&acc)[16]) {
@@ -298,14 +327,19 @@ __device__ __forceinline__ void chol32_f64(double* __restrict__ sT, double* __re
         __syncthreads();
         const double d = cb[j];
         if (!(d > 0.0) && bad == 0) bad = 32 * kb + j + 1;     // uniform: every thread reads the same pivot
-        const double dinv = 1.0 / d, rs = 1.0 / sqrt(d);
+        // 1/sqrt(d) from v_rsq_f64 + two Newton steps (full fp64 division and square root cost ~100 instructions each,
+        // three of them per pivot made this loop the longest part of the kernel); 1/d = rs^2, sqrt(d) = d rs
+        double rs = __builtin_amdgcn_rsq(d);
+        rs = rs * (1.5 - 0.5 * d * rs * rs);
+        rs = rs * (1.5 - 0.5 * d * rs * rs);
+        const double dinv = rs * rs;
 #pragma unroll
         for (int ia = 0; ia < 2; ++ia)
 #pragma unroll
             for (int ic = 0; ic < 2; ++ic) {
                 const int r = ty + 16 * ia, c = tx + 16 * ic;
                 if (c > j && r >= c) a[ia][ic] -= cb[r] * cb[c] * dinv;
-                else if (c == j && r >= j) a[ia][ic] = (r == j) ? sqrt(d) : a[ia][ic] * rs;   // column j becomes L
+                else if (c == j && r >= j) a[ia][ic] = (r == j) ? d * rs : a[ia][ic] * rs;   // column j becomes L
             }
     }
 #pragma unroll

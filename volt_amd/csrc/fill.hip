@@ -42,9 +42,14 @@ __global__ __launch_bounds__(256) void cumtrapz_kernel(const T* __restrict__ vol
 }
 
 // K[b,i,j] = V[b,min(i,j)].  Pure HBM-write stream: 4*N^2 bytes out, 4*N in (L2-resident).
-// Workgroup = 32 rows x 256 columns; a thread owns one 16-byte column quad and walks 8 rows, so
-// every store instruction of a wave writes 64 x 16 B = 1 KiB contiguous.  Non-temporal stores:
+// Workgroup = 16 rows x 256 columns; a thread owns one 16-byte column quad and walks 4 rows, so
+// every store instruction of a wave writes 64 x 16 B = 1 KiB contiguous.  Rows per thread measured at 64 x 4096^2
+// (scripts/fill_tune.sh, best of 5): 2 -> 6.57, 4 -> 6.54, 8 -> 6.30, 16 -> 5.75, 32 -> 4.95 TB/s: short workgroups win.  Non-temporal stores:
 // the matrix is far larger than L2 and is not re-read by this kernel.
+#ifndef VOLT_FILL_ROWS
+#define VOLT_FILL_ROWS 4
+#endif
+constexpr int FILL_RPT = VOLT_FILL_ROWS;          // rows per thread; a workgroup covers 4 * FILL_RPT rows x 256 columns
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void fill_kernel(const T* __restrict__ V, T* __restrict__ K, int N,
                                                    int64_t ldk, int64_t bsk) {
@@ -53,13 +58,13 @@ __global__ __launch_bounds__(256) void fill_kernel(const T* __restrict__ V, T* _
     const T* v = V + (int64_t)b * N;
     T* k = K + (int64_t)b * bsk;
     const int j0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * VEC;
-    const int i0 = blockIdx.y * 32 + (threadIdx.x >> 6);
+    const int i0 = blockIdx.y * (4 * FILL_RPT) + (threadIdx.x >> 6);
     if (j0 >= N) return;
     T vj[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) vj[c] = (j0 + c < N) ? v[j0 + c] : T(0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < FILL_RPT; ++r) {
         const int i = i0 + 4 * r;
         if (i >= N) break;
         const T vi = v[i];
@@ -106,10 +111,10 @@ static int launch_fill(const T* V, T* K, int B, int N, int64_t ldk, int64_t bsk,
     constexpr int VEC = 16 / sizeof(T);
     const bool aligned = (ldk % VEC == 0) && (bsk % VEC == 0) && ((uintptr_t)K % 16 == 0);
     if (aligned) {
-        dim3 grid((N + 64 * VEC - 1) / (64 * VEC), (N + 31) / 32, B);
+        dim3 grid((N + 64 * VEC - 1) / (64 * VEC), (N + 4 * FILL_RPT - 1) / (4 * FILL_RPT), B);
         hipLaunchKernelGGL((fill_kernel<T, VEC>), grid, dim3(256), 0, (hipStream_t)stream, V, K, N, ldk, bsk);
     } else {
-        dim3 grid((N + 63) / 64, (N + 31) / 32, B);
+        dim3 grid((N + 63) / 64, (N + 4 * FILL_RPT - 1) / (4 * FILL_RPT), B);
         hipLaunchKernelGGL((fill_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, V, K, N, ldk, bsk);
     }
     VOLT_LAUNCH_CHECK();
