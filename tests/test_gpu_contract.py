@@ -265,3 +265,28 @@ def test_small_batch_split_schedules(ops, B, n):
     _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out.cpu().numpy(), alpha.cpu().numpy(), rows)
     out2, alpha2, _ = ops.mll_step(K, dev(y - mean), s2)
     assert torch.equal(out, out2) and torch.equal(alpha, alpha2)
+
+
+def test_one_launch_trsv_oversubscribed(ops):
+    """64 matrices x 32 blocks = 2048 chained workgroups on 512 resident slots: the ticket order is what guarantees
+    progress.  Forward-only MLL (potrf + TRSV on the group streams) against the gradient path, and explicit solves."""
+    B, n = 64, 4096
+    x, F, vol = sde_batch(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    y = torch.log(dev(F[:, 1:]))
+    r = (y - y.mean(-1, keepdim=True)).float()
+    s2 = torch.linspace(0.3, 0.9, B, device="cuda")
+    o1, _, i1 = ops.mll_step(K, r, s2, want_grad=True)
+    o1 = o1.clone()
+    o0, _, i0 = ops.mll_step(K, r, s2, want_grad=False)
+    assert int(i1.abs().sum()) == 0 and int(i0.abs().sum()) == 0
+    assert torch.allclose(o1[:, 0], o0[:, 0], rtol=1e-5) and torch.allclose(o1[:, 2], o0[:, 2], rtol=2e-4)
+    f = ops.potrf(K, s2)
+    z = ops.trsv(f, r)
+    xs = ops.trsv(f, z, transpose=True)
+    assert bool(torch.isfinite(xs).all())
+    back = torch.empty_like(r, dtype=torch.float64)
+    for b0 in range(0, B, 8):
+        sl = slice(b0, b0 + 8)
+        back[sl] = (K[sl].double() @ xs[sl].double().unsqueeze(-1)).squeeze(-1) + s2[sl].double().unsqueeze(-1) * xs[sl].double()
+    assert float(((back - r.double()).norm(dim=-1) / r.double().norm(dim=-1)).max()) < 2e-3
