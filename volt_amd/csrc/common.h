@@ -273,6 +273,12 @@ struct TriTile {
 
 // One per-lane byte offset per operand (row t >> 3, 16-byte column t & 7); the row group p (32 rows further down) and
 // the K offset of the chunk are wave-uniform and ride in the instruction's SGPR offset.
+// Cache policy of the operand each tile reads ONCE (Z: its own block row): nt (aux = 2), so that it does not push the
+// operand the tiles of a matrix SHARE (X: block row k) out of the XCD's L2 -- FETCH_SIZE per launch 1.95 -> 1.70 GB,
+// speed unchanged (scripts/nt_exp.sh).
+#ifndef VOLT_Z_AUX
+#define VOLT_Z_AUX 2
+#endif
 struct TriSrc {
     __amdgpu_buffer_rsrc_t ra, rb, rw;
     int va, vb, vw;
@@ -285,7 +291,7 @@ __device__ __forceinline__ void tri_load_piece(StageRegs& s, const TriSrc& ts, i
         const int sa = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pa);
         const int sb = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pb);
         s.a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.ra, ts.va, sa, 0));
-        s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rb, ts.vb, sb, 0));
+        s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rb, ts.vb, sb, VOLT_Z_AUX));
     } else {
         const int so = __builtin_amdgcn_readfirstlane((c - ts.n1) * BK * 4 + p * (32 * TS * 4));
         s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rw, ts.vw, so, 0));
