@@ -385,6 +385,33 @@ def test_batched_driver_matches_per_series_functions(va, mean):
         assert p0.shape[0] == B and float(p0.detach().std()) > 0
 
 
+def test_graph_captured_training_loops_match_eager(va):
+    """train_utils graph=True: the warm-up iterations run eagerly, then ONE captured iteration (every HIP launch of the
+    step + the capturable Adam update) is replayed.  Same number of optimiser steps, same arithmetic: the trained
+    parameters agree with the eager loop to fp32 noise; a non-PD matrix inside the captured loop is reported after it."""
+    from volt_amd import gp
+    from volt_amd.train_utils import TrainVolModel, TrainVoltMagpieModel
+    n = 200
+    F, vol = sde_series(n, 5)
+    tx = torch.arange(n, device="cuda") / 252.
+    prices, v = dev(F), dev(vol)
+    out = {}
+    for graph in (False, True):
+        vmod, vlh = TrainVolModel(tx, v, train_iters=60, graph=graph)
+        m, lh = TrainVoltMagpieModel(tx, prices[1:], vmod, vlh, v, train_iters=60, k=20, graph=graph)
+        out[graph] = (float(vmod.covar_module.raw_vol.detach()), float(vlh.raw_noise.detach()), float(lh.raw_noise.detach()))
+    for a, b in zip(out[False], out[True]):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(a)), out
+    # the deferred check: a covariance that is not PD inside the captured loop raises after the loop
+    with pytest.raises(gp.NotPSDError):
+        with gp.deferred_checks() as chk:
+            lik = gp.GaussianLikelihood().cuda()
+            mll = gp.ExactMarginalLogLikelihood(lik, None)
+            Kbad = -torch.eye(64, device="cuda")
+            mll(gp.MultivariateNormal(torch.zeros(64, device="cuda"), Kbad), torch.ones(64, device="cuda"))
+            chk.raise_if_bad()
+
+
 def test_model_method_generate_prediction_twin(va):
     """VoltronGP.GeneratePrediction(test_x, pred_vol, n_sample) (VoltronGP.py:62-95, the notebook's cell 15):
     H-point joint prediction with n_sample draws, checked against the oracle's GeneratePrediction restatement

@@ -59,7 +59,7 @@ def _standard_mean_prediction(model, train_x, log_y, vol, test_x, pred_vol, z):
 
 
 def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample, mean, k, gpcv_iters, vol_iters,
-                      data_iters, theta, vol_fn, generator, save, path_fn, debug=None):
+                      data_iters, theta, vol_fn, generator, save, path_fn, debug=None, graph=False):
     """One batched pass per window: GPCV -> data model -> vol forecasters -> rollouts, every stage for all series of
     this rank at once.  series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e].
     ``debug`` (a dict) receives the last window's intermediates (vol, pred_vol, z, model) for tests."""
@@ -70,11 +70,11 @@ def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample,
     for last_day in end_idxs:
         train_y = series[:, last_day - ntrain:last_day].float()                          # [B, ntrain] prices
         if vol_fn is None:
-            vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters)                    # all series at once
+            vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters, graph=graph)       # all series at once
         else:
             vol = vol_fn(train_x, train_y)                                               # [B, ntrain-1]
         model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean)
-        vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters)
+        vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters, graph=graph)
         vmod.eval()
         pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous().detach()   # [B,S,H]
         z = torch.randn(B, nsample, H, device=dev, generator=generator)
@@ -97,7 +97,7 @@ def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample,
 
 def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=20, train_iters=400, nsample=1000,
                                   ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=None,
-                                  vol_iters=None, par_dir="./saved-outputs/", generator=None, debug=None):
+                                  vol_iters=None, par_dir="./saved-outputs/", generator=None, debug=None, graph=False):
     """closes [B, T] prices for B tickers on a common calendar (device tensor).  Same window schedule,
     model name and file layout as GenerateStockPredictions (GenerateMultiMeanPreds.py:69-83,128); ``mean`` in
     ewma / dewma / tewma takes the Rollouts branch (:110-112), constant / loglinear / linear the "VOLT + standard
@@ -124,12 +124,12 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
         date = str(last_day) if dates is None else str(dates[last_day])
         return os.path.join(par_dir, tckr, model_name + date + ".pt")                    # :128
     return _forecast_windows(tickers, closes, end_idxs.tolist(), ntrain, train_x, test_x, nsample, mean, k,
-                             train_iters, vol_iters, train_iters, None, vol_fn, generator, save, path_fn, debug)
+                             train_iters, vol_iters, train_iters, None, vol_fn, generator, save, path_fn, debug, graph)
 
 
 def GenerateWindPredictionsBatch(stations, data, forecast_horizon=100, ntrain=400, n_test_times=10, nsample=1000, k=400,
                                  theta=0.01, gpcv_iters=200, vol_iters=500, data_iters=0, save=False, vol_fn=None,
-                                 par_dir="./saved-outputs/", generator=None):
+                                 par_dir="./saved-outputs/", generator=None, graph=False):
     """The ``--kernel volt --mean ewma`` branch of experiments/weather/GPGenerator.py:20-112 for B stations at once:
     data [B,T] wind speeds (missing = -99 -> 0, then +1 as at :47,55), dt = 1/365 (:38-41), the schedule of test
     windows of :33-34, GPCV 200 / vol model 500 / data model 0 iterations (:64-67,89-92), EWMA(k=400) mean and
@@ -149,4 +149,4 @@ def GenerateWindPredictionsBatch(stations, data, forecast_horizon=100, ntrain=40
         return os.path.join(par_dir, "stn" + str(stn), "volt_ema" + str(k) + "_theta" + str(theta) + "_" +
                             str(last_day) + ".pt")
     return _forecast_windows(stations, data, end_idxs, ntrain, train_x, test_x, nsample, "ewma", k, gpcv_iters,
-                             vol_iters, data_iters, theta, vol_fn, generator, save, path_fn)
+                             vol_iters, data_iters, theta, vol_fn, generator, save, path_fn, None, graph)

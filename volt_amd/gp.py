@@ -60,6 +60,35 @@ class NotPSDError(RuntimeError):
     pass
 
 
+class deferred_checks:
+    """Context in which the factorisation's per-matrix ``info`` is NOT read back on the host after every step (that
+    read is a device synchronisation, and it makes a training iteration impossible to capture in a hipGraph) but
+    accumulated on the device; ``raise_if_bad()`` reads the count once, after the loop.  Used by the graph-captured
+    training loops of train_utils (``graph=True``); the jitter-retry ladder of psd_safe_cholesky cannot run inside a
+    captured iteration, so a non-PD matrix there is an error the caller answers by rerunning without the graph."""
+    _active = None
+
+    def __enter__(self):
+        self.bad = None
+        self._prev = deferred_checks._active
+        deferred_checks._active = self
+        return self
+
+    def __exit__(self, *exc):
+        deferred_checks._active = self._prev
+        return False
+
+    def note(self, info):
+        if self.bad is None:
+            self.bad = torch.zeros((), dtype=torch.int64, device=info.device)
+        self.bad.add_((info != 0).sum())
+
+    def raise_if_bad(self):
+        if self.bad is not None and int(self.bad.item()) != 0:
+            raise NotPSDError(f"{int(self.bad.item())} factorisations inside the captured loop were not positive definite; "
+                              "rerun with graph=False to get gpytorch's jitter-retry behaviour")
+
+
 class NanError(RuntimeError):
     pass
 
@@ -381,7 +410,11 @@ class _ExactMLL(torch.autograd.Function):
         # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
         # NumericalWarning, then NotPSDError.  Same ladder here; the jitter is added inside the fused step.
         out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0)
-        bad = int((info != 0).sum().item())
+        if deferred_checks._active is not None:
+            deferred_checks._active.note(info)
+            bad = 0
+        else:
+            bad = int((info != 0).sum().item())
         if bad:
             if torch.isnan(K).any() or torch.isnan(resid).any() or torch.isnan(noise).any():
                 raise NanError("cholesky: NaN in the covariance, the noise or the residual")

@@ -16,11 +16,59 @@ import torch
 
 from . import gp
 from .gp import ExactMarginalLogLikelihood, GaussianLikelihood
+
+
+def _adam(params, lr, graph):
+    """torch.optim.Adam as the reference builds it; `capturable` keeps the step counter on the device so that the
+    update can be recorded into a hipGraph (same arithmetic)."""
+    return torch.optim.Adam(params, lr=lr, capturable=bool(graph))
+
+
+def _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=1.0, warm=3):
+    """The reference's loop body ``optimizer.zero_grad(); output = model(x); loss = -mll(output, y); loss.backward();
+    optimizer.step()`` (train_utils.py:243-254 and its siblings) run `train_iters` times.  ``iteration()`` does forward
+    + backward and returns the loss.
+
+    graph=False: eagerly, statement for statement.  graph=True: the first `warm` iterations eagerly on a side stream,
+    then ONE iteration is captured into a hipGraph (torch.cuda.CUDAGraph: every HIP launch of the step, the torch glue
+    and the capturable Adam update) and replayed -- at the reference's sizes (N = 399) an iteration is ~10 short launches
+    plus ~0.4 ms of Python, i.e. launch-bound, and the replay removes the Python.  The per-step ``info`` read-back (a device
+    synchronisation) is deferred to one check after the loop (gp.deferred_checks)."""
+    print_every = 50
+    if not graph or train_iters <= warm + 1:
+        loss = None
+        for i in range(train_iters):
+            optimizer.zero_grad()
+            loss = iteration()
+            if printing and i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item() * scale))
+            optimizer.step()
+        return loss
+    with gp.deferred_checks() as chk:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warm):
+                optimizer.zero_grad(set_to_none=True)
+                iteration()                                       # (no reference to the loss kept: the autograd graph dies here)
+                optimizer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        optimizer.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_loss = iteration()
+            optimizer.step()
+        for i in range(warm, train_iters):                        # capturing records an iteration, it does not run it
+            g.replay()
+            if printing and i % print_every == 0:
+                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, static_loss.item() * scale))
+        chk.raise_if_bad()
+    return static_loss
 from .means import LogLinearMean, EWMAMean, DEWMAMean, TEWMAMean, MeanRevertingEMAMean
 from .models import VoltronGP, VoltMagpie
 
 
-def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm"):
+def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", graph=False):
     """The fit of LearnGPCV (train_utils.py:15-58) returning what it builds: (model, likelihood, losses)."""
     from .kernels import BMKernel, FBMKernel
     from .likelihoods import VolatilityGaussianLikelihood
@@ -47,45 +95,46 @@ def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm"):
     model.train()
     likelihood.train()
 
-    optimizer = torch.optim.Adam([
+    optimizer = _adam([
         {"params": model.parameters()},
-    ], lr=0.01)
+    ], 0.01, graph)
 
     mll = VariationalELBO(likelihood, model, yy.shape[-1], combine_terms=True)
 
-    print_every = 50
     losses = []
-    for i in range(train_iters):
-        optimizer.zero_grad()
+
+    def iteration():                                     # train_utils.py:50-54
         with num_gauss_hermite_locs(75):
             output = model(train_x)
             loss = -mll(output, yy)
-            losses.append(loss.detach())
+            if not graph:
+                losses.append(loss.detach())
             if loss.ndim:
                 loss = loss.sum()                      # independent series: one backward for all of them
             loss.backward()
-            if printing:
-                if i % print_every == 0:
-                    print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
-            optimizer.step()
+        return loss
+
+    last = _run_iterations(iteration, optimizer, train_iters, printing, graph)
+    if graph and last is not None:
+        losses.append(last.detach())
     model.eval()
     likelihood.eval()
     return model, likelihood, losses
 
 
-def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping=False, kernel="bm"):
+def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping=False, kernel="bm", graph=False):
     """voltron/train_utils.py:15-67 -- SURVEY 8(f) row 4: extract the volatility path from prices by fitting a
     variational GP (BM or FBM prior over log-vol, ``y | f ~ N(0, exp f)``) to the scaled returns.  Same statements
     as the reference; ``mll`` is volt_amd.variational.VariationalELBO, one HIP step per iteration.
     train_y [N+1] prices -> pred_scale [N]; train_y [T,N+1] fits T series at once (batched parameters)."""
-    model, likelihood, _ = FitGPCV(train_x, train_y, train_iters=train_iters, printing=printing, kernel=kernel)
+    model, likelihood, _ = FitGPCV(train_x, train_y, train_iters=train_iters, printing=printing, kernel=kernel, graph=graph)
     predictive = model(train_x)
     pred_scale = likelihood(predictive, return_gaussian=False).scale.mean(0).detach()
 
     return pred_scale
 
 
-def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm"):
+def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=False):
     """voltron/train_utils.py:69-95 -- SURVEY 8(f) row 1: the Brownian-motion GP over log-vol that later
     supplies pred_vol to Rollouts.  Same loop; the MLL and its gradient wrt the kernel's `vol` and the
     noise run on the HIP path (K = vol * min(x,x') keeps d mll / d vol in closed form, gp._ExactMLL).
@@ -96,23 +145,21 @@ def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="b
     vol_lh.noise.data = torch.tensor([1e-2])          # no-op, as in the reference
     vol_model = BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device)
 
-    optimizer = torch.optim.Adam([{'params': vol_model.parameters()}], lr=0.01)
+    optimizer = _adam([{'params': vol_model.parameters()}], 0.01, graph)
     mll = ExactMarginalLogLikelihood(vol_lh, vol_model)
+    log_vol = vol_path.log()
 
-    print_every = 50
-    for i in range(train_iters):
-        optimizer.zero_grad()
+    def iteration():                                     # train_utils.py:84-88
         output = vol_model(train_x)
-        loss = -mll(output, vol_path.log())
+        loss = -mll(output, log_vol)
         loss.backward()
-        if printing:
-            if i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
-        optimizer.step()
+        return loss
+
+    _run_iterations(iteration, optimizer, train_iters, printing, graph)
     return vol_model, vol_lh
 
 
-def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kernel="bm"):
+def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=False):
     """TrainVolModel for T series at once: vol_path [T,N] -> one batched BMGP (per-series kernel parameter and noise).
     The series are independent, so the summed loss gives every series exactly the gradient its own TrainVolModel
     loop would (Adam is elementwise)."""
@@ -120,18 +167,17 @@ def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kern
     T = vol_path.shape[0]
     vol_lh = GaussianLikelihood(batch_shape=torch.Size([T])).to(train_x.device)
     vol_model = BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device)
-    optimizer = torch.optim.Adam([{'params': vol_model.parameters()}], lr=0.01)
+    optimizer = _adam([{'params': vol_model.parameters()}], 0.01, graph)
     mll = ExactMarginalLogLikelihood(vol_lh, vol_model)
-    print_every = 50
-    for i in range(train_iters):
-        optimizer.zero_grad()
+    log_vol = vol_path.log()
+
+    def iteration():
         output = vol_model(train_x)
-        loss = -mll(output, vol_path.log()).sum()
+        loss = -mll(output, log_vol).sum()
         loss.backward()
-        if printing:
-            if i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item() / T))
-        optimizer.step()
+        return loss
+
+    _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=1.0 / T)
     return vol_model, vol_lh
 
 
@@ -189,25 +235,22 @@ def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=10
     voltron.train()
     voltron_lh.train()
 
-    optimizer = torch.optim.Adam([{'params': voltron.parameters()}], lr=0.1)
+    optimizer = _adam([{'params': voltron.parameters()}], 0.1, graph)
     mll = ExactMarginalLogLikelihood(voltron_lh, voltron)
+    log_y = train_y.log()
 
-    print_every = 50
-    for i in range(train_iters):
-        optimizer.zero_grad()
+    def iteration():                                     # train_utils.py:245-250
         output = voltron(train_x)
-        loss = -mll(output, train_y.log())
+        loss = -mll(output, log_y)
         loss.backward()
-        if printing:
-            if i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
-        optimizer.step()
+        return loss
 
+    _run_iterations(iteration, optimizer, train_iters, printing, graph)
     return voltron, voltron_lh
 
 
 def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, k=25,
-                         theta=0.5, mean_func="ewma"):
+                         theta=0.5, mean_func="ewma", graph=False):
     voltron_lh = GaussianLikelihood().to(train_x.device)
     voltron = VoltMagpie(train_x, train_y.log(), voltron_lh, vol_path, k=k).to(train_x.device)
 
@@ -245,20 +288,17 @@ def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_it
     voltron.train()
     voltron_lh.train()
 
-    optimizer = torch.optim.Adam([{'params': voltron.parameters()}], lr=0.1)
+    optimizer = _adam([{'params': voltron.parameters()}], 0.1, graph)
     mll = ExactMarginalLogLikelihood(voltron_lh, voltron)
+    log_y = train_y.log()
 
-    print_every = 50
-    for i in range(train_iters):
-        optimizer.zero_grad()
+    def iteration():                                     # train_utils.py:245-250
         output = voltron(train_x)
-        loss = -mll(output, train_y.log())
+        loss = -mll(output, log_y)
         loss.backward()
-        if printing:
-            if i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
-        optimizer.step()
+        return loss
 
+    _run_iterations(iteration, optimizer, train_iters, printing, graph)
     return voltron, voltron_lh
 
 

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import ops
+from . import gp, ops
 from .gp import Module, MultivariateNormal, NotPSDError, NanError, _ScaledDense, _dense
 
 PRIOR_JITTER = 1e-3        # LazyTensor.add_jitter() default on the inducing prior
@@ -133,7 +133,9 @@ class _GPCVElbo(torch.autograd.Function):
         ws = holder.workspace(B, n, want_dk, m.device)
         ops.gpcv_step(K.detach(), (m - mean).detach(), m.detach(), Lq.detach(), y, gh_x, gh_w, ws, want_dk=want_dk,
                       jitter=PRIOR_JITTER, min_var=MIN_VARIANCE, w_ell=w_ell, w_kl=w_kl)
-        if bool((ws.info != 0).any().item()):
+        if gp.deferred_checks._active is not None:
+            gp.deferred_checks._active.note(ws.info)
+        elif bool((ws.info != 0).any().item()):
             if torch.isnan(K).any() or torch.isnan(m).any() or torch.isnan(Lq).any():
                 raise NanError("GPCV step: NaN in the prior covariance or the variational parameters")
             raise NotPSDError("GPCV step: prior covariance K + 1e-3 I is not positive definite")
