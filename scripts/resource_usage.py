@@ -16,10 +16,10 @@ for src in SOURCES:
             cur = {"file": src, "kernel": re.sub(r"\(.*", "", name)}
             rows.append(cur)
             continue
-        m = re.search(r"remark:\s+(SGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
+        m = re.search(r"remark:\s+(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]): (\d+)", line)
         if m and cur is not None:
             cur[m.group(1).split(" [")[0]] = int(m.group(2))
-cols = ["VGPRs", "AGPRs", "SGPRs", "VGPRs Spill", "SGPRs Spill", "ScratchSize", "Occupancy", "LDS Size"]
+cols = ["VGPRs", "AGPRs", "TotalSGPRs", "VGPRs Spill", "SGPRs Spill", "ScratchSize", "Occupancy", "LDS Size"]
 print(f"{'file':12s} {'kernel':48s} " + " ".join(f"{c:>12s}" for c in cols))
 for r in rows:
     print(f"{r['file']:12s} {r['kernel'][:48]:48s} " + " ".join(f"{r.get(c, 0):12d}" for c in cols))
