@@ -97,7 +97,8 @@ __device__ __forceinline__ float input_elem(const KSource& src, const float* Kb,
 // prefetch registers are carried through the loop.
 template <bool FROMK, int ABL = 0>
 __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int rowblk, int colblk, int kb0, int kb1,
-                                            bool fromk, int b, const KSource& src, float* smem) {
+                                            bool fromk, int b, const KSource& src, float* smem,
+                                            bool to_image = false) {
     float* Ab = A + (int64_t)b * Np * Np;
     const float* Arows = Ab + (int64_t)rowblk * TS * Np + (int64_t)kb0 * TS;   // L[rowblk, kb0:kb1]
     const float* Brows = Ab + (int64_t)colblk * TS * Np + (int64_t)kb0 * TS;   // L[colblk, kb0:kb1]
@@ -127,6 +128,22 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
 #pragma unroll
             for (int q = 0; q < 16; ++q) sum += acc[t4][q];
         C[(int64_t)(threadIdx.x >> 1) * Np + (threadIdx.x & 1)] = sum;
+        return;
+    }
+    if (to_image) {
+        // the diagonal tile of the step it is factored in: straight into the LDS image diag_body works on (lower
+        // triangle, zeros above) instead of out to memory and back
+        __syncthreads();                                           // the staging buffers the image overlays are drained
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                    const int c = wc * 64 + tn * 32 + (lane & 31);
+                    smem[r * (TS + 1) + c] = (c <= r) ? -acc[tm * 2 + tn][q] : 0.f;
+                }
         return;
     }
 #pragma unroll
@@ -219,21 +236,6 @@ __device__ __forceinline__ void rl_fma2(float& c0, float& c1, float b0, float b1
 // path and the compiler cannot see into the asm blocks): tie a one-cycle nop to the value.
 __device__ __forceinline__ void settle(float& v) { asm volatile("s_nop 0" : "+v"(v)); }
 
-// the same with one accumulator: acc -= b0 rl(s0) + b1 rl(s1) + b2 rl(s2)
-__device__ __forceinline__ void rl_dot3(float& acc, float b0, float b1, float b2, float s0, float s1, float s2, int ln) {
-    float t0, t1, t2;
-    asm volatile(VOLT_RL "%1, %7, %10\n\t" VOLT_RL "%2, %8, %10\n\t" VOLT_RL "%3, %9, %10\n\t"
-                 "v_fma_f32 %0, -%4, %1, %0\n\tv_fma_f32 %0, -%5, %2, %0\n\tv_fma_f32 %0, -%6, %3, %0"
-                 : "+v"(acc), "=&s"(t0), "=&s"(t1), "=&s"(t2)
-                 : "v"(b0), "v"(b1), "v"(b2), "v"(s0), "v"(s1), "v"(s2), "i"(ln));
-}
-__device__ __forceinline__ void rl_dot2(float& acc, float b0, float b1, float s0, float s1, int ln) {
-    float t0, t1;
-    asm volatile(VOLT_RL "%1, %5, %7\n\t" VOLT_RL "%2, %6, %7\n\ts_nop 0\n\t"
-                 "v_fma_f32 %0, -%3, %1, %0\n\tv_fma_f32 %0, -%4, %2, %0"
-                 : "+v"(acc), "=&s"(t0), "=&s"(t1)
-                 : "v"(b0), "v"(b1), "v"(s0), "v"(s1), "i"(ln));
-}
 __device__ __forceinline__ void rl_fma1(float& c0, float b0, float s0, int l0) {
     float t0;
     asm volatile(VOLT_RL "%1, %3, %4\n\ts_nop 1\n\tv_fma_f32 %0, -%2, %1, %0"
@@ -241,34 +243,110 @@ __device__ __forceinline__ void rl_fma1(float& c0, float b0, float s0, int l0) {
                  : "v"(b0), "v"(s0), "i"(l0));
 }
 
-// One wave factors the 32x32 diagonal sub-block kb of the image and inverts it.  Lane r (both half-waves hold the
-// same data) keeps row r in registers; per pivot the pivot and the column entries travel by v_readlane (SGPR
-// broadcast), so the 32 dependent pivots cost no barrier and no LDS round trip.  L_kk goes straight to global
-// memory; its inverse X = L_kk^-1 (column c solved in lane c, L entries again by readlane) replaces it in the
-// image: the panel solve, the trailing updates and the blocked inverse only ever need X.
-__device__ __forceinline__ void factor32(float* __restrict__ sT, int kb, float* __restrict__ Dg, int Np, int& bad) {
-    const int lane = threadIdx.x & 63, l31 = lane & 31;
-    float* Dk = sT + (32 * kb) * DT + 32 * kb;
-    float a[32], rv[32];
+// Phase stamps (tuning hook volt_tune_diag_f32 only): s_memtime of thread 0 at the phase boundaries
+#define VOLT_STAMP(i)                                                                  \
+    do {                                                                               \
+        if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+
+// One wave factors the 32x32 diagonal sub-block kb of the image and inverts it, recursively blocked by 16.  Lane r
+// (both half-waves hold the same data) keeps row r in registers; per pivot the pivot and the column entries travel by
+// v_readlane (SGPR broadcast), so the dependent pivots cost no barrier and no LDS round trip -- but every element
+// update is a readlane + FMA pair, and that instruction count is what the diagonal block's latency is made of.  So
+// only the two 16x16 diagonal quarters (and, for free, the 16x16 panel below the first: its rows sit in lanes 16..31
+// of the same instructions) are done that way; the Schur complement A22 -= L21 L21^T and the off-diagonal quarter of
+// the inverse X21 = -X22 L21 X11 go through the image to v_mfma_f32_16x16x4_f32 (480 pairs + 16 MFMAs instead of
+// 992 pairs: 6.3 -> 3.x us per sub-block).  L_kk goes straight to global memory; X = L_kk^-1 replaces it in the image:
+// the panel solve, the trailing updates and the blocked inverse only ever need X.
+// pivots j in [J0, J1) of the lane-per-row factorisation, updating columns (j, J1)
+template <int J0, int J1>
+__device__ __forceinline__ void pivots16(float (&a)[32], float (&rv)[32], int kb, int& bad) {
+    settle(a[J0]);
+    float d = lane_bcast(a[J0], J0);
+    float rinv = __builtin_amdgcn_rsqf(d);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) a[c] = Dk[l31 * DT + c];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        settle(a[j]);                                                       // last written inside an asm block
-        const float d = lane_bcast(a[j], j);
+    for (int j = J0; j < J1; ++j) {
         if (!(d > 0.f) && bad == 0) bad = 32 * kb + j + 1;                  // non-positive or NaN pivot (wave-uniform)
-        const float rinv = __builtin_amdgcn_rsqf(d);
         rv[j] = rinv;
         float l = a[j] * rinv;                                              // lane r: L[r][j]; lane j: sqrt(d)
         settle(l);
         a[j] = l;
-        // a[c] -= L[r][j] L[c][j] for c > j (valid where r >= c)
-        int c = j + 1;
+        // a[c] -= L[r][j] L[c][j] for j < c < J1 (valid where r >= c); the next pivot's column first, so that its
+        // broadcast and rsq are in flight under the other columns' updates
+        float rnext = 0.f;
+        if (j + 1 < J1) {
+            rl_fma1(a[j + 1], l, l, j + 1);
+            settle(a[j + 1]);
+            d = lane_bcast(a[j + 1], j + 1);
+            rnext = __builtin_amdgcn_rsqf(d);
+        }
+        int c = j + 2;
 #pragma unroll
-        for (; c + 2 < 32; c += 3) rl_fma3(a[c], a[c + 1], a[c + 2], l, l, l, l, l, l, c, c + 1, c + 2);
-        if (c + 1 < 32) rl_fma2(a[c], a[c + 1], l, l, l, l, c, c + 1);
-        else if (c < 32) rl_fma1(a[c], l, l, c);
+        for (; c + 2 < J1; c += 3) rl_fma3(a[c], a[c + 1], a[c + 2], l, l, l, l, l, l, c, c + 1, c + 2);
+        if (c + 1 < J1) rl_fma2(a[c], a[c + 1], l, l, l, l, c, c + 1);
+        else if (c < J1) rl_fma1(a[c], l, l, c);
+        rinv = rnext;
     }
+}
+// rows [R0, R1) of the inverse of the 16x16 diagonal quarter starting at R0: lane c solves L x = e_c, column
+// oriented so that the FMAs of one step are independent: x[m] = acc[m] / L[m][m], then acc[r] -= L[r][m] x[m] for
+// r > m, with L[r][m] broadcast from lane r's register a[m]
+template <int R0, int R1>
+__device__ __forceinline__ void invert16(const float (&a)[32], const float (&rv)[32], float (&x)[32], int l31) {
+#pragma unroll
+    for (int r = R0; r < R1; ++r) x[r] = (r == l31) ? 1.f : 0.f;
+#pragma unroll
+    for (int m = R0; m < R1; ++m) {
+        const float xm = x[m] * rv[m];
+        x[m] = xm;
+        int r = m + 1;
+#pragma unroll
+        for (; r + 2 < R1; r += 3) rl_fma3(x[r], x[r + 1], x[r + 2], xm, xm, xm, a[m], a[m], a[m], r, r + 1, r + 2);
+        if (r + 1 < R1) rl_fma2(x[r], x[r + 1], xm, xm, a[m], a[m], r, r + 1);
+        else if (r < R1) rl_fma1(x[r], xm, a[m], r);
+    }
+}
+// LDS hand-over between the lanes of ONE wave (its LDS operations execute in order): keep the compiler from moving
+// accesses across, no instruction is needed
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool STAMP = false>
+__device__ __forceinline__ void factor32(float* __restrict__ sT, int kb, float* __restrict__ Dg, int Np, int& bad,
+                                         long long* stamps = nullptr) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, l15 = lane & 15, g = lane >> 4;
+    float* Dk = sT + (32 * kb) * DT + 32 * kb;
+    float a[32], rv[32];
+    // ---- left half: L11 (lanes 0..15) and L21 = A21 L11^-T (lanes 16..31) in the same pivot loop
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = Dk[l31 * DT + c];
+    pivots16<0, 16>(a, rv, kb, bad);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Dk[l31 * DT + c] = a[c];                   // rows 16..31: L21, read back in MFMA layout
+    wave_lds_fence();
+    // ---- A22 -= L21 L21^T on the matrix cores: A[i][k] and B[k][j] are the same register, L21[l15][4s + g]
+    float v21[4];
+    f32x4 s22;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v21[s] = Dk[(16 + l15) * DT + 4 * s + g];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s22[q] = Dk[(16 + 4 * g + q) * DT + 16 + l15];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) s22 = __builtin_amdgcn_mfma_f32_16x16x4f32(-v21[s], v21[s], s22, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dk[(16 + 4 * g + q) * DT + 16 + l15] = s22[q];
+    wave_lds_fence();
+    // ---- right half: L22 in lanes 16..31 (the others carry zeros)
+#pragma unroll
+    for (int c = 16; c < 32; ++c) {
+        const float t = Dk[l31 * DT + c];
+        a[c] = (l31 >= 16) ? t : 0.f;
+    }
+    pivots16<16, 32>(a, rv, kb, bad);
+    VOLT_STAMP(11);
     // L_kk out (zeros above the diagonal); both half-waves write the same words
     float* Dgk = Dg + (int64_t)(32 * kb + l31) * Np + 32 * kb;
 #pragma unroll
@@ -278,46 +356,70 @@ __device__ __forceinline__ void factor32(float* __restrict__ sT, int kb, float* 
         for (int q = 0; q < 4; ++q) v[q] = (4 * c4 + q <= l31) ? a[4 * c4 + q] : 0.f;
         *reinterpret_cast<f32x4*>(Dgk + 4 * c4) = v;
     }
-    // X = L_kk^-1: lane c solves L x = e_c;  x[r] = (delta_rc - sum_{m<r} L[r][m] x[m]) / L[r][r], with L[r][m]
-    // broadcast from lane r's register a[m]  (x[m] == 0 for m < c by construction)
+    VOLT_STAMP(12);
+    // ---- X11 = L11^-1 (columns in lanes 0..15, zero elsewhere) and X22 = L22^-1 (lanes 16..31)
     float x[32];
+    invert16<0, 16>(a, rv, x, l31);
+    invert16<16, 32>(a, rv, x, l31);
+    VOLT_STAMP(13);
 #pragma unroll
-    for (int r = 0; r < 32; ++r) {
-        float acc = (r == l31) ? 1.f : 0.f;
-        int m = 0;
+    for (int r = 0; r < 16; ++r) Dk[r * DT + l31] = x[r];                   // X11 | 0
+    if (l31 >= 16) {
 #pragma unroll
-        for (; m + 2 < r; m += 3) rl_dot3(acc, x[m], x[m + 1], x[m + 2], a[m], a[m + 1], a[m + 2], r);
-        if (m + 1 < r) rl_dot2(acc, x[m], x[m + 1], a[m], a[m + 1], r);
-        else if (m < r) rl_fma1(acc, x[m], a[m], r);
-        x[r] = acc * rv[r];
+        for (int r = 16; r < 32; ++r) Dk[r * DT + l31] = x[r];              // X22 (the L21 quarter beside it stays)
     }
+    wave_lds_fence();
+    // ---- X21 = -X22 (L21 X11): T = L21 X11 lands as T[4g + q][l15] in register q, which is the B operand of a
+    // product whose k index runs 4g + q at step q; A follows that order
+    f32x4 t21 = {0.f, 0.f, 0.f, 0.f}, r21 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 32; ++r) Dk[r * DT + l31] = x[r];                   // X[r][c], zero above the diagonal
+    for (int s = 0; s < 4; ++s)
+        t21 = __builtin_amdgcn_mfma_f32_16x16x4f32(v21[s], Dk[(4 * s + g) * DT + l15], t21, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        r21 = __builtin_amdgcn_mfma_f32_16x16x4f32(Dk[(16 + l15) * DT + 16 + 4 * g + q], t21[q], r21, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Dk[(16 + 4 * g + q) * DT + l15] = -r21[q];
+    VOLT_STAMP(14);
 }
 
+template <bool STAMP = false>
 __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
-                                          int Np, int k, int b, float* smem) {
+                                          int Np, int k, int b, float* smem, long long* stamps = nullptr,
+                                          bool loaded = false) {
     float* sT = smem;                                    // row-major image (row stride DT): A -> L / X -> W
+    VOLT_STAMP(0);
     const int n = Np / TS;
     float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     float* W = Winv + ((int64_t)b * n + k) * TS * TS;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
 
-    for (int e = tid; e < TS * TS / 4; e += NT) {        // lower triangle in, zeros above
-        const int r = e >> 5, c = (e & 31) * 4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(D + (int64_t)r * Np + c);
+    if (!loaded) {                                       // lower triangle in (unless update_body left it in the image), zeros above: every load in flight at once
+        f32x4 v[TS * TS / 4 / NT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sT[r * DT + c + q] = (c + q <= r) ? v[q] : 0.f;
+        for (int it = 0; it < TS * TS / 4 / NT; ++it) {
+            const int e = tid + it * NT, r = e >> 5, c = (e & 31) * 4;
+            v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c <= r) v[it] = *reinterpret_cast<const f32x4*>(D + (int64_t)r * Np + c);
+        }
+#pragma unroll
+        for (int it = 0; it < TS * TS / 4 / NT; ++it) {
+            const int e = tid + it * NT, r = e >> 5, c = (e & 31) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sT[r * DT + c + q] = (c + q <= r) ? v[it][q] : 0.f;
+        }
     }
     __syncthreads();
+    VOLT_STAMP(1);
 
     // ---- L = chol(D), blocked by 32: factor32 on one wave, panel solve and trailing updates on the matrix cores.
     // Wave 0 runs ahead: it updates the next diagonal sub-block first and factors it while waves 1..3 finish the
     // other updates of the step.
     int bad = 0;
-    if (wave == 0) factor32(sT, 0, D, Np, bad);
+    if (wave == 0) factor32<STAMP>(sT, 0, D, Np, bad, stamps);
     __syncthreads();
+    VOLT_STAMP(2);
 #pragma unroll 1
     for (int kb = 0; kb < 3; ++kb) {
         // panel: L[i,kb] = A[i,kb] X_kb^T, block row i = kb+1+wave
@@ -350,23 +452,15 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
             }
         if (wave == 0) factor32(sT, kb + 1, D, Np, bad);
         __syncthreads();
+        VOLT_STAMP(3 + kb);
     }
-    // off-diagonal L blocks out (the diagonal sub-blocks went out of factor32's registers), zeros above
-    for (int e = tid; e < TS * TS / 4; e += NT) {
-        const int r = e >> 5, c = (e & 31) * 4;
-        if ((r >> 5) != (c >> 5)) {
-            f32x4 v;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (c < r) ? sT[r * DT + c + q] : 0.f;
-            *reinterpret_cast<f32x4*>(D + (int64_t)r * Np + c) = v;
-        }
-    }
-
+    VOLT_STAMP(6);
     // ---- W = L^-1, blocked by 32 on the matrix cores: wave j < 3 owns block column j,
     // W[i,j] = -X_i * sum_{m=j}^{i-1} L[i,m] W[m,j], top to bottom; the W[m,j] it produced stay in its accumulators
-    // and are fed back as B operands from registers; then the W blocks replace the L blocks and the image goes out.
-    f32x16 Wr[3];
+    // and are fed back as B operands from registers.  W[i,j] is parked in the image block (j,i) ABOVE the diagonal,
+    // which nothing else uses: the L blocks stay intact and go out after W_k has been published.
     if (wave < 3) {
+        f32x16 Wr[3];
         const int j = wave;
 #pragma unroll
         for (int di = 1; di <= 3; ++di) {
@@ -384,31 +478,26 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
                 for (int q = 0; q < 16; ++q) R[q] = 0.f;
                 R = mm32_lds_reg(R, sT + (32 * i) * DT + 32 * i, S);                                  // X_i S
 #pragma unroll
-                for (int q = 0; q < 16; ++q) Wr[di - 1][q] = -R[q];
-            }
-        }
-    }
-    __syncthreads();                                                          // every L block has been consumed
-    if (wave < 3) {
-        const int j = wave;
-#pragma unroll
-        for (int di = 1; di <= 3; ++di) {
-            const int i = j + di;
-            if (i <= 3) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) sT[(32 * i + accrow(q, lane)) * DT + 32 * j + l31] = Wr[di - 1][q];
+                for (int q = 0; q < 16; ++q) {
+                    Wr[di - 1][q] = -R[q];
+                    sT[(32 * j + accrow(q, lane)) * DT + 32 * i + l31] = -R[q];
+                }
             }
         }
     }
     __syncthreads();
+    VOLT_STAMP(7);
     // W goes out, all but its first word: W[0][0] = 1 / L[0][0] is never 0 (NaN for a failed pivot), so it doubles as
     // the "W_k is ready" flag the panel tiles of the same launch poll -- published last, behind an agent-scope release.
     const float w00 = sT[0];
     for (int e = tid; e < TS * TS / 4; e += NT) {
         const int r = e >> 5, c = (e & 31) * 4;
+        const int rb = r >> 5, cb = c >> 5;
+        // diagonal blocks: X where it stands; below: the parked block (cb, rb), same in-block coordinates
+        const float* src = (rb == cb) ? sT + r * DT + c : sT + (32 * cb + (r & 31)) * DT + 32 * rb + (c & 31);
         f32x4 w4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) w4[q] = (c + q <= r) ? sT[r * DT + c + q] : 0.f;
+        for (int q = 0; q < 4; ++q) w4[q] = (c + q <= r) ? src[q] : 0.f;
         if (e == 0) {
             W[1] = 0.f; W[2] = 0.f; W[3] = 0.f;
         } else {
@@ -416,14 +505,28 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         }
     }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);          // tid 0 sits in wave 0, which tracked the pivots
+    VOLT_STAMP(8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    VOLT_STAMP(9);
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int bits = __float_as_int(w00);
         __hip_atomic_store(reinterpret_cast<int*>(W), bits ? bits : 0x7fc00000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    VOLT_STAMP(10);
+    // off-diagonal L blocks out (the diagonal sub-blocks went out of factor32's registers), zeros above: behind the
+    // publish, only the next launch reads them
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        if ((r >> 5) != (c >> 5)) {
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = (c < r) ? sT[r * DT + c + q] : 0.f;
+            *reinterpret_cast<f32x4*>(D + (int64_t)r * Np + c) = v;
+        }
+    }
+    VOLT_STAMP(15);
 }
 
 // ----------------------------------------------------------------------------- trtri
@@ -636,13 +739,9 @@ __global__ __launch_bounds__(256, 2) void factor_step_kernel(float* __restrict__
     if (k_upd >= 0) {
         const int k = k_upd;
         if (w < B) {                                                      // diagonal tile of matrix w
-            if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, w, src, smem);
-            else if (k == 1) update_body<FROMK>(A, Np, 1, 1, 0, 1, true, w, src, smem);
-            if (k > 0) {
-                __threadfence_block();           // this workgroup's own C-tile stores, re-read below
-                __syncthreads();
-            }
-            diag_body(A, Winv, info, Np, k, w, smem);
+            if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, w, src, smem, true);
+            else if (k == 1) update_body<FROMK>(A, Np, 1, 1, 0, 1, true, w, src, smem, true);
+            diag_body(A, Winv, info, Np, k, w, smem, nullptr, k > 0);
             return;
         }
         w -= B;
@@ -768,13 +867,9 @@ __global__ __launch_bounds__(256, 2) void factor_step_split_kernel(float* __rest
     const int k = k_upd;                                     // k >= 0 always here (the trailing trtri row passes k = n)
     // ---- diagonal tiles: as in factor_step_kernel
     if (k < n && w < B) {
-        if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, w, src, smem);
-        else if (k == 1) update_body<FROMK>(A, Np, 1, 1, 0, 1, true, w, src, smem);
-        if (k > 0) {
-            __threadfence_block();
-            __syncthreads();
-        }
-        diag_body(A, Winv, info, Np, k, w, smem);
+        if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, w, src, smem, true);
+        else if (k == 1) update_body<FROMK>(A, Np, 1, 1, 0, 1, true, w, src, smem, true);
+        diag_body(A, Winv, info, Np, k, w, smem, nullptr, k > 0);
         return;
     }
     if (k < n) w -= B;
@@ -876,6 +971,13 @@ __global__ __launch_bounds__(256, 2) void factor_step_split_kernel(float* __rest
     if (threadIdx.x == 0 && !ok) atomicCAS(info + jb.b, 0, (int)0x80000000);
     tri_store(O, jb.out, Np);
     if (jb.i >= 0 && red.rpad) trtri_reduce(O, Np, jb.i, jb.j, jb.b, red, smem);
+}
+
+// Diagonal block alone with phase stamps (tuning hook): one workgroup per matrix on block column k of a COPY of A
+__global__ __launch_bounds__(256, 2) void tune_diag_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                          int* __restrict__ info, int Np, int k, long long* stamps) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    diag_body<true>(A, Winv, info, Np, k, blockIdx.x, smem, stamps + 16 * blockIdx.x);
 }
 
 // Clears the first word of every W block: it is the "ready" flag of the block (diag_body / panel_body).
@@ -1260,6 +1362,19 @@ int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, 
         else if (var == 4) hipLaunchKernelGGL(tune_update_sq_kernel<3>, dim3((n - k - 1) * B), dim3(256), 0, s, A, Np, k, B, none);
         else hipLaunchKernelGGL(tune_empty_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A);
     }
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!info) return -3;
+    if (B < 1) return -4;
+    if (Np < TS || Np % TS) return -5;
+    if (k < 0 || k >= Np / TS) return -6;
+    if (!stamps) return -7;
+    hipLaunchKernelGGL(tune_diag_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, A, Winv, info, Np, k, stamps);
     VOLT_LAUNCH_CHECK();
     return 0;
 }

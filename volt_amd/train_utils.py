@@ -218,7 +218,7 @@ def TrainBasicModel(train_x, train_y, train_iters=1000, printing=False, model_ty
     return model, lh
 
 
-def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False):
+def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, graph=False):
     voltron_lh = GaussianLikelihood().to(train_x.device)
     voltron = VoltronGP(train_x, train_y.log(), voltron_lh, vol_path)
     voltron.mean_module = LogLinearMean(1).to(train_x.device)
