@@ -160,7 +160,7 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
  * matters. */
 int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream);
 /* The diagonal-block kernel alone on block column k of B (unfactored) matrices, with s_memtime stamps of its
- * phases: stamps [B,16] int64 (load, factor32 x4 with panel / trailing updates, L out, inverse, W out, publish). */
+ * phases: stamps [B,32] int64 (load, factor32 x4 with panel / trailing updates, L out, inverse, W out, publish). */
 int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);
 
 /* ---- a5: MLL + gradient  (ExactMarginalLogLikelihood + loss.backward(), train_utils.py:249-250)

@@ -176,22 +176,30 @@ constexpr int DIAG_LDS_FLOATS = TS * DT;                        // 66,048 B, fit
 // 32x32x32 products on fp32 MFMA for the blocked inverse below.  A (and B) are 32x32 blocks of the LDS tile image
 // (row stride DT); "reg" variants take the B operand straight from an accumulator: register q of lane (c, h) holds
 // B[p_q + 4h][c], p_q = (q&3) + 8(q>>2), which is exactly what MFMA step q wants if A supplies column p_q + 4h.
+// Operands are fetched for the whole product first (32 independent LDS reads in flight) and the 16 MFMAs then issue
+// back to back: left interleaved, every step waited for its own two reads (1.0 us per product instead of 0.45).
 __device__ __forceinline__ f32x16 mm32_lds_lds(f32x16 acc, const float* __restrict__ A, const float* __restrict__ B) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    float av[16], bv[16];
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
         const int kk = 2 * s2 + lh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[l31 * DT + kk], B[kk * DT + l31], acc, 0, 0, 0);
+        av[s2] = A[l31 * DT + kk];
+        bv[s2] = B[kk * DT + l31];
     }
+    VOLT_SB();
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2], bv[s2], acc, 0, 0, 0);
     return acc;
 }
 __device__ __forceinline__ f32x16 mm32_lds_reg(f32x16 acc, const float* __restrict__ A, const f32x16& Breg) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    float av[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int p = (q & 3) + 8 * (q >> 2) + 4 * lh;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[l31 * DT + p], Breg[q], acc, 0, 0, 0);
-    }
+    for (int q = 0; q < 16; ++q) av[q] = A[l31 * DT + (q & 3) + 8 * (q >> 2) + 4 * lh];
+    VOLT_SB();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], Breg[q], acc, 0, 0, 0);
     return acc;
 }
 
@@ -199,12 +207,17 @@ __device__ __forceinline__ f32x16 mm32_lds_reg(f32x16 acc, const float* __restri
 template <bool NEG>
 __device__ __forceinline__ f32x16 mm32_nt(f32x16 acc, const float* __restrict__ A, const float* __restrict__ B) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, lh = lane >> 5;
+    float av[16], bv[16];
 #pragma unroll
     for (int s2 = 0; s2 < 16; ++s2) {
         const int kk = 2 * s2 + lh;
-        const float av = A[l31 * DT + kk];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(NEG ? -av : av, B[l31 * DT + kk], acc, 0, 0, 0);
+        av[s2] = A[l31 * DT + kk];
+        bv[s2] = B[l31 * DT + kk];
     }
+    VOLT_SB();
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(NEG ? -av[s2] : av[s2], bv[s2], acc, 0, 0, 0);
     return acc;
 }
 
@@ -249,24 +262,26 @@ __device__ __forceinline__ void rl_fma1(float& c0, float b0, float s0, int l0) {
         if (STAMP && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memtime();       \
     } while (0)
 
-// One wave factors the 32x32 diagonal sub-block kb of the image and inverts it, recursively blocked by 16.  Lane r
-// (both half-waves hold the same data) keeps row r in registers; per pivot the pivot and the column entries travel by
-// v_readlane (SGPR broadcast), so the dependent pivots cost no barrier and no LDS round trip -- but every element
-// update is a readlane + FMA pair, and that instruction count is what the diagonal block's latency is made of.  So
-// only the two 16x16 diagonal quarters (and, for free, the 16x16 panel below the first: its rows sit in lanes 16..31
-// of the same instructions) are done that way; the Schur complement A22 -= L21 L21^T and the off-diagonal quarter of
-// the inverse X21 = -X22 L21 X11 go through the image to v_mfma_f32_16x16x4_f32 (480 pairs + 16 MFMAs instead of
-// 992 pairs: 6.3 -> 3.x us per sub-block).  L_kk goes straight to global memory; X = L_kk^-1 replaces it in the image:
-// the panel solve, the trailing updates and the blocked inverse only ever need X.
+// The 128x128 diagonal block is factored in four sub-block columns of 32.  A wave keeps one matrix row per lane in
+// registers; per pivot the pivot and the column entries travel by v_readlane (SGPR broadcast), so the dependent pivots
+// cost no barrier and no LDS round trip -- but every element update is a readlane + FMA pair (5 clocks each, measured:
+// scripts/ubench/readlane.hip), and that instruction count is what the block's latency is made of.  Two things keep
+// it down:
+//  * recursion by 16: only the two 16x16 diagonal quarters of a sub-block go through the pivot loop; the Schur
+//    complement between them runs on v_mfma_f32_16x16x4_f32 (through a small private LDS scratch for the layout change);
+//  * the rows BELOW the sub-block ride along: lanes 32..63 of a pivot wave carry the 32 rows of one panel block
+//    (kb+1+wave, kb), which the very same instructions turn into L[i,kb] = A[i,kb] L_kk^-T.  Waves 0..2 each repeat the
+//    (tiny) diagonal factorisation for their own panel block, so NO inverse is needed on the way down: X_kb = L_kk^-1
+//    and the rows of W = L^-1 are worked out one phase later by the waves that have no panel rows left.
 // pivots j in [J0, J1) of the lane-per-row factorisation, updating columns (j, J1)
 template <int J0, int J1>
-__device__ __forceinline__ void pivots16(float (&a)[32], float (&rv)[32], int kb, int& bad) {
+__device__ __forceinline__ void pivots16(float (&a)[32], float (&rv)[32], int& npos) {
     settle(a[J0]);
     float d = lane_bcast(a[J0], J0);
     float rinv = __builtin_amdgcn_rsqf(d);
 #pragma unroll
     for (int j = J0; j < J1; ++j) {
-        if (!(d > 0.f) && bad == 0) bad = 32 * kb + j + 1;                  // non-positive or NaN pivot (wave-uniform)
+        npos += (d > 0.f) ? 1 : 0;                                          // non-positive and NaN pivots are not counted
         rv[j] = rinv;
         float l = a[j] * rinv;                                              // lane r: L[r][j]; lane j: sqrt(d)
         settle(l);
@@ -314,63 +329,129 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int PSC = 17;                                         // row stride of the 16x16 private scratch tiles
+constexpr int PIVOT_SCRATCH_FLOATS = 2 * 16 * PSC;              // per pivot wave: L21 and the updated A22
+static_assert(DIAG_LDS_FLOATS + 3 * PIVOT_SCRATCH_FLOATS <= 2 * STAGE_FLOATS, "pivot scratch must fit behind the image");
+
+// One pivot wave, sub-block column kb: lanes 0..31 hold the rows of the diagonal sub-block (kb,kb), lanes 32..63 the
+// rows of the panel block (prow,kb) -- or mirror lanes 0..31 when prow < 0.  The diagonal sub-block in the image is
+// only READ here (several waves factor it side by side); the panel block is rewritten in place with L[prow,kb]; the
+// factored diagonal rows come back in a[] (lane r < 32: L_kk[r][0..r]).
 template <bool STAMP = false>
-__device__ __forceinline__ void factor32(float* __restrict__ sT, int kb, float* __restrict__ Dg, int Np, int& bad,
-                                         long long* stamps = nullptr) {
-    const int lane = threadIdx.x & 63, l31 = lane & 31, l15 = lane & 15, g = lane >> 4;
+__device__ __forceinline__ void pivot_phase(float* __restrict__ sT, int kb, int prow, float (&a)[32], int& npos,
+                                            long long* stamps = nullptr) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, l15 = lane & 15, g = lane >> 4;
+    const bool panel = prow >= 0;                                           // wave-uniform
+    const bool prw = panel && lane >= 32;                                   // this lane carries a panel row
+    const bool low = !prw && l31 >= 16;                                     // ... a row of the lower diagonal half
     float* Dk = sT + (32 * kb) * DT + 32 * kb;
-    float a[32], rv[32];
-    // ---- left half: L11 (lanes 0..15) and L21 = A21 L11^-T (lanes 16..31) in the same pivot loop
+    float* Rw = prw ? sT + (32 * prow + l31) * DT + 32 * kb : Dk + l31 * DT;
+    float* S21 = sT + DIAG_LDS_FLOATS + wave * PIVOT_SCRATCH_FLOATS;        // L21[16][16] of this wave's copy
+    float* S22 = S21 + 16 * PSC;                                            // A22 - L21 L21^T
+    float rv[32];
+    // ---- left half: L11 (lanes 0..15), L21 = A21 L11^-T (lanes 16..31), P1 = A[prow,kb][:, :16] L11^-T (lanes 32..63)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = Dk[l31 * DT + c];
-    pivots16<0, 16>(a, rv, kb, bad);
+    for (int c = 0; c < 16; ++c) a[c] = Rw[c];
+    if (STAMP && kb == 1) VOLT_STAMP(16);
+    pivots16<0, 16>(a, rv, npos);
+    if (STAMP && kb == 1) VOLT_STAMP(17);
+    {
+        float* dst = prw ? Rw : S21 + (l31 & 15) * PSC;
+        if (prw || low) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Dk[l31 * DT + c] = a[c];                   // rows 16..31: L21, read back in MFMA layout
+            for (int c = 0; c < 16; ++c) dst[c] = a[c];
+        }
+    }
     wave_lds_fence();
-    // ---- A22 -= L21 L21^T on the matrix cores: A[i][k] and B[k][j] are the same register, L21[l15][4s + g]
+    // ---- Schur complement on the matrix cores: [A22; P2] -= [L21; P1] L21^T, B[k][j] = L21[j][k] = L21[l15][4s + g]
     float v21[4];
-    f32x4 s22;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) v21[s] = Dk[(16 + l15) * DT + 4 * s + g];
+    for (int s = 0; s < 4; ++s) v21[s] = S21[l15 * PSC + 4 * s + g];
+    {
+        f32x4 c22;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s22[q] = Dk[(16 + 4 * g + q) * DT + 16 + l15];
+        for (int q = 0; q < 4; ++q) c22[q] = Dk[(16 + 4 * g + q) * DT + 16 + l15];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) s22 = __builtin_amdgcn_mfma_f32_16x16x4f32(-v21[s], v21[s], s22, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) c22 = __builtin_amdgcn_mfma_f32_16x16x4f32(-v21[s], v21[s], c22, 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Dk[(16 + 4 * g + q) * DT + 16 + l15] = s22[q];
-    wave_lds_fence();
-    // ---- right half: L22 in lanes 16..31 (the others carry zeros)
-#pragma unroll
-    for (int c = 16; c < 32; ++c) {
-        const float t = Dk[l31 * DT + c];
-        a[c] = (l31 >= 16) ? t : 0.f;
+        for (int q = 0; q < 4; ++q) S22[(4 * g + q) * PSC + l15] = c22[q];
     }
-    pivots16<16, 32>(a, rv, kb, bad);
-    VOLT_STAMP(11);
-    // L_kk out (zeros above the diagonal); both half-waves write the same words
-    float* Dgk = Dg + (int64_t)(32 * kb + l31) * Np + 32 * kb;
+    if (panel) {
+        float* Pk = sT + (32 * prow) * DT + 32 * kb;
 #pragma unroll
-    for (int c4 = 0; c4 < 8; ++c4) {
-        f32x4 v;
+        for (int t = 0; t < 2; ++t) {
+            f32x4 cp;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = (4 * c4 + q <= l31) ? a[4 * c4 + q] : 0.f;
-        *reinterpret_cast<f32x4*>(Dgk + 4 * c4) = v;
-    }
-    VOLT_STAMP(12);
-    // ---- X11 = L11^-1 (columns in lanes 0..15, zero elsewhere) and X22 = L22^-1 (lanes 16..31)
-    float x[32];
-    invert16<0, 16>(a, rv, x, l31);
-    invert16<16, 32>(a, rv, x, l31);
-    VOLT_STAMP(13);
+            for (int q = 0; q < 4; ++q) cp[q] = Pk[(16 * t + 4 * g + q) * DT + 16 + l15];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Dk[r * DT + l31] = x[r];                   // X11 | 0
-    if (l31 >= 16) {
+            for (int s = 0; s < 4; ++s)
+                cp = __builtin_amdgcn_mfma_f32_16x16x4f32(-Pk[(16 * t + l15) * DT + 4 * s + g], v21[s], cp, 0, 0, 0);
 #pragma unroll
-        for (int r = 16; r < 32; ++r) Dk[r * DT + l31] = x[r];              // X22 (the L21 quarter beside it stays)
+            for (int q = 0; q < 4; ++q) Pk[(16 * t + 4 * g + q) * DT + 16 + l15] = cp[q];
+        }
     }
     wave_lds_fence();
-    // ---- X21 = -X22 (L21 X11): T = L21 X11 lands as T[4g + q][l15] in register q, which is the B operand of a
-    // product whose k index runs 4g + q at step q; A follows that order
+    if (STAMP && kb == 1) VOLT_STAMP(18);
+    // ---- right half: L22 in lanes 16..31 (lanes 0..15 carry zeros), P2 L22^-T in lanes 32..63
+    {
+        const float* src = prw ? Rw + 16 : S22 + (l31 & 15) * PSC;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float t = src[c];
+            a[16 + c] = (prw || low) ? t : 0.f;
+        }
+    }
+    if (STAMP && kb == 1) VOLT_STAMP(19);
+    pivots16<16, 32>(a, rv, npos);
+    if (STAMP && kb == 1) VOLT_STAMP(20);
+    if (prw) {
+#pragma unroll
+        for (int c = 16; c < 32; ++c) Rw[c] = a[c];
+    }
+}
+
+// Stores into the 128x128 block W_k go through one buffer descriptor: lane part of the address in ONE 32-bit VGPR,
+// the row part as a constant scalar offset.  (As flat stores the rows are 512 B apart, beyond the 12-bit immediate:
+// the compiler then keeps a 64-bit address pair per store and hoists them all -- 190 spilled VGPRs.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(float* W) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, TS * TS * 4, 0x00020000);
+}
+__device__ __forceinline__ void w_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+}
+// One wave: X = L_kk^-1 in place of L_kk in the image, and out to the diagonal block kb of W in memory -- all but
+// W[0][0], the ready flag, which is published last.  The two 16x16 diagonal quarters are inverted SIDE BY SIDE, X11 in
+// lanes 0..15 and X22 in lanes 32..47 (lane c solves L x = e_c by forward substitution); the L entries are the same
+// for every lane of a half-wave and come as LDS broadcast reads -- one ds_read + one FMA per term and no row
+// registers, where the pivot loop's readlane idiom would need two instructions and serve one quarter at a time.  The
+// off-diagonal quarter X21 = -X22 L21 X11 runs on the matrix cores.
+__device__ __forceinline__ void x_block(float* __restrict__ sT, int kb, __amdgpu_buffer_rsrc_t rs) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4, h = lane >> 5;
+    const bool up = (lane & 16) != 0;                                       // lanes 16..31, 48..63: no column of their own
+    float* Dk = sT + (32 * kb) * DT + 32 * kb;
+    const float* Lh = Dk + (16 * h) * DT + 16 * h;                          // this half-wave's diagonal quarter
+    float v21[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v21[s] = Dk[(16 + l15) * DT + 4 * s + g];   // L21 in MFMA operand layout
+    float x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float acc = (r == l15) ? 1.f : 0.f;
+#pragma unroll
+        for (int m = 0; m < r; ++m) acc = __builtin_fmaf(-Lh[r * DT + m], x[m], acc);
+        const float d = Lh[r * DT + r];
+        const float ri = __builtin_amdgcn_rcpf(d);
+        x[r] = acc * __builtin_fmaf(__builtin_fmaf(-d, ri, 1.f), ri, ri);   // one Newton step on the hardware reciprocal
+    }
+    wave_lds_fence();
+    if (!up) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Dk[(16 * h + r) * DT + 16 * h + l15] = x[r];      // X11, X22 (zeros above stay)
+    }
+    wave_lds_fence();
+    // T = L21 X11 lands as T[4g + q][l15] in register q, which is the B operand of a product whose k index runs
+    // 4g + q at step q; A follows that order
     f32x4 t21 = {0.f, 0.f, 0.f, 0.f}, r21 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -378,16 +459,58 @@ __device__ __forceinline__ void factor32(float* __restrict__ sT, int kb, float* 
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         r21 = __builtin_amdgcn_mfma_f32_16x16x4f32(Dk[(16 + l15) * DT + 16 + 4 * g + q], t21[q], r21, 0, 0, 0);
+    const int wbase = (32 * kb * TS + 32 * kb) * 4;                         // block (kb,kb) of W, bytes
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Dk[(16 + 4 * g + q) * DT + l15] = -r21[q];
-    VOLT_STAMP(14);
+    for (int q = 0; q < 4; ++q) {
+        Dk[(16 + 4 * g + q) * DT + l15] = -r21[q];
+        w_store(rs, wbase + ((16 + 4 * g) * TS + l15) * 4, q * TS * 4, -r21[q]);                   // X21
+    }
+    // X11 and X22 from their lanes; lanes 16..31 write the zero quarter above X22
+    if (!up || h == 0) {
+        const int voff = wbase + (up ? 16 + l15 : (16 * h) * TS + 16 * h + l15) * 4;
+        if (kb != 0 || lane != 0) w_store(rs, voff, 0, up ? 0.f : x[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) w_store(rs, voff, r * TS * 4, up ? 0.f : x[r]);
+    }
 }
 
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) z[q] = 0.f;
+    return z;
+}
+// a finished block (i,j) of W: -R (accumulator layout) to memory and, when later blocks need it as an operand, to an
+// image block
+__device__ __forceinline__ void w_out(__amdgpu_buffer_rsrc_t rs, int i, int j, float* __restrict__ blk, const f32x16& R) {
+    const int lane = threadIdx.x & 63;
+    const int voff = ((32 * i + 4 * (lane >> 5)) * TS + 32 * j + (lane & 31)) * 4;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        w_store(rs, voff, ((q & 3) + 8 * (q >> 2)) * TS * 4, -R[q]);
+        if (blk) blk[accrow(q, lane) * DT + (lane & 31)] = -R[q];
+    }
+}
+
+// One workgroup per matrix factors the 128x128 diagonal block D = L L^T and inverts it, W = L^-1.  Phases between
+// barriers (kb = sub-block column; "pivot k" = pivot_phase, "X k" = x_block, "W ij" = one 32x32 block of the inverse):
+//   A0  waves 0,1,2: pivot 0 with panel blocks (1,0) (2,0) (3,0);  wave 3: the zero blocks of W
+//   B0  A[i,1] -= L[i,0] L[1,0]^T, i = 1..3, one block per wave      (wave 0 first parks L_00 in the image and in memory)
+//   A1  waves 0,1: pivot 1 with (2,1) (3,1);  wave 2: X 0;  wave 3: step 0's updates of (2,2) (3,2) (3,3)
+//   B1  A[i,2] -= L[i,1] L[2,1]^T, i = 2, 3
+//   A2  wave 0: pivot 2 with (3,2);  wave 1: X 1;  wave 3: step 1's update of (3,3)
+//   B2  A[3,3] -= L[3,2] L[3,2]^T
+//   A3  wave 0: pivot 3;  wave 1: X 2;  wave 2: W 10
+//   A4  wave 0: X 3;  wave 1: W 20;  wave 2: W 21, then L31 X1;  wave 3: L30 X0 + L31 W10
+//   T   wave 3: W 30;  wave 2: W 31;  wave 1: W 32
+// W[i,j] = -X_i sum_{m=j}^{i-1} L[i,m] W[m,j] (W[j,j] = X_j).  Every block of W goes to memory from the registers of
+// the wave that made it; W10, W20, W21 are also parked in the image blocks (0,1) (0,2) (1,2) ABOVE the diagonal, which
+// nothing else uses, as operands for the rows below.  The L blocks stay intact and go out after W_k has been published.
 template <bool STAMP = false>
 __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
                                           int Np, int k, int b, float* smem, long long* stamps = nullptr,
                                           bool loaded = false) {
-    float* sT = smem;                                    // row-major image (row stride DT): A -> L / X -> W
+    float* sT = smem;                                    // row-major image (row stride DT): A -> L / X / W
     VOLT_STAMP(0);
     const int n = Np / TS;
     float* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
@@ -395,7 +518,7 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31;
 
-    if (!loaded) {                                       // lower triangle in (unless update_body left it in the image), zeros above: every load in flight at once
+    if (!loaded) {                                       // lower triangle in (unless update_body left it in the image)
         f32x4 v[TS * TS / 4 / NT];
 #pragma unroll
         for (int it = 0; it < TS * TS / 4 / NT; ++it) {
@@ -413,109 +536,124 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
     __syncthreads();
     VOLT_STAMP(1);
 
-    // ---- L = chol(D), blocked by 32: factor32 on one wave, panel solve and trailing updates on the matrix cores.
-    // Wave 0 runs ahead: it updates the next diagonal sub-block first and factors it while waves 1..3 finish the
-    // other updates of the step.
+    auto blk = [&](int i, int j) { return sT + (32 * i) * DT + 32 * j; };
+    const __amdgpu_buffer_rsrc_t wrs = w_rsrc(W);
+    // A[i,j] -= L[i,m] L[j,m]^T on this wave
+    auto trail = [&](int i, int j, int m) {
+        float* C = blk(i, j);
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = C[accrow(q, lane) * DT + l31];
+        acc = mm32_nt<true>(acc, blk(i, m), blk(j, m));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) C[accrow(q, lane) * DT + l31] = acc[q];
+    };
+    // L_kk out of wave 0's registers: to memory, and into the image for x_block
+    auto park_l = [&](int kb, const float (&a)[32]) {
+        if (lane < 32) {
+            float* Dgk = D + (int64_t)(32 * kb + l31) * Np + 32 * kb;
+            float* Dk = blk(kb, kb) + l31 * DT;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q] = (4 * c4 + q <= l31) ? a[4 * c4 + q] : 0.f;
+                    Dk[4 * c4 + q] = v[q];
+                }
+                *reinterpret_cast<f32x4*>(Dgk + 4 * c4) = v;
+            }
+        }
+    };
     int bad = 0;
-    if (wave == 0) factor32<STAMP>(sT, 0, D, Np, bad, stamps);
-    __syncthreads();
-    VOLT_STAMP(2);
 #pragma unroll 1
-    for (int kb = 0; kb < 3; ++kb) {
-        // panel: L[i,kb] = A[i,kb] X_kb^T, block row i = kb+1+wave
-        if (kb + 1 + wave <= 3) {
-            const int i = kb + 1 + wave;
-            float* P = sT + (32 * i) * DT + 32 * kb;
-            f32x16 acc;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-            acc = mm32_nt<false>(acc, P, sT + (32 * kb) * DT + 32 * kb);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) P[accrow(q, lane) * DT + l31] = acc[q];
-        }
-        __syncthreads();
-        // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3: (kb+1,kb+1) on wave 0, the rest dealt to 1..3
-        int cnt = 0;
-        for (int i = kb + 1; i <= 3; ++i)
-            for (int j = kb + 1; j <= i; ++j) {
-                const bool first = (i == kb + 1);                              // then j == kb+1 too
-                const int owner = first ? 0 : 1 + (cnt++ % 3);
-                if (wave == owner) {
-                    float* C = sT + (32 * i) * DT + 32 * j;
-                    f32x16 acc;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) acc[q] = C[accrow(q, lane) * DT + l31];
-                    acc = mm32_nt<true>(acc, sT + (32 * i) * DT + 32 * kb, sT + (32 * j) * DT + 32 * kb);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) C[accrow(q, lane) * DT + l31] = acc[q];
+    for (int kb = 0; kb <= 4; ++kb) {
+        float a[32];                                     // wave 0: the factored rows of sub-block kb, phase A -> B
+        f32x16 P = zero16();                             // kb = 4, waves 2, 3: partial sums of W's last block row, A4 -> T
+        // ---- phase A
+        const int npw = kb > 3 ? 0 : (kb == 3 ? 1 : 3 - kb);               // pivot waves
+        const int xw = kb == 1 ? 2 : (kb == 4 ? 0 : 1);                     // the wave that inverts sub-block kb - 1
+        if (wave < npw) {
+            int npos = 0;
+            pivot_phase<STAMP>(sT, kb, kb < 3 ? kb + 1 + wave : -1, a, npos, stamps);
+            if (npos != 32 && bad == 0) {                                   // rare: find the first failed pivot, whose
+#pragma unroll                                                              // L[j][j] = d rsq(d) is NaN (d <= 0 or NaN)
+                for (int j = 0; j < 32; ++j) {
+                    const float ljj = lane_bcast(a[j], j);
+                    if (!(ljj > 0.f) && bad == 0) bad = 32 * kb + j + 1;
                 }
             }
-        if (wave == 0) factor32(sT, kb + 1, D, Np, bad);
+            if (kb == 3) park_l(3, a);                                      // no other wave reads (3,3) in this phase
+        } else if (kb >= 1 && wave == xw) {
+            x_block(sT, kb - 1, wrs);
+        } else if (kb == 0) {                                               // wave 3: the zero blocks of W above the diagonal
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            const int voff = ((lane >> 3) * TS + 4 * (lane & 7)) * 4;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = i + 1; j <= 3; ++j)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it)
+                        __builtin_amdgcn_raw_buffer_store_b128(z, wrs, voff, ((32 * i + 8 * it) * TS + 32 * j) * 4, 0);
+        } else if (wave == 3 && kb <= 2) {                                  // what step kb-1 still owes the blocks right of column kb
+            for (int i = kb + 1; i <= 3; ++i)
+                for (int j = kb + 1; j <= i; ++j) trail(i, j, kb - 1);
+        } else if (kb == 3 && wave == 2) {
+            f32x16 S = mm32_lds_lds(zero16(), blk(1, 0), blk(0, 0));                                  // L10 X0
+            w_out(wrs, 1, 0, blk(0, 1), mm32_lds_reg(zero16(), blk(1, 1), S));                      // W10 = -X1 S
+        } else if (kb == 4 && wave == 1) {
+            f32x16 S = mm32_lds_lds(zero16(), blk(2, 0), blk(0, 0));                                  // L20 X0
+            S = mm32_lds_lds(S, blk(2, 1), blk(0, 1));                                                // + L21 W10
+            w_out(wrs, 2, 0, blk(0, 2), mm32_lds_reg(zero16(), blk(2, 2), S));                      // W20 = -X2 S
+        } else if (kb == 4 && wave == 2) {
+            f32x16 S = mm32_lds_lds(zero16(), blk(2, 1), blk(1, 1));                                  // L21 X1
+            w_out(wrs, 2, 1, blk(1, 2), mm32_lds_reg(zero16(), blk(2, 2), S));                      // W21 = -X2 S
+            P = mm32_lds_lds(P, blk(3, 1), blk(1, 1));                                                // L31 X1
+        } else if (kb == 4 && wave == 3) {
+            P = mm32_lds_lds(P, blk(3, 0), blk(0, 0));                                                // L30 X0
+            P = mm32_lds_lds(P, blk(3, 1), blk(0, 1));                                                // + L31 W10
+        }
+        if (STAMP && kb == 1 && lane == 0) stamps[21 + wave] = __builtin_amdgcn_s_memtime();
+        if (STAMP && kb == 3 && lane == 0) stamps[25 + wave] = __builtin_amdgcn_s_memtime();
         __syncthreads();
-        VOLT_STAMP(3 + kb);
-    }
-    VOLT_STAMP(6);
-    // ---- W = L^-1, blocked by 32 on the matrix cores: wave j < 3 owns block column j,
-    // W[i,j] = -X_i * sum_{m=j}^{i-1} L[i,m] W[m,j], top to bottom; the W[m,j] it produced stay in its accumulators
-    // and are fed back as B operands from registers.  W[i,j] is parked in the image block (j,i) ABOVE the diagonal,
-    // which nothing else uses: the L blocks stay intact and go out after W_k has been published.
-    if (wave < 3) {
-        f32x16 Wr[3];
-        const int j = wave;
-#pragma unroll
-        for (int di = 1; di <= 3; ++di) {
-            const int i = j + di;
-            if (i <= 3) {                                                     // wave-uniform
-                f32x16 S;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) S[q] = 0.f;
-                S = mm32_lds_lds(S, sT + (32 * i) * DT + 32 * j, sT + (32 * j) * DT + 32 * j);       // L[i,j] X_j
-#pragma unroll
-                for (int dm = 1; dm < di; ++dm)
-                    S = mm32_lds_reg(S, sT + (32 * i) * DT + 32 * (j + dm), Wr[dm - 1]);              // L[i,m] W[m,j]
-                f32x16 R;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) R[q] = 0.f;
-                R = mm32_lds_reg(R, sT + (32 * i) * DT + 32 * i, S);                                  // X_i S
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    Wr[di - 1][q] = -R[q];
-                    sT[(32 * j + accrow(q, lane)) * DT + 32 * i + l31] = -R[q];
-                }
+        VOLT_STAMP(2 + 2 * kb);
+        if (kb == 4) {
+            // ---- phase T: the last block row of W
+            if (wave == 3) {
+                P = mm32_lds_lds(P, blk(3, 2), blk(0, 2));                                            // + L32 W20
+                w_out(wrs, 3, 0, nullptr, mm32_lds_reg(zero16(), blk(3, 3), P));                    // W30 = -X3 P
+            } else if (wave == 2) {
+                P = mm32_lds_lds(P, blk(3, 2), blk(1, 2));                                            // + L32 W21
+                w_out(wrs, 3, 1, nullptr, mm32_lds_reg(zero16(), blk(3, 3), P));                    // W31
+            } else if (wave == 1) {
+                f32x16 S = mm32_lds_lds(zero16(), blk(3, 2), blk(2, 2));                              // L32 X2
+                w_out(wrs, 3, 2, nullptr, mm32_lds_reg(zero16(), blk(3, 3), S));                    // W32
             }
         }
-    }
-    __syncthreads();
-    VOLT_STAMP(7);
-    // W goes out, all but its first word: W[0][0] = 1 / L[0][0] is never 0 (NaN for a failed pivot), so it doubles as
-    // the "W_k is ready" flag the panel tiles of the same launch poll -- published last, behind an agent-scope release.
-    const float w00 = sT[0];
-    for (int e = tid; e < TS * TS / 4; e += NT) {
-        const int r = e >> 5, c = (e & 31) * 4;
-        const int rb = r >> 5, cb = c >> 5;
-        // diagonal blocks: X where it stands; below: the parked block (cb, rb), same in-block coordinates
-        const float* src = (rb == cb) ? sT + r * DT + c : sT + (32 * cb + (r & 31)) * DT + 32 * rb + (c & 31);
-        f32x4 w4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w4[q] = (c + q <= r) ? src[q] : 0.f;
-        if (e == 0) {
-            W[1] = 0.f; W[2] = 0.f; W[3] = 0.f;
-        } else {
-            *reinterpret_cast<f32x4*>(W + r * TS + c) = w4;
-        }
+        if (kb >= 3) continue;
+        // ---- phase B: L_kk out; the trailing updates of block column kb+1, A[i,kb+1] -= L[i,kb] L[kb+1,kb]^T, one per
+        // wave (the blocks further right are caught up by wave 3 during the next pivot phase)
+        if (wave == 0) park_l(kb, a);
+        if (kb + 1 + wave <= 3) trail(kb + 1 + wave, kb + 1, kb);
+        __syncthreads();
+        VOLT_STAMP(3 + 2 * kb);
     }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);          // tid 0 sits in wave 0, which tracked the pivots
-    VOLT_STAMP(8);
+    VOLT_STAMP(11);
+    // Every block of W went to memory from the wave that made it -- all but the first word: W[0][0] = 1 / L[0][0] is
+    // never 0 (NaN for a failed pivot), so it doubles as the "W_k is ready" flag the panel tiles of the same launch
+    // poll -- published last, behind an agent-scope release.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    VOLT_STAMP(9);
+    VOLT_STAMP(12);
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const int bits = __float_as_int(w00);
+        const int bits = __float_as_int(sT[0]);
         __hip_atomic_store(reinterpret_cast<int*>(W), bits ? bits : 0x7fc00000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    VOLT_STAMP(10);
-    // off-diagonal L blocks out (the diagonal sub-blocks went out of factor32's registers), zeros above: behind the
+    VOLT_STAMP(13);
+    // off-diagonal L blocks out (the diagonal sub-blocks went out of wave 0's registers), zeros above: behind the
     // publish, only the next launch reads them
     for (int e = tid; e < TS * TS / 4; e += NT) {
         const int r = e >> 5, c = (e & 31) * 4;
@@ -526,7 +664,7 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
             *reinterpret_cast<f32x4*>(D + (int64_t)r * Np + c) = v;
         }
     }
-    VOLT_STAMP(15);
+    VOLT_STAMP(14);
 }
 
 // ----------------------------------------------------------------------------- trtri
@@ -814,7 +952,6 @@ struct SplitK {
 // Slabs are stored WRITE-THROUGH (sc1): the data goes to memory without a release fence.  A release
 // (buffer_wbl2) writes back every dirty line of the XCD's L2 -- with hundreds of slices arriving per launch, each
 // behind its own release, the split schedule ran SLOWER the more slices there were (B = 8: S = 2 5.1 ms, S = 8 9.0 ms).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void slab_dump(const f32x16 (&acc)[4], float* __restrict__ slab) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, TS * TS * 4, 0x00020000);
 #pragma unroll
@@ -977,7 +1114,7 @@ __global__ __launch_bounds__(256, 2) void factor_step_split_kernel(float* __rest
 __global__ __launch_bounds__(256, 2) void tune_diag_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                           int* __restrict__ info, int Np, int k, long long* stamps) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    diag_body<true>(A, Winv, info, Np, k, blockIdx.x, smem, stamps + 16 * blockIdx.x);
+    diag_body<true>(A, Winv, info, Np, k, blockIdx.x, smem, stamps + 32 * blockIdx.x);
 }
 
 // Clears the first word of every W block: it is the "ready" flag of the block (diag_body / panel_body).
@@ -1115,10 +1252,12 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
         const int kk = k < n ? k : n - 1;
         const double blocks = (double)B * ((double)(n - kk - 1) * kk + 0.5 * kk * (kk - 1) + kk);   // panel + trtri + look-ahead
         int L = (int)(blocks / (double)g.o.sk.S + 0.999);
-        if (L < 2) L = 2;
+        static const int minl = getenv("VOLT_SPLITK_MINL") ? atoi(getenv("VOLT_SPLITK_MINL")) : 2;
+        if (L < minl) L = minl;
         int S = (kk + L - 1) / L;
         if (S < 1) S = 1;
-        if (S > 8) S = 8;
+        static const int maxs = getenv("VOLT_SPLITK_MAXS") ? atoi(getenv("VOLT_SPLITK_MAXS")) : 8;
+        if (S > maxs) S = maxs;
         if (S * B > g.o.sk.cap) S = g.o.sk.cap / B;
         if (S < 1) S = 1;
         SplitK sk = g.o.sk;
