@@ -159,6 +159,12 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
  * update (var 1) of block column k `reps` times on an already factored A; results are garbage, only the timing
  * matters. */
 int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream);
+/* Host only (no GPU): the balanced schedule of launch k (k == n: the trailing trtri launch) of a factorisation of B
+ * matrices with n block columns, as volt_potrf / the MLL step build it for mid-size batches (csrc/sched.h).  items
+ * [max_items][4] int32 in grid order (kind | b << 3; block index; sl | nsl << 8 | tile << 16; b0 | b1 << 16), loads [G]
+ * the load of each of G slots under greedy list scheduling of that order, in K-block units.  Returns the item count,
+ * -1 bad argument, -2 max_items too small. */
+int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac, int* items, int max_items, float* loads);
 /* The diagonal-block kernel alone on block column k of B (unfactored) matrices, with s_memtime stamps of its
  * phases: stamps [B,32] int64 (load, factor32 x4 with panel / trailing updates, L out, inverse, W out, publish). */
 int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);

@@ -13,7 +13,7 @@ for f in glob.glob("gpurun_out/kt_small/*kernel_trace.csv") + glob.glob("gpurun_
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").replace("volt::", ""), int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if "factor_step_split" in r[2]]
+idx = [i for i, r in enumerate(rows) if "factor_step_s" in r[2]]
 # the last timed step: from the kernel after the 34th-from-last split launch's predecessor up to the next non-step kernel
 last = idx[-33]
 lo = last

@@ -267,6 +267,29 @@ def test_small_batch_split_schedules(ops, B, n):
     assert torch.equal(out, out2) and torch.equal(alpha, alpha2)
 
 
+@pytest.mark.parametrize("B,n", [(9, 3072), (12, 2900), (8, 4096)])
+def test_mid_batch_balanced_schedule(ops, B, n):
+    """8 <= B < 32: the late block columns (from 20 of 24 / 16 of 23 / 20 of 32 here) run the host-balanced schedule of
+    csrc/sched.h -- K-slices dealt out longest first, one group up to B = 9 and two groups on two streams from 10 on --
+    after plain launches for the early ones.  Same contract as the split schedules: fp64 oracle, bitwise repeatable."""
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    s2 = torch.full((B,), SIG2, device="cuda")
+    out, alpha, info = ops.mll_step(K, dev(y - mean), s2)
+    out, alpha = out.clone(), alpha.clone()
+    assert int(info.abs().sum()) == 0
+    rows = [0, B // 2, B - 1]                                   # both groups when there are two
+    _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out.cpu().numpy(), alpha.cpu().numpy(), rows)
+    out2, alpha2, _ = ops.mll_step(K, dev(y - mean), s2)
+    assert torch.equal(out, out2) and torch.equal(alpha, alpha2)
+    # a non-PD member is reported with its pivot, and only it
+    Kb = K.clone()
+    Kb[1, 2500, 2500] = -50.0
+    _, _, info = ops.mll_step(Kb, dev(y - mean), s2)
+    info = info.cpu().numpy()
+    assert info[1] == 2501 and (np.delete(info, 1) == 0).all()
+
+
 def test_one_launch_trsv_oversubscribed(ops):
     """64 matrices x 32 blocks = 2048 chained workgroups on 512 resident slots: the ticket order is what guarantees
     progress.  Forward-only MLL (potrf + TRSV on the group streams) against the gradient path, and explicit solves."""
