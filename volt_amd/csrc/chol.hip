@@ -1313,8 +1313,10 @@ static const SchedDev* get_sched(int B, int n, bool has_y, const SchedParams& p,
     sd->pad_lds = 16 * 1024;                                 // 72 KB static + 16 KB: one workgroup per 160 KB CU
     // measured (N = 4096): below these block columns the plain launch is as fast or faster -- a cut tile pays ~25 us for
     // its slabs, and only the late launches (long trtri rows, k + 2 blocks against a mean of ~k / 2) are unbalanced enough
+    // (ms/step at N = 4096 by first scheduled column, B = 3: 8 2.58, 12 2.57, 16 2.60; B = 6: 12 3.66, 16 3.64, 20 3.70;
+    // B = 8: 16 4.03, 20 3.97; two groups of B / 2: 16)
     static const int kmin_env = getenv("VOLT_SCHED_KMIN") ? atoi(getenv("VOLT_SCHED_KMIN")) : -1;
-    sd->kmin = kmin_env >= 0 ? kmin_env : (p.G >= 256 ? 20 : 16);
+    sd->kmin = kmin_env >= 0 ? kmin_env : (p.G < 256 ? 16 : B <= 4 ? 12 : B <= 7 ? 16 : 20);
     const int launches = has_y ? n + 1 : n;
     for (int k = 0; k < launches; ++k) {
         sd->item_off.push_back((int)items.size());
@@ -1507,11 +1509,12 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
         G = split_groups;
         o1.sk.S = target / G;
     }
-    // Mid-size batches (8 <= B < 32): the late block columns run the host-balanced schedule (sched.h), one group up to
-    // B = 9, two groups on two streams from 10 on; the early columns the plain launch.  Measured, N = 4096, ms/step
-    // before -> after: B = 8 4.60 -> 3.97, 12 5.90 -> 5.43, 20 8.79 -> 8.02, 24 9.99 -> 9.20, 28 11.08 -> 10.46 (16: no change).
+    // 3 <= B < 32: the late block columns run the host-balanced schedule (sched.h), one group up to B = 9, two groups on
+    // two streams from 10 on; the early columns the plain launch.  Measured, N = 4096, ms/step before -> after: B = 3
+    // 2.90 -> 2.57, 4 3.24 -> 3.00, 6 4.21 -> 3.64, 7 4.76 -> 3.83, 8 4.60 -> 3.97, 12 5.90 -> 5.43, 20 8.79 -> 8.02,
+    // 24 9.99 -> 9.20, 28 11.08 -> 10.46 (16: no change).  B = 1, 2 stay on the all-split schedule below.
     static const int sched_on = getenv("VOLT_SCHED") ? atoi(getenv("VOLT_SCHED")) : 1;
-    static const int sched_minb = getenv("VOLT_SCHED_MINB") ? atoi(getenv("VOLT_SCHED_MINB")) : 8;
+    static const int sched_minb = getenv("VOLT_SCHED_MINB") ? atoi(getenv("VOLT_SCHED_MINB")) : 3;
     static const int sched_maxb = getenv("VOLT_SCHED_MAXB") ? atoi(getenv("VOLT_SCHED_MAXB")) : 31;
     if (can_split && sched_on && B >= sched_minb && B <= sched_maxb) {
         static const int sg = getenv("VOLT_SCHED_G") ? atoi(getenv("VOLT_SCHED_G")) : 256;
@@ -1523,7 +1526,11 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
         sp.G = sg / Gs;
         sp.S = std::max(1, std::min(ss, o.sk.cap / B));      // the groups share the slab: cap / Gs rows for B / Gs matrices
         sp.frac = sf;
-        if (const SchedDev* sd = get_sched(B / Gs, n, o.Y != nullptr, sp, s)) {
+        const SchedDev* sd = get_sched(B / Gs, n, o.Y != nullptr, sp, s);
+        // short matrices never reach the scheduled columns; below 8 matrices the alternative is the all-split schedule,
+        // which is the better one while most columns are early ones (B = 4, n = 16: 0.92 ms all-split, 1.04 hybrid)
+        if (sd && n > sd->kmin + (B < 8 ? 7 : 1)) {
+            // (the early columns as all-split launches instead of plain ones were measured too: no better, B = 7 4.13 vs 3.82)
             G = Gs;
             o1.sk.S = 2;                                     // > 1: the counters are cleared below, the slab is shared out
             o1.sched = sd;
