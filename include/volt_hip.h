@@ -159,6 +159,15 @@ int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const floa
  * update (var 1) of block column k `reps` times on an already factored A; results are garbage, only the timing
  * matters. */
 int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream);
+/* One-launch Adam step over a list of fp32 parameter tensors (train_utils.py:43,100,166,238,291 build
+ * torch.optim.Adam(lr=0.1); same arithmetic, amsgrad off, no weight decay).  slots: DEVICE array of nslots records
+ * {float* p; float* m; float* v; int64 end} (end = one past the tensor's last element in the flattened index space,
+ * ascending); total = the last end; grad [total]: the gradients flattened in slot order.  state: 2 DEVICE ints {step
+ * count t, arrival ticket}, zero before the first step; t is read and advanced on the device, so the launch can be
+ * replayed from a graph. */
+int volt_adam_step_f32(const void* slots, int nslots, long long total, const float* grad, float lr, float beta1, float beta2,
+                       float eps, int* state, void* stream);
+
 /* Host only (no GPU): the balanced schedule of launch k (k == n: the trailing trtri launch) of a factorisation of B
  * matrices with n block columns, as volt_potrf / the MLL step build it for mid-size batches (csrc/sched.h).  items
  * [max_items][4] int32 in grid order (kind | b << 3; block index; sl | nsl << 8 | tile << 16; b0 | b1 << 16), loads [G]

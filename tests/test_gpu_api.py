@@ -496,3 +496,50 @@ def test_batched_wind_driver_writes_reference_layout(va, tmp_path):
     assert sorted(p.name for p in (tmp_path / "stn1").iterdir()) == sorted(want)
     saved = torch.load(tmp_path / "stn2" / want[-1])
     assert tuple(saved.shape) == (S, H) and torch.equal(saved, out[2])
+
+
+def test_fused_adam_matches_torch_adam():
+    """optim.FusedAdam (two launches per step, device-side step count) against torch.optim.Adam(lr=0.1) -- the optimiser
+    every training loop of the reference builds (train_utils.py:43,100,166,238,291): same trajectory over 30 steps on
+    parameters of the shapes those loops have (scalars, a vector, a 300 x 300 matrix), eagerly and replayed from a graph."""
+    from volt_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(1,), (), (300,), (300, 300), (1, 1)]
+    target = [torch.randn(s, device="cuda") for s in shapes]
+
+    def make():
+        torch.manual_seed(4)
+        return [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+
+    def loss_of(ps):
+        return sum(((p - t) ** 2 * (1.0 + 0.1 * i)).sum() for i, (p, t) in enumerate(zip(ps, target)))
+
+    pa, pb, pc = make(), make(), make()
+    oa, ob, oc = torch.optim.Adam(pa, lr=0.1), FusedAdam(pb, lr=0.1), FusedAdam(pc, lr=0.1)
+    for _ in range(30):
+        for ps, o in ((pa, oa), (pb, ob)):
+            o.zero_grad()
+            loss_of(ps).backward()
+            o.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-6), float((a - b).abs().max())
+    # graph: 3 eager steps, then one captured step replayed 27 times
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            oc.zero_grad(set_to_none=True)
+            loss_of(pc).backward()
+            oc.step()
+    torch.cuda.current_stream().wait_stream(side)
+    oc.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss_of(pc).backward()
+        oc.step()
+    for _ in range(27):
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(oc._state[0]) == 30
+    for a, c in zip(pa, pc):
+        assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), float((a - c).abs().max())

@@ -37,6 +37,7 @@ _SIGS = {
     "volt_profile_factor_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr,
                                           _ptr, _ptr]),
     "volt_tune_update_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "volt_adam_step_f32": (C.c_int, [_ptr, _i32, C.c_longlong, _ptr, C.c_float, C.c_float, C.c_float, C.c_float, _ptr, _ptr]),
     "volt_sched_describe": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _ptr, _i32, _ptr]),
     "volt_tune_diag_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr]),
     "volt_mll_workspace_bytes": (_sz, [_i32, _i32, _i32]),

@@ -1172,10 +1172,14 @@ __global__ __launch_bounds__(256, 2) void tune_diag_kernel(float* __restrict__ A
     diag_body<true>(A, Winv, info, Np, k, blockIdx.x, smem, stamps + 32 * blockIdx.x);
 }
 
-// Clears the first word of every W block: it is the "ready" flag of the block (diag_body / panel_body).
-__global__ void clear_w_flags_kernel(float* __restrict__ Winv, int count) {
+// What a factorisation needs cleared, in ONE launch: the first word of every W block (the "ready" flag of the block:
+// diag_body / tri_tile_run), info, and the arrival counters of the split / scheduled launches when there are any.
+__global__ void begin_factor_kernel(float* __restrict__ Winv, int nflags, int* __restrict__ info, int ninfo,
+                                    int* __restrict__ count, int ncount) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) reinterpret_cast<int*>(Winv)[(int64_t)i * TS * TS] = 0;
+    if (i < nflags) reinterpret_cast<int*>(Winv)[(int64_t)i * TS * TS] = 0;
+    if (i < ninfo) info[i] = 0;
+    for (int c = i; c < ncount; c += gridDim.x * blockDim.x) count[c] = 0;
 }
 
 // Panel tiles alone (tuning hook: replayed on a finished factor -- W_k is there, the results are garbage)
@@ -1424,13 +1428,11 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
 
 // info = 0 and every W block's ready flag cleared, on the caller's stream before anything forks from it
 static int begin_factor(float* Winv, int* info, int B, int n, hipStream_t s, int* sk_count = nullptr) {
-    hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
-    if (e != hipSuccess) return (int)e;
-    if (sk_count) {                                          // split-K arrival counters: [n+1 launches][B (n+1) tiles]
-        e = hipMemsetAsync(sk_count, 0, sizeof(int) * (size_t)(n + 1) * (n + 1) * B, s);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(clear_w_flags_kernel, dim3((B * n + 255) / 256), dim3(256), 0, s, Winv, B * n);
+    const int nflags = B * n, ncount = sk_count ? (n + 1) * (n + 1) * B : 0;   // counters: [n+1 launches][B (n+1) tiles]
+    int blocks = (std::max(std::max(nflags, B), ncount) + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks * 256 < std::max(nflags, B)) blocks = (std::max(nflags, B) + 255) / 256;
+    hipLaunchKernelGGL(begin_factor_kernel, dim3(blocks), dim3(256), 0, s, Winv, nflags, info, B, sk_count, ncount);
     return 0;
 }
 

@@ -79,14 +79,18 @@ class deferred_checks:
         return False
 
     def note(self, info):
-        if self.bad is None:
-            self.bad = torch.zeros((), dtype=torch.int64, device=info.device)
-        self.bad.add_((info != 0).sum())
+        # one launch per step: OR the info words together per matrix (non-zero once any step failed)
+        flat = info.reshape(-1)
+        if self.bad is None or self.bad.shape != flat.shape:
+            self.bad = torch.zeros_like(flat)
+        self.bad.bitwise_or_(flat)
 
     def raise_if_bad(self):
-        if self.bad is not None and int(self.bad.item()) != 0:
-            raise NotPSDError(f"{int(self.bad.item())} factorisations inside the captured loop were not positive definite; "
-                              "rerun with graph=False to get gpytorch's jitter-retry behaviour")
+        if self.bad is not None:
+            nbad = int((self.bad != 0).sum().item())
+            if nbad:
+                raise NotPSDError(f"{nbad} matrices failed a factorisation inside the captured loop (not positive definite); "
+                                  "rerun with graph=False to get gpytorch's jitter-retry behaviour")
 
 
 class NanError(RuntimeError):

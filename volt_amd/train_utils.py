@@ -12,6 +12,8 @@ d mll / d K from the HIP step, kernel derivatives by autograd).
 in Python (experiments/stocks/ForecastGenerator.py:27-41): B independent series in one batched
 step, optionally sharded over ranks with one all-reduce of the summed loss.
 """
+import os
+
 import torch
 
 from . import gp
@@ -19,8 +21,12 @@ from .gp import ExactMarginalLogLikelihood, GaussianLikelihood
 
 
 def _adam(params, lr, graph):
-    """torch.optim.Adam as the reference builds it; `capturable` keeps the step counter on the device so that the
-    update can be recorded into a hipGraph (same arithmetic)."""
+    """torch.optim.Adam as the reference builds it (eager loops); for the graph-captured loops the same update as two
+    launches with the step count on the device (optim.FusedAdam: torch's capturable Adam is 13 launches per step and
+    the iteration is launch-bound).  VOLT_TORCH_ADAM=1 keeps torch's in both."""
+    if graph and not os.environ.get("VOLT_TORCH_ADAM"):
+        from .optim import FusedAdam
+        return FusedAdam(params, lr=lr)
     return torch.optim.Adam(params, lr=lr, capturable=bool(graph))
 
 
