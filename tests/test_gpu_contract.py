@@ -252,9 +252,10 @@ def test_one_launch_trsv_f32_large(ops, B, n):
 
 @pytest.mark.parametrize("B,n", [(3, 1500), (12, 1100), (5, 4096)])
 def test_small_batch_split_schedules(ops, B, n):
-    """Small batches cut every long product into K-slices (B < 8 on one stream, 10 <= B < 16 as two split groups): the
-    result agrees with the fp64 oracle, and -- the slabs are summed in slice order whoever arrives last -- two runs are
-    bitwise identical."""
+    """Small batches cut every long product into K-slices (B = 1, 2 throughout; B = 3..7 at these sizes too: 12 and 9 block
+    columns never reach the scheduled ones; B = 5 at N = 4096 runs plain launches up to column 15 and the balanced
+    schedule of csrc/sched.h from 16 on): the result agrees with the fp64 oracle, and -- the slabs are summed in slice
+    order whoever arrives last -- two runs are bitwise identical."""
     x, vol, y, mean = _series_problem(B, n)
     K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
     s2 = torch.full((B,), SIG2, device="cuda")
@@ -282,6 +283,10 @@ def test_mid_batch_balanced_schedule(ops, B, n):
     _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out.cpu().numpy(), alpha.cpu().numpy(), rows)
     out2, alpha2, _ = ops.mll_step(K, dev(y - mean), s2)
     assert torch.equal(out, out2) and torch.equal(alpha, alpha2)
+    # forward only (no triangular inverse: the scheduled launches carry panel tiles and look-ahead alone)
+    outf, _, infof = ops.mll_step(K, dev(y - mean), s2, want_grad=False)           # (alpha needs the inverse)
+    assert int(infof.abs().sum()) == 0
+    assert float((outf[:, 0] / out[:, 0] - 1).abs().max()) < 2e-6
     # a non-PD member is reported with its pivot, and only it
     Kb = K.clone()
     Kb[1, 2500, 2500] = -50.0
