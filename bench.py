@@ -223,10 +223,15 @@ def main():
         L_ = _lib.lib()
         legs = () if args.no_aux_legs else ("chol", "fwd")
 
+        pws_bytes = int(L_.volt_potrf_workspace_bytes(B, Np))   # scratch of the late-column schedule (what ops.potrf passes)
+        pws = torch.empty(pws_bytes + 256, dtype=torch.uint8, device=dev) if pws_bytes else None
+        pws_ptr = ((pws.data_ptr() + 255) // 256) * 256 if pws is not None else None
+
         def potrf_once():
             _lib.check(L_.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n,
                                            _lib.stream_ptr()), "prepare")
-            _lib.check(L_.volt_potrf_f32(A.data_ptr(), Winv.data_ptr(), inf.data_ptr(), B, Np, _lib.stream_ptr()), "potrf")
+            _lib.check(L_.volt_potrf_ws_f32(A.data_ptr(), Winv.data_ptr(), inf.data_ptr(), B, Np, pws_ptr, pws_bytes,
+                                            _lib.stream_ptr()), "potrf")
 
         def fwd_once():
             _lib.check(L_.volt_mll_step_f32(K.data_ptr(), n, n * n, y.data_ptr(), s2.data_ptr(), 0.0, ws.out.data_ptr(),
@@ -251,7 +256,7 @@ def main():
             extra["ms_per_mll_forward"] = round(res["fwd"] / B, 4)
         extra["cholesky_note"] = ("ms_per_cholesky = wall time of one batched factorisation of K + s2 I (copy-in + blocked "
                                   "Cholesky, N^3/3 flop each) / 64; ms_per_mll_forward adds the forward solve and log-det")
-        del A, Winv, Y, f
+        del A, Winv, Y, f, pws
 
     # ---- rollouts leg (rank 0): BASELINE config 5's per-GPU share -- 8 series x 10,000 paths x 256 steps at this N
     roll = None

@@ -89,6 +89,12 @@ int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
  * expected).  Diagonal tiles come back with their strict upper triangle zeroed; tiles above the diagonal are
  * never touched. */
 int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream);
+/* The same with caller scratch (256-byte aligned, volt_potrf_workspace_bytes(B, Np) bytes; 0 for B >= 32): fewer than 32
+ * matrices do not fill the chip with whole tiles, and with the scratch the long products of a launch are cut into
+ * K-slices (csrc/chol.hip: split-K below 3 matrices, the balanced schedule of csrc/sched.h for the late block columns
+ * of 3..31) -- one 4096^2 matrix 4.4 -> 1.3 ms.  ws == NULL is volt_potrf_f32. */
+size_t volt_potrf_workspace_bytes(int B, int Np);
+int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream);
 
 /* fp64 twins on v_mfma_f64_16x16x4_f64 (the reference keeps the caller's dtype, VolKernel.py:28-33; the
  * noise-free train block of rollout_utils.py:35 has condition number 1e6 (N = 400) .. 1e8 (N = 4096), beyond

@@ -295,6 +295,42 @@ def test_mid_batch_balanced_schedule(ops, B, n):
     assert info[1] == 2501 and (np.delete(info, 1) == 0).all()
 
 
+@pytest.mark.parametrize("B,n", [(1, 4096), (5, 3072), (12, 2900), (33, 2176), (64, 3072)])
+def test_potrf_with_scratch_small_and_late_column_schedules(ops, B, n):
+    """ops.potrf hands volt_potrf_ws_f32 its scratch: the factorisation ALONE then runs the split-K schedule (B < 3), the
+    balanced schedule for its late block columns (3 <= B <= 64: without trtri rows even 64 matrices leave CUs idle
+    there) -- same factor as LAPACK in fp64 to fp32 accuracy, bitwise repeatable, and equal to the scratch-free call
+    to rounding."""
+    from volt_amd import _lib
+    x, vol, _, _ = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    s2 = torch.full((B,), SIG2, device="cuda")
+    f = ops.potrf(K, s2)
+    assert int(f.info.abs().sum()) == 0
+    L1 = f.L.clone()
+    for b in (0, B - 1):
+        ref = torch.linalg.cholesky(K[b].double() + SIG2 * torch.eye(n, device="cuda", dtype=torch.float64))
+        assert float((L1[b].double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert torch.equal(ops.potrf(K, s2).L, L1)
+    # the scratch-free entry point on the same input
+    Np = ops.padded_n(n)
+    A = torch.empty(B, Np, Np, device="cuda")
+    W = torch.empty(B, Np // 128, 128, 128, device="cuda")
+    info = torch.empty(B, dtype=torch.int32, device="cuda")
+    lib = _lib.lib()
+    _lib.check(lib.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n, _lib.stream_ptr()), "prepare")
+    _lib.check(lib.volt_potrf_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, _lib.stream_ptr()), "potrf")
+    L0 = torch.tril(A[:, :n, :n])
+    assert float((L0 - L1).abs().max()) < 6e-5 * float(L1.abs().max())       # two fp32 summation orders, each 2e-5 from fp64
+    # bad scratch arguments
+    need = int(lib.volt_potrf_workspace_bytes(B, Np))
+    assert need > 0
+    ws = torch.empty(need + 512, dtype=torch.uint8, device="cuda")
+    base = ((ws.data_ptr() + 255) // 256) * 256
+    assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base + 4, need, _lib.stream_ptr()) == -6
+    assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need - 1, _lib.stream_ptr()) == -7
+
+
 def test_one_launch_trsv_oversubscribed(ops):
     """64 matrices x 32 blocks = 2048 chained workgroups on 512 resident slots: the ticket order is what guarantees
     progress.  Forward-only MLL (potrf + TRSV on the group streams) against the gradient path, and explicit solves."""

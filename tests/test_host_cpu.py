@@ -32,6 +32,10 @@ def test_argument_validation_without_a_device():
     assert L.volt_fill_f32(None, None, 1, 8, 8, 64, None) == -1
     assert L.volt_cumtrapz_f32(1, 8, 1, 0, 1, 1, 1, 1, None) == -7            # N < 2: x[1]-x[0] undefined
     assert L.volt_potrf_f32(1, 1, 1, 1, 100, None) == -5                      # Np not a multiple of 128
+    assert L.volt_potrf_ws_f32(1, 1, 1, 1, 100, None, 0, None) == -5
+    assert L.volt_potrf_workspace_bytes(65, 4096) == 0 and L.volt_potrf_workspace_bytes(1, 100) == 0
+    assert L.volt_potrf_workspace_bytes(8, 4096) == 64 * 33 * 65536 + (33 * 33 * 8 * 4 + 255) // 256 * 256    # slab rows + counters
+    assert L.volt_potrf_workspace_bytes(64, 4096) > 128 * 33 * 65536
     assert L.volt_mll_workspace_bytes(64, 4096, 1) > L.volt_mll_workspace_bytes(64, 4096, 0) > 0
     assert L.volt_rollout_scratch_bytes(2, 3, 4) == 2 * 3 * 16 * 4
     with pytest.raises(_lib.VoltHipError):

@@ -1320,7 +1320,9 @@ static const SchedDev* get_sched(int B, int n, bool has_y, const SchedParams& p,
     // (ms/step at N = 4096 by first scheduled column, B = 3: 8 2.58, 12 2.57, 16 2.60; B = 6: 12 3.66, 16 3.64, 20 3.70;
     // B = 8: 16 4.03, 20 3.97; two groups of B / 2: 16)
     static const int kmin_env = getenv("VOLT_SCHED_KMIN") ? atoi(getenv("VOLT_SCHED_KMIN")) : -1;
-    sd->kmin = kmin_env >= 0 ? kmin_env : (p.G < 256 ? 16 : B <= 4 ? 12 : B <= 7 ? 16 : 20);
+    // the factorisation alone (no trtri rows; per-call ms at N = 4096 by first scheduled column, B = 16: 12 3.95, 16 4.04,
+    // 20 4.28, off 4.82; B = 32: 12 6.60, 20 6.64, off 7.93; B = 64: 12 12.48, 20 12.21, 24 12.22, off 12.87)
+    sd->kmin = kmin_env >= 0 ? kmin_env : !has_y ? (B * (256 / p.G) >= 48 ? 20 : 12) : (p.G < 256 ? 16 : B <= 4 ? 12 : B <= 7 ? 16 : 20);
     const int launches = has_y ? n + 1 : n;
     for (int k = 0; k < launches; ++k) {
         sd->item_off.push_back((int)items.size());
@@ -1518,7 +1520,8 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     static const int sched_on = getenv("VOLT_SCHED") ? atoi(getenv("VOLT_SCHED")) : 1;
     static const int sched_minb = getenv("VOLT_SCHED_MINB") ? atoi(getenv("VOLT_SCHED_MINB")) : 3;
     static const int sched_maxb = getenv("VOLT_SCHED_MAXB") ? atoi(getenv("VOLT_SCHED_MAXB")) : 31;
-    if (can_split && sched_on && B >= sched_minb && B <= sched_maxb) {
+    static const int sched_maxb_potrf = getenv("VOLT_SCHED_MAXB_POTRF") ? atoi(getenv("VOLT_SCHED_MAXB_POTRF")) : 64;
+    if (can_split && sched_on && B >= sched_minb && B <= (o.Y ? sched_maxb : sched_maxb_potrf)) {
         static const int sg = getenv("VOLT_SCHED_G") ? atoi(getenv("VOLT_SCHED_G")) : 256;
         static const int ss = getenv("VOLT_SCHED_S") ? atoi(getenv("VOLT_SCHED_S")) : 4;
         static const float sf = getenv("VOLT_SCHED_FRAC") ? (float)atof(getenv("VOLT_SCHED_FRAC")) : 0.6f;
@@ -1557,9 +1560,9 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
         FactorOpts og = o1;
         const int b0 = g * Bg;
         if (og.sk.S > 1) {                                   // each group its own share of the slab and of the counters
-            og.sk.slab += (int64_t)g * (VOLT_SPLITK_SLABS / G) * (n + 1) * TS * TS;
+            og.sk.slab += (int64_t)g * (o.sk.cap / G) * (n + 1) * TS * TS;
             og.sk.count += (int64_t)g * (n + 1) * (n + 1) * Bg;
-            og.sk.cap = VOLT_SPLITK_SLABS / G;
+            og.sk.cap = o.sk.cap / G;
         }
         if (og.src.K) {
             og.src.K += (int64_t)b0 * og.src.bsk;
@@ -1611,12 +1614,12 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count) {
+                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows) {
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
     // block column 0 (its diagonal tile is factored straight out of A) is copied; everything else is read from K
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
-    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}, SplitK{sk_slab, sk_count, 1, 1, VOLT_SPLITK_SLABS}};
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}, SplitK{sk_slab, sk_count, 1, 1, sk_rows}};
     return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
 }
 
@@ -1688,16 +1691,44 @@ int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, l
     return 0;
 }
 
-int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream) {
+// Scratch of the factorisation alone: slab rows (of n + 1 tiles each) and arrival counters.  Without the trtri rows a
+// launch has only B (n - k + 1) tiles, so even 64 matrices leave CUs idle in the late block columns: up to 31 matrices
+// get the 64 rows the MLL step's workspace has, 32..64 get 128 (two slices per tile for 64 matrices).
+static int potrf_ws_rows(int B) { return B < 32 ? VOLT_SPLITK_SLABS : (B <= 64 ? 2 * VOLT_SPLITK_SLABS : 0); }
+static size_t potrf_ws_slab_bytes(int B, int Np) {
+    return (((size_t)potrf_ws_rows(B) * (Np / TS + 1) * TS * TS * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+size_t volt_potrf_workspace_bytes(int B, int Np) {
+    if (B < 1 || potrf_ws_rows(B) == 0 || Np < TS || Np % TS) return 0;   // more than 64 matrices fill the chip with whole tiles
+    const size_t n = (size_t)Np / TS;
+    return potrf_ws_slab_bytes(B, Np) + ((((n + 1) * (n + 1) * B * sizeof(int)) + 255) & ~(size_t)255);
+}
+
+int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {
     if (!A) return -1;
     if (!Winv) return -2;
     if (!info) return -3;
     if (B < 0) return -4;
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
-    FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0},
-                 SplitK{nullptr, nullptr, 1, 1, 0}};
+    SplitK sk{nullptr, nullptr, 1, 1, 0};
+    const size_t need = volt_potrf_workspace_bytes(B, Np);
+    if (ws) {
+        if (((uintptr_t)ws & 255) != 0) return -6;
+        if (ws_bytes < need) return -7;
+        if (need) {                                              // K-slices and the balanced schedule
+            sk.slab = reinterpret_cast<float*>(ws);
+            sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
+            sk.cap = potrf_ws_rows(B);
+        }
+    }
+    FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}, sk};
     return run_factor_groups(A, Winv, info, B, Np, (hipStream_t)stream, o);
+}
+
+int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream) {
+    return volt_potrf_ws_f32(A, Winv, info, B, Np, nullptr, 0, stream);
 }
 
 int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv,

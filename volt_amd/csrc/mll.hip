@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
 
 struct MllWs {
     float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob, *sk_slab;
+    int sk_rows;
     int* sk_count;
     size_t bytes;
 };
@@ -142,9 +143,12 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
     } else {
         w.Y = w.zpart = w.frob = nullptr;
     }
-    // split-K scratch of the small-batch schedule (chol.hip): 64 (n+1) tile-slabs + arrival counters
-    if (B < 32) {
-        w.sk_slab = take((size_t)64 * (n + 1) * TS * TS);
+    // scratch of the small-batch / balanced schedules (chol.hip): slab rows of (n+1) tiles + arrival counters.  64 rows
+    // below 32 matrices; the forward-only step has no trtri rows to fill the late launches with, so it gets 128 rows up to
+    // 64 matrices (two slices per tile at 64)
+    w.sk_rows = B < 32 ? 64 : (!want_grad && B <= 64 ? 128 : 0);
+    if (w.sk_rows) {
+        w.sk_slab = take((size_t)w.sk_rows * (n + 1) * TS * TS);
         w.sk_count = reinterpret_cast<int*>(take((size_t)(n + 1) * (n + 1) * B));
     } else {
         w.sk_slab = nullptr;
@@ -164,7 +168,7 @@ using namespace volt;
 typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count);
+                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows);
 
 namespace {
 struct TailCtx {
@@ -230,7 +234,7 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
                                    want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx, w.sk_slab,
-                                   w.sk_count)))
+                                   w.sk_count, w.sk_rows)))
         return rc > 0 ? rc : -1;
     VOLT_LAUNCH_CHECK();
     return 0;

@@ -115,11 +115,17 @@ def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0
         s2 = sigma2.to(K.dtype).expand(B).contiguous()
     L = _lib.lib()
     st = _lib.stream_ptr()
-    prep, fac = ((L.volt_prepare_f32, L.volt_potrf_f32) if K.dtype == torch.float32
-                 else (L.volt_prepare_f64, L.volt_potrf_f64))
+    prep = L.volt_prepare_f32 if K.dtype == torch.float32 else L.volt_prepare_f64
     _lib.check(prep(K.data_ptr(), K.stride(1), K.stride(0), s2.data_ptr() if s2 is not None else None,
                     float(jitter), A.data_ptr(), B, n, st), "volt_prepare")
-    _lib.check(fac(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
+    if K.dtype == torch.float32:
+        # scratch for the small-batch schedules (0 bytes from 32 matrices on); the caller owns it, the call does not retain it
+        nbytes = int(L.volt_potrf_workspace_bytes(B, Np))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=K.device) if nbytes else None
+        wp = ((ws.data_ptr() + 255) // 256) * 256 if ws is not None else None
+        _lib.check(L.volt_potrf_ws_f32(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, wp, nbytes, st), "volt_potrf")
+    else:
+        _lib.check(L.volt_potrf_f64(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
     return CholeskyFactor(A, Winv, info, n)
 
 
