@@ -17,15 +17,12 @@ for i, v in enumerate(sys.argv[1:]):
     rows = []
     for f in glob.glob(f"gpurun_out/kts_{i}/*kernel_trace.csv") + glob.glob(f"gpurun_out/kts_{i}/*/*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
-            if "factor_step" in r["Kernel_Name"]:
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    for tag in ("sched", "split"):                 # the MLL step's own launches (bench.py's profile leg at the end runs unsplit)
-        if any(tag in r[2] for r in rows):
-            rows = [r for r in rows if tag in r[2]]
-            break
-    # launches per factorisation: 33 (32 columns + trailing trtri row); take the last complete one on the main pattern
-    last = rows[-33:]
+    # the last TIMED step ends with its mll_scalars_kernel (bench.py's roofline leg, which runs behind it, has none):
+    # the 33 factorisation launches in front of that one (32 columns + the trailing trtri row), whatever kernel each is
+    end = max(i for i, r in enumerate(rows) if "mll_scalars" in r[2])
+    last = [r for r in rows[:end] if "factor_step" in r[2]][-33:]
     cols.append([(e - s) / 1e3 for s, e, _ in last])
 print("k    " + "  ".join(f"{v[:22]:>22s}" for v in sys.argv[1:]))
 for k in range(33):
