@@ -71,14 +71,22 @@ inline void sched_build_launch(int B, int n, bool has_y, int k, const SchedParam
     for (const Tile& t : tiles) total += t.kb + t.tail;
     const float mean = (float)(total / p.G);
     const int lmax = std::max(p.min_len, (int)std::ceil(p.frac * mean));
-    for (const Tile& t : tiles) {
-        int nsl = (t.kb + lmax - 1) / lmax;
+    // `tiles` holds B consecutive entries per tile position (same kind, index and length, b = 0 .. B-1).  The slices of
+    // a position go out slice by slice with b innermost, so that B consecutive workgroups are the B matrices' copies of one
+    // piece: the dispatcher puts workgroup w on XCD w % 8, and with B a multiple of 8 every XCD then keeps working on
+    // the same matrices (their shared block row stays in ITS L2) -- as decode_tile_batch arranges for the plain launches.
+    for (size_t c0 = 0; c0 < tiles.size(); c0 += (size_t)B) {
+        const Tile& t0 = tiles[c0];
+        int nsl = (t0.kb + lmax - 1) / lmax;
         nsl = std::max(1, std::min(nsl, p.S));
         for (int sl = 0; sl < nsl; ++sl) {
-            const int b0 = sl * t.kb / nsl, b1 = (sl + 1) * t.kb / nsl;
-            float cost = (float)(b1 - b0) + t.tail / nsl;
+            const int b0 = sl * t0.kb / nsl, b1 = (sl + 1) * t0.kb / nsl;
+            float cost = (float)(b1 - b0) + t0.tail / nsl;
             if (nsl > 1) cost += p.dump + p.dump;                // its own dump + its share of the summing
-            rest.push_back({{t.kind | t.b << 3, t.idx, sl | nsl << 8 | t.id << 16, b0 | b1 << 16}, cost});
+            for (int b = 0; b < B; ++b) {
+                const Tile& t = tiles[c0 + b];
+                rest.push_back({{t.kind | t.b << 3, t.idx, sl | nsl << 8 | t.id << 16, b0 | b1 << 16}, cost});
+            }
         }
     }
     std::stable_sort(rest.begin(), rest.end(), [](const Piece& a, const Piece& b) { return a.cost > b.cost; });
