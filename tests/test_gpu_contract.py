@@ -331,6 +331,45 @@ def test_potrf_with_scratch_small_and_late_column_schedules(ops, B, n):
     assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need - 1, _lib.stream_ptr()) == -7
 
 
+def test_two_host_threads_two_streams(ops):
+    """The header's threading contract: re-entrant across streams; calls on one device serialise on the host only while they
+    enqueue.  Two host threads, each on its own torch stream with its own workspace, run different schedules at once
+    (12 series of N = 2900: two groups on the library's auxiliary streams + the cached balanced schedule; 3 series of
+    N = 1500: all-split) -- every result bitwise equal to the same call made alone."""
+    import threading
+    cases = []
+    for B, n in ((12, 2900), (3, 1500)):
+        x, vol, y, mean = _series_problem(B, n)
+        K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+        s2 = torch.full((B,), SIG2, device="cuda")
+        r = dev(y - mean)
+        out, alpha, info = ops.mll_step(K, r, s2)
+        cases.append((K, r, s2, out.clone(), alpha.clone()))
+    torch.cuda.synchronize()
+    errs = []
+
+    def worker(idx):
+        try:
+            K, r, s2, out0, alpha0 = cases[idx]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ws = ops.MllWorkspace(K.shape[0], K.shape[1], True, K.device)
+                for _ in range(6):
+                    out, alpha, info = ops.mll_step(K, r, s2, ws=ws)
+                    st.synchronize()
+                    if not (torch.equal(out, out0) and torch.equal(alpha, alpha0) and int(info.abs().sum()) == 0):
+                        errs.append(f"case {idx}: result differs from the call made alone")
+        except Exception as e:                                   # noqa: BLE001 -- reported through the assertion below
+            errs.append(f"case {idx}: {e!r}")
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
 def test_one_launch_trsv_oversubscribed(ops):
     """64 matrices x 32 blocks = 2048 chained workgroups on 512 resident slots: the ticket order is what guarantees
     progress.  Forward-only MLL (potrf + TRSV on the group streams) against the gradient path, and explicit solves."""
