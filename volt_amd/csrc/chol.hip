@@ -1495,6 +1495,10 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     const int n = Np / TS;
     StreamPool* pool = stream_pool();
     int G = pool ? pick_groups(pool, B, force_groups) : 1;
+    // Short series: a launch of B (n + 1) tiles that does not fill the 512 workgroup slots gains nothing from sharing the
+    // chip with a second group and pays its launches twice (64 x N=399: 0.289 ms/step as one group, 0.387 as two; 64 x
+    // 1000: 0.884 / 0.926; 64 x 1400: 1.85 / 1.62; 512 x 399: 1.12 / 1.09)
+    if (force_groups == 0 && (int64_t)B * (n + 1) < 700) G = 1;
     // Small batches: cut the long products into K-slices so that a launch has ~`target` workgroups (measured, N = 4096,
     // ms/step unsplit -> split: B = 1 4.5 -> 2.0, 2 4.6 -> 2.6, 4 4.7 -> 3.4, 6 4.7 -> 4.4; from B = 8 on a launch has a
     // tile per CU and splitting on ONE stream stops paying: B = 8 stays unsplit, 4.8 ms).  10 <= B <= 20: two split groups
