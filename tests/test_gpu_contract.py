@@ -331,6 +331,30 @@ def test_potrf_with_scratch_small_and_late_column_schedules(ops, B, n):
     assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need - 1, _lib.stream_ptr()) == -7
 
 
+def test_diagonal_block_tuning_hook(ops):
+    """volt_tune_diag_f32 runs the diagonal-block kernel alone on block column 0 with phase stamps: the stamps are
+    monotone, and its L_00 / W_0 are bitwise the ones the factorisation produces (same device code)."""
+    from volt_amd import _lib
+    B, n = 3, 512
+    x, vol, _, _ = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True)) + SIG2 * torch.eye(n, device="cuda")
+    f = ops.potrf(K)
+    lib = _lib.lib()
+    A = K.clone()
+    W = torch.zeros(B, n // 128, 128, 128, device="cuda")
+    info = torch.zeros(B, dtype=torch.int32, device="cuda")
+    st = torch.zeros(B, 32, dtype=torch.int64, device="cuda")
+    _lib.check(lib.volt_tune_diag_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, n, 0, st.data_ptr(), _lib.stream_ptr()), "tune_diag")
+    torch.cuda.synchronize()
+    assert int(info.abs().sum()) == 0
+    assert torch.equal(torch.tril(A[:, :128, :128]), torch.tril(f.A[:, :128, :128]))
+    assert torch.equal(W[:, 0], f.Winv[:, 0])
+    s = st.cpu().numpy()
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 14]          # the stamps diag_body writes, in program order
+    assert (np.diff(s[:, order], axis=1) >= 0).all() and (s[:, 14] - s[:, 0] > 0).all()
+    assert lib.volt_tune_diag_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, n, 4, st.data_ptr(), _lib.stream_ptr()) == -6
+
+
 def test_two_host_threads_two_streams(ops):
     """The header's threading contract: re-entrant across streams; calls on one device serialise on the host only while they
     enqueue.  Two host threads, each on its own torch stream with its own workspace, run different schedules at once
