@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- MLL+grad steps/s at N=4096, batch=64 per GPU (BASELINE.json metric), MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1 runs one process per GPU over RCCL.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process is one
+rank; without one, `python bench.py --gpus N` starts the N ranks ITSELF (re-exec under torch.distributed.run,
+127.0.0.1 rendezvous) and fails loudly when fewer than N GPUs are visible -- it never prints an N-GPU line from
+fewer ranks (`ranks_seen` in the JSON is an all-reduce of ones).
 
 A *step* is one pass of the training-loop body of voltron/train_utils.py:243-254 over a batch of
 independent series with K (train_cov) already resident: residual y - EWMA mean -> K + sigma^2 I
 -> blocked Cholesky -> L^-T -> MLL and its gradient wrt raw_noise -> Adam update of raw_noise ->
 (N>1) one RCCL all-reduce of the summed loss/grad scalars.  Series shard across ranks, no data-path
 collective.  --scaling weak (default): 64 series per GPU; --scaling strong: 64 series in total, split
-evenly over the ranks (BASELINE.json's metric reads "N=4096, batch=64; 1/2/4/8 GPU").
+evenly over the ranks (BASELINE.json's metric reads "N=4096, batch=64; 1/2/4/8 GPU").  With N > 1 the OTHER mode is
+timed right after the headline region and reported beside it (`other_scaling`).
 
 Rank 0 prints ONE JSON line.  `value` = batch-of-64 steps per second summed over ranks, inputs
 resident in HBM.  `roofline` is for the dominant kernel (per-launch HIP events in the timed schedule);
@@ -56,6 +62,27 @@ def kernel_class_flops(B: int, Np: int):
     return [B * step, B * row(n - 1)]
 
 
+def launch_ranks(n_gpus: int, one_dev: bool) -> int:
+    """`python bench.py --gpus N` without a launcher: one process per GPU, started here the way the driver starts them
+    (torch.distributed.run, one node, 127.0.0.1 rendezvous).  Refuses when the box has fewer than N GPUs."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n_gpus and not one_dev:
+        print(f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs, this box has {ndev}; not printing an "
+              f"{n_gpus}-GPU line from fewer ranks", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,17 +99,26 @@ def main():
                          "that every factor_step_kernel<true> launch in the trace is a gradient-step launch)")
     args = ap.parse_args()
 
+    one_dev = os.environ.get("VOLT_BENCH_ONE_DEVICE") == "1"     # dry-run hook (tests): every rank on device 0 over gloo
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, one_dev))               # start the N ranks ourselves; this process only waits
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # dry-run hooks for a 1-GPU box (tests of the world > 1 code path only): all ranks on device 0 over gloo
-    if os.environ.get("VOLT_BENCH_ONE_DEVICE") == "1":
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    ndev = torch.cuda.device_count()
+    if one_dev:
         local_rank = 0
+    if ndev <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {ndev} GPU(s) are visible "
+                         f"(--gpus {args.gpus}); refusing to share a device")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -95,70 +131,106 @@ def main():
     from volt_amd import _lib, ops
     from volt_amd.synthetic import sde_batch
 
-    n, B = args.n, args.batch
-    if args.scaling == "strong":
-        if B % world:
-            raise SystemExit(f"--scaling strong: batch {B} does not divide over {world} ranks")
-        B //= world                                                  # this rank's share of the fixed total
-    x, F, vol = sde_batch(B, n, seed=2019, first=rank * B)          # this rank's shard of series
+    ranks_seen = 1
+    if dist is not None:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                    # every rank that really runs adds one
+        ranks_seen = int(ones.item())
+        if ranks_seen != world:
+            raise SystemExit(f"bench.py: {ranks_seen} ranks answered the all-reduce, {world} expected")
+
+    n = args.n
+    if args.batch % world:
+        raise SystemExit(f"batch {args.batch} does not divide over {world} ranks (needed for the strong-scaling leg)")
+    B_by_mode = {"weak": args.batch, "strong": args.batch // world}     # series per rank
+    B = B_by_mode[args.scaling]
+    Bmax = max(B_by_mode.values())
+    x, F, vol = sde_batch(Bmax, n, seed=2019, first=rank * Bmax)        # this rank's shard of series
     xd, vold = torch.tensor(x, device=dev), torch.tensor(vol, device=dev)
-    y = torch.log(torch.tensor(F[:, 1:], device=dev))
+    y_all = torch.log(torch.tensor(F[:, 1:], device=dev))
 
     # ---- fill (timed separately): K is built once per model (VoltMagpie.py:46)
     V = ops.cumtrapz(vold, xd, square=True)
-    K = ops.fill(V)
+    K_all = ops.fill(V)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     fills = []
     for _ in range(7):
         e0.record()
-        K = ops.fill(V)
+        K_all = ops.fill(V)
         e1.record()
         torch.cuda.synchronize()
         fills.append(e0.elapsed_time(e1))
     fill_ms = float(np.median(fills))
-    fill_gbs = B * n * n * 4 / (fill_ms * 1e-3) / 1e9
+    fill_gbs = Bmax * n * n * 4 / (fill_ms * 1e-3) / 1e9
 
-    raw_noise = torch.full((B,), 1e-5, device=dev, requires_grad=True)   # train_utils.py:222
-    opt = torch.optim.Adam([raw_noise], lr=0.1)                            # train_utils.py:236-238
-    ws = ops.MllWorkspace(B, n, True, dev)
-    red = torch.zeros(2, device=dev)
+    def make_step(Bs):
+        """The training-loop body over this rank's first Bs series (K resident)."""
+        Ks, ys = K_all[:Bs], y_all[:Bs]
+        raw = torch.full((Bs,), 1e-5, device=dev, requires_grad=True)    # train_utils.py:222
+        opt_ = torch.optim.Adam([raw], lr=0.1)                             # train_utils.py:236-238
+        ws_ = ops.MllWorkspace(Bs, n, True, dev)
+        red_ = torch.zeros(2, device=dev)
 
-    def step():
-        opt.zero_grad(set_to_none=False)
-        mean = ops.ewma(y, EWMA_K)[..., :-1]                    # EWMAMean.forward (EWMA.py:46-54)
-        resid = y - mean
-        with torch.no_grad():
-            sigma2 = torch.nn.functional.softplus(raw_noise) + 1e-4
-        out, alpha, info = ops.mll_step(K, resid, sigma2, ws, want_grad=True)
-        with torch.no_grad():
-            # loss = -mll ; d loss / d raw = -(d mll / d sigma2) * sigmoid(raw)
-            raw_noise.grad = -(out[:, 1] * torch.sigmoid(raw_noise))
-            red[0] = -out[:, 0].sum()
-            red[1] = raw_noise.grad.sum()
+        def step():
+            opt_.zero_grad(set_to_none=False)
+            mean = ops.ewma(ys, EWMA_K)[..., :-1]                  # EWMAMean.forward (EWMA.py:46-54)
+            resid = ys - mean
+            with torch.no_grad():
+                sigma2 = torch.nn.functional.softplus(raw) + 1e-4
+            out, alpha, info = ops.mll_step(Ks, resid, sigma2, ws_, want_grad=True)
+            with torch.no_grad():
+                # loss = -mll ; d loss / d raw = -(d mll / d sigma2) * sigmoid(raw)
+                raw.grad = -(out[:, 1] * torch.sigmoid(raw))
+                red_[0] = -out[:, 0].sum()
+                red_[1] = raw.grad.sum()
+            if dist is not None:
+                dist.all_reduce(red_)                              # the path's only collective
+            opt_.step()
+            return out, info
+        return step, raw, ws_, red_
+
+    def timed(step, warmup, steps):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
+        for _ in range(warmup):
+            step()
         if dist is not None:
-            dist.all_reduce(red)                                 # the path's only collective
-        opt.step()
-        return out, info
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, info = step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt_ = time.perf_counter() - t0
+        per_rank = [dt_]
+        if dist is not None:
+            tt = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            gathered = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(gathered, tt)
+            per_rank = [float(g.item()) for g in gathered]
+        return max(per_rank), per_rank, info
 
-    for _ in range(args.warmup):
-        step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, info = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    step, raw_noise, ws, red = make_step(B)
+    dt, dt_ranks, info = timed(step, args.warmup, args.steps)
     bad = int((info != 0).sum().item())
     loss = float(red[0].item()) / (B * world)
+    K, y = K_all[:B], y_all[:B]
+
+    other = None
+    if world > 1:                       # the other scaling mode, same steps, right behind the headline region
+        om = "strong" if args.scaling == "weak" else "weak"
+        Bo = B_by_mode[om]
+        del ws
+        step_o, _, ws_o, _ = make_step(Bo)
+        dto, dto_ranks, info_o = timed(step_o, args.warmup, args.steps)
+        other = {"scaling": om, "series_per_gpu": Bo, "series_total": Bo * world,
+                 "value": round(Bo * world / args.batch * args.steps / dto, 4), "ms_per_step": round(dto / args.steps * 1e3, 3),
+                 "ms_per_step_by_rank": [round(t / args.steps * 1e3, 3) for t in dto_ranks],
+                 "not_pd": int((info_o != 0).sum().item())}
+        del step_o, ws_o
+        ws = ops.MllWorkspace(B, n, True, dev)
 
     # ---- roofline leg: per-launch HIP events (on the stream each launch goes to) around every launch of one
     # factor+inverse in the SAME schedule the timed steps use; per class the union of the launch intervals
@@ -274,12 +346,14 @@ def main():
         line = {
             "metric": "mll_grad_steps_per_s", "value": round(steps_per_s, 4),
             "unit": f"steps/s (1 step = MLL+grad over {args.batch} series of N={n})",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "ms_per_step_by_rank": [round(t / args.steps * 1e3, 3) for t in dt_ranks],
+            "higher_is_better": True, "scaling": args.scaling, "other_scaling": other,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"MLL+grad step, N={n}, batch={B} series per GPU, Volatility kernel + EWMA(k={EWMA_K}) mean",
                        "series_total": per_step_series, "parallelism": f"series-sharded x{world}",
-                       "collective": "all_reduce(2 floats)/step" if world > 1 else "none"},
+                       "collective": f"all_reduce(2 floats)/step over {backend}" if world > 1 else "none"},
             "step_tflops": round(per_step_series * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
             "loss": round(loss, 6), "not_pd": bad,
             "roofline": roof,
@@ -336,19 +410,37 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
     return out
 
 
+def _cpu_worker(idx, threads, Kc, yc, mc, reps, barrier, q):
+    """One worker of the whole-host CPU baseline: its own series, `threads` intra-op threads, all workers in step."""
+    import torch as th
+    from oracle import torch_cpu_path as tp
+    th.set_num_threads(threads)
+    raw = th.full((Kc.shape[0],), 1e-5, requires_grad=True)
+    tp.mll_step(Kc, yc, mc, raw)                      # warm-up (also sizes the allocator)
+    barrier.wait()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tp.mll_step(Kc, yc, mc, raw)
+    t1 = time.perf_counter()
+    q.put((idx, t0, t1))
+
+
 def cpu_baseline_leg(K, y, mean, n, batch):
     """The CPU path timed on this box's host cores on a bounded sample of the same workload: the torch-only
     restatement of gpytorch's dense step (kind "port"), and real gpytorch under max_cholesky_size(N+1) when it is
-    importable -- reported, never the optimisation target."""
+    importable -- reported, never the optimisation target.
+
+    Two figures.  `single_worker`: one process, the series in one batched call, at the thread count that is fastest for
+    ONE series (LAPACK/MKL does not scale to every core of a big host at this size).  `value` (the headline baseline):
+    the WHOLE host -- cpu_count // best_threads concurrent worker processes of best_threads threads each over disjoint
+    series (the series are independent), aggregate series-steps/s / batch."""
     from oracle import torch_cpu_path as tp
     ncpu = os.cpu_count() or 1
     bs = 8 if n >= 4096 else 16
     bs = min(bs, K.shape[0])
     Kc, yc, mc = K[:bs].cpu(), y[:bs].cpu(), mean[:bs].cpu()
-    # LAPACK/MKL does not scale to every core of a big host at this size (256 threads ran 2.7x slower than
-    # 8 here): calibrate the thread count on one series and report the baseline at its best setting.
     best_t, best_c = None, None
-    for t_ in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+    for t_ in sorted({c for c in (4, 8, 16, 32, 64, ncpu) if c <= ncpu}):
         torch.set_num_threads(t_)
         r1 = torch.full((1,), 1e-5, requires_grad=True)
         tp.mll_step(Kc[:1], yc[:1], mc[:1], r1)
@@ -368,10 +460,44 @@ def cpu_baseline_leg(K, y, mean, n, batch):
         tp.mll_step(Kc, yc, mc, rawc)
         times.append(time.perf_counter() - t1)
     tc = float(np.median(times))
-    cpu = {"value": round(1.0 / (tc / bs * batch), 5), "unit": "steps/s", "cores": cores, "kind": "port",
-           "sample": f"{bs} of {batch} series x {reps} steps at N={n} (torch-CPU fp32 cholesky+autograd, median "
-                     f"{tc:.2f} s per {bs}-series step, min {min(times):.2f} max {max(times):.2f}), scaled x{batch / bs:g} to the "
-                     f"batch; threads calibrated over 8..{ncpu} on one series, best = {cores} of {ncpu} host cores"}
+    single = {"value": round(1.0 / (tc / bs * batch), 5), "unit": "steps/s", "cores": cores,
+              "sample": f"{bs} of {batch} series x {reps} steps at N={n} in one batched call (median {tc:.2f} s per "
+                        f"{bs}-series step, min {min(times):.2f} max {max(times):.2f}), scaled x{batch / bs:g}; threads "
+                        f"calibrated over 4..{ncpu} on one series, best = {cores}"}
+    # ---- the whole host: workers x threads = every core, disjoint series, all in flight at once
+    import torch.multiprocessing as mp
+    nw = max(1, min(ncpu // cores, 64))
+    per = 1                                           # series per worker (bounded sample: nw series in flight)
+    wreps = 2
+    Kh = K[: min(K.shape[0], nw * per)].cpu()
+    nw = min(nw, Kh.shape[0] // per)
+    yh, mh = y[: nw * per].cpu(), mean[: nw * per].cpu()
+    ctx = mp.get_context("spawn")
+    barrier, q = ctx.Barrier(nw), ctx.Queue()
+    procs = []
+    for w_ in range(nw):
+        sl = slice(w_ * per, (w_ + 1) * per)
+        pr = ctx.Process(target=_cpu_worker, args=(w_, cores, Kh[sl].clone().share_memory_(), yh[sl].clone().share_memory_(),
+                                                   mh[sl].clone().share_memory_(), wreps, barrier, q))
+        pr.start()
+        procs.append(pr)
+    spans = []
+    try:
+        for _ in range(nw):
+            spans.append(q.get(timeout=900))
+    finally:
+        for pr in procs:
+            pr.join(30)
+            if pr.is_alive():
+                pr.kill()
+    wall = max(s[2] for s in spans) - min(s[1] for s in spans)
+    series_steps_per_s = nw * per * wreps / wall
+    cpu = {"value": round(series_steps_per_s / batch, 5), "unit": "steps/s", "cores": nw * cores, "kind": "port",
+           "sample": f"{nw} concurrent workers x {cores} threads = {nw * cores} of {ncpu} host cores, {per} series of N={n} "
+                     f"each x {wreps} steps (torch-CPU fp32 cholesky+autograd), wall {wall:.2f} s for {nw * per * wreps} "
+                     f"series-steps, scaled to the batch of {batch}",
+           "single_worker": single}
+    torch.set_num_threads(cores)
     cpu["gpytorch"] = gpytorch_leg(Kc, yc, mc, n, batch, cores)
     if cpu["gpytorch"].get("value") is None:
         cpu["note"] = "gpytorch absent -- baseline is a torch-only restatement (oracle/torch_cpu_path.py)"

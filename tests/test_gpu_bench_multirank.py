@@ -33,6 +33,8 @@ def test_bench_two_ranks(scaling):
     assert len(lines) == 1                                         # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 3 and d["not_pd"] == 0
+    assert d["ranks_seen"] == 2 and len(d["ms_per_step_by_rank"]) == 2
+    assert d["other_scaling"]["scaling"] == ("strong" if scaling == "weak" else "weak")
     per_gpu = 16 if scaling == "weak" else 8
     assert d["config"]["series_total"] == 2 * per_gpu
     # value counts batches of 16 series per second over the whole job
