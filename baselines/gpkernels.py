@@ -1,5 +1,5 @@
 """Stationary kernels of the baseline GPs (voltron/models/BasicGPModels.py:10,20; experiments/weather/BasicWind.py:30-38)
--- SURVEY 8(f) row 2.  These are gpytorch classes (ScaleKernel, RBFKernel, MaternKernel, SpectralMixtureKernel),
+-- outside the product package (out of scope), kept for the (f)2 tests.  These are gpytorch classes (ScaleKernel, RBFKernel, MaternKernel, SpectralMixtureKernel),
 restated from their published formulas with gpytorch's parameter names and ``Positive`` (softplus) constraints; the
 covariance entries are elementwise torch (autograd gives dK/dtheta), the factorisation, the MLL and the dense
 d mll / d K they are contracted with run in libvolt_hip.so (volt_mll_step_f32 + volt_mll_grad_k_f32)."""
@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from .gp import Kernel, _dense
+from volt_amd.gp import Kernel, _dense
 
 
 def _inv_softplus(v):

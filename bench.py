@@ -240,18 +240,17 @@ def main():
         Np = ops.padded_n(n)
         L = _lib.lib()
         s2 = (torch.nn.functional.softplus(raw_noise.detach()) + 1e-4).contiguous()
-        A = torch.empty(B, Np, Np, device=dev)
-        Winv = torch.empty(B, Np // 128, 128, 128, device=dev)
-        Y = torch.empty(B, Np, Np, device=dev)
         inf = torch.empty(B, dtype=torch.int32, device=dev)
+        resid_p = (y - ops.ewma(y, EWMA_K)[..., :-1]).contiguous()
 
         def profile(groups, reps=3):
             ms_sum, ms_un, cnt = (ctypes.c_float * 2)(), (ctypes.c_float * 2)(), (ctypes.c_int * 2)()
             tot_s, tot_u = np.zeros(2), np.zeros(2)
             for _ in range(reps):
-                _lib.check(L.volt_profile_factor_f32(K.data_ptr(), n, n * n, s2.data_ptr(), A.data_ptr(), Winv.data_ptr(),
-                                                     Y.data_ptr(), inf.data_ptr(), B, n, groups, _lib.stream_ptr(),
-                                                     ms_sum, ms_un, cnt, None), "profile")
+                # the step's own workspace: same buffers, fused reductions and scratch as the timed steps
+                _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid_p.data_ptr(), s2.data_ptr(), ws.ptr,
+                                                   inf.data_ptr(), B, n, groups, _lib.stream_ptr(), ms_sum, ms_un, cnt,
+                                                   None), "profile")
                 tot_s += np.array(list(ms_sum))
                 tot_u += np.array(list(ms_un))
             return tot_s / reps, tot_u / reps, list(cnt)
@@ -295,6 +294,10 @@ def main():
         L_ = _lib.lib()
         legs = () if args.no_aux_legs else ("chol", "fwd")
 
+        A = Winv = None
+        if legs:
+            A = torch.empty(B, Np, Np, device=dev)
+            Winv = torch.empty(B, Np // 128, 128, 128, device=dev)
         pws_bytes = int(L_.volt_potrf_workspace_bytes(B, Np))   # scratch of the late-column schedule (what ops.potrf passes)
         pws = torch.empty(pws_bytes + 256, dtype=torch.uint8, device=dev) if pws_bytes else None
         pws_ptr = ((pws.data_ptr() + 255) // 256) * 256 if pws is not None else None
@@ -328,7 +331,7 @@ def main():
             extra["ms_per_mll_forward"] = round(res["fwd"] / B, 4)
         extra["cholesky_note"] = ("ms_per_cholesky = wall time of one batched factorisation of K + s2 I (copy-in + blocked "
                                   "Cholesky, N^3/3 flop each) / 64; ms_per_mll_forward adds the forward solve and log-det")
-        del A, Winv, Y, f, pws
+        del A, Winv, f, pws
 
     # ---- rollouts leg (rank 0): BASELINE config 5's per-GPU share -- 8 series x 10,000 paths x 256 steps at this N
     roll = None

@@ -107,8 +107,9 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
  * rollout_utils.py:36,44; gpytorch inv_quad) ------------------------------------------------
  * rhs/out [B,Np] contiguous (pad with zeros).  `scratch` [B,Np] elements.  lower: out = L^-1 rhs;
  * lower_t: out = L^-T rhs.  rhs and out may alias.  ONE launch per solve: one workgroup per 128-block,
- * chained through release/acquire flags kept in `scratch`; an internal time-out (never expected) turns the
- * affected blocks into NaN instead of hanging. */
+ * chained through release/acquire flags kept in `scratch`.  A hand-off that does not arrive within ~3 s of WALL CLOCK
+ * (s_memrealtime; never expected -- only a bug or a wedged device gets there) turns the affected blocks into NaN
+ * instead of hanging AND sets the error word: after the call, ((const int*)scratch)[1] != 0 says the solve timed out. */
 int volt_trsv_lower_f32(const float* A, const float* Winv, const float* rhs, float* out,
                         float* scratch, int B, int Np, void* stream);
 int volt_trsv_lower_t_f32(const float* A, const float* Winv, const float* rhs, float* out,
@@ -150,24 +151,6 @@ int volt_rollout_shared_f32(const float* hist_y, const float* hist_e1, const flo
                             const float* mr_latent, const float* w, const float* e, float* samples, int G, int S,
                             int H, int k, int mean_mode, float mr_theta, void* stream);
 
-/* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
- * Runs exactly the factorisation of volt_mll_step_f32 (block column 0 copied from K, the rest read from K inside
- * the tiles; with Y != NULL also the triangular inverse, co-launched) in the schedule the step uses -- `groups` = 0:
- * the library's default split of the batch over its streams; 1: one stream, the whole batch per launch -- with every
- * launch bracketed by HIP events on the stream it is launched on.  Synchronises, and writes to HOST arrays, per
- * kernel class, the summed launch durations, the length of the UNION of the launch intervals (what the class
- * occupied of the wall clock when launches of several groups overlap) and the launch counts:
- *   [0] factor_step_kernel with a factorisation part (diagonal tile + look-ahead + panel tiles (update + solve) +
- *       trtri row k-1 in one grid, k = 0 .. n-1)          [1] factor_step_kernel carrying only the last trtri row. */
-int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A,
-                            float* Winv, float* Y, int* info, int B, int N, int groups, void* stream,
-                            float* ms_sum_host /*[2]*/, float* ms_union_host /*[2]*/, int* launches_host /*[2]*/,
-                            float* per_launch_host /* NULL, or [every launch, in enqueue order] durations in ms */);
-
-/* Tuning hook (scripts/tune_gemm.py): launches the panel tiles (update + solve, var 0) or the 2x2-wave diagonal
- * update (var 1) of block column k `reps` times on an already factored A; results are garbage, only the timing
- * matters. */
-int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream);
 /* One-launch Adam step over a list of fp32 parameter tensors (train_utils.py:43,100,166,238,291 build
  * torch.optim.Adam(lr=0.1); same arithmetic, amsgrad off, no weight decay).  slots: DEVICE array of nslots records
  * {float* p; float* m; float* v; int64 end} (end = one past the tensor's last element in the flattened index space,
@@ -176,16 +159,6 @@ int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, 
  * replayed from a graph. */
 int volt_adam_step_f32(const void* slots, int nslots, long long total, const float* grad, float lr, float beta1, float beta2,
                        float eps, int* state, void* stream);
-
-/* Host only (no GPU): the balanced schedule of launch k (k == n: the trailing trtri launch) of a factorisation of B
- * matrices with n block columns, as volt_potrf / the MLL step build it for mid-size batches (csrc/sched.h).  items
- * [max_items][4] int32 in grid order (kind | b << 3; block index; sl | nsl << 8 | tile << 16; b0 | b1 << 16), loads [G]
- * the load of each of G slots under greedy list scheduling of that order, in K-block units.  Returns the item count,
- * -1 bad argument, -2 max_items too small. */
-int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac, int* items, int max_items, float* loads);
-/* The diagonal-block kernel alone on block column k of B (unfactored) matrices, with s_memtime stamps of its
- * phases: stamps [B,32] int64 (load, factor32 x4 with panel / trailing updates, L out, inverse, W out, publish). */
-int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);
 
 /* ---- a5: MLL + gradient  (ExactMarginalLogLikelihood + loss.backward(), train_utils.py:249-250)
  * One "step" of SURVEY 8(d) with K resident:
@@ -202,8 +175,8 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
                       int* info, void* workspace, int B, int N, int want_grad, void* stream);
 
-/* Dense gradient of the MLL wrt the covariance, for kernels with trainable parameters (Matern / RBF / spectral
- * mixture baselines, voltron/models/BasicGPModels.py, TrainBasicModel train_utils.py:146-190):
+/* Dense gradient of the MLL wrt the covariance, for kernels whose parameters enter K elementwise (the fractional
+ * Brownian-motion prior of the vol forecaster, voltron/models/BMGP.py:15-16 + kernels/FBMKernel.py:38-59):
  *     grad_K[b] = d mll_b / d K_b = 1/2 (alpha alpha' - K_s^-1) / N,   K_s^-1 = Y Y' on the structured GEMM.
  * Call after volt_mll_step_f32(want_grad = 1) on the same workspace; scratch [B, Np, Np] floats, 16-byte aligned. */
 int volt_mll_grad_k_f32(void* mll_workspace, const float* alpha, float* scratch, float* grad_K, int B, int N,

@@ -1,0 +1,60 @@
+/* volt_hip_tune.h -- measurement and tuning hooks of libvolt_hip.so.  NOT part of the drop-in boundary
+ * (include/volt_hip.h): nothing on the product path calls these; bench.py's roofline leg, the scripts under scripts/
+ * and tests/test_sched_host.py do.  They live in the same shared library so that what they time is the shipped code.
+ *
+ * Environment knobs.  The schedule defaults below are compiled in and were measured on MI355X;
+ * every one can be overridden for experiments through ONE table read once per process (csrc/chol.hip, `tunables()`):
+ *   VOLT_GROUPS            stream groups for batches >= 16 (2)        VOLT_SPLITK_TARGET  workgroups per split launch (512)
+ *   VOLT_SPLITK_MINL       shortest K-slice in blocks (2)            VOLT_SPLITK_MAXS    most slices per tile (8)
+ *   VOLT_SPLITK_GROUPS / _MAXB   two split groups for 10 <= B < 22   VOLT_SCHED          balanced schedule on/off (1)
+ *   VOLT_SCHED_MINB / _MAXB / _MAXB_POTRF   batch range of the balanced schedule (3 / 31 / 64)
+ *   VOLT_SCHED_G / _S / _FRAC / _GROUPS / _KMIN   its slots (256), slices per tile (4), cut threshold (0.6), groups (2),
+ *                          first scheduled block column (by batch size)
+ *   VOLT_SPINE / VOLT_SPINE_MAXB   the dataflow (spine) factorisation for small batches on/off, largest batch
+ * None of them is read by the product's Python; a deployment sets none.
+ */
+#ifndef VOLT_HIP_TUNE_H
+#define VOLT_HIP_TUNE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
+ * Runs exactly the factorisation + triangular inverse of the gradient step (the MLL entry point of volt_hip.h with
+ * want_grad = 1) ON THAT STEP'S OWN WORKSPACE -- same buffers, the fused z / Frobenius reductions in the trtri
+ * epilogues, the split-K scratch of the small-batch schedules -- in the schedule the step uses (`groups` = 0: the
+ * library's default; > 0: that many stream groups, 1 = lockstep, whole batch per launch on one stream), with every
+ * launch bracketed by HIP events on the stream it is launched on.  The O(N^2) tail (sum_zpart, y_times_z, scalars) is
+ * not run.  Synchronises, and writes to HOST arrays, per kernel class, the summed launch durations, the length of the
+ * UNION of the launch intervals (what the class occupied of the wall clock when launches of several groups overlap)
+ * and the launch counts:
+ *   [0] factor_step_kernel with a factorisation part (diagonal tile + look-ahead + panel tiles (update + solve) +
+ *       trtri row k-1 in one grid, k = 0 .. n-1)          [1] factor_step_kernel carrying only the last trtri row.
+ * workspace: as for the MLL step (volt_mll_workspace_bytes(B, N, 1) bytes, 256-byte aligned). */
+int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                          void* workspace, int* info, int B, int N, int groups, void* stream,
+                          float* ms_sum_host /*[2]*/, float* ms_union_host /*[2]*/, int* launches_host /*[2]*/,
+                          float* per_launch_host /* NULL, or [every launch, in enqueue order] durations in ms */);
+
+/* Tuning hook (scripts/tune_gemm.py): launches the panel tiles (update + solve, var 0) or the 2x2-wave diagonal
+ * update (var 1) of block column k `reps` times on an already factored A; results are garbage, only the timing
+ * matters. */
+int volt_tune_update_f32(float* A, const float* Winv, int* info, int B, int Np, int k, int var, int reps, void* stream);
+/* Host only (no GPU): the balanced schedule of launch k (k == n: the trailing trtri launch) of a factorisation of B
+ * matrices with n block columns, as volt_potrf / the MLL step build it for mid-size batches (csrc/sched.h).  items
+ * [max_items][4] int32 in grid order (kind | b << 3; block index; sl | nsl << 8 | tile << 16; b0 | b1 << 16), loads [G]
+ * the load of each of G slots under greedy list scheduling of that order, in K-block units.  Returns the item count,
+ * -1 bad argument, -2 max_items too small. */
+int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac, int* items, int max_items, float* loads);
+/* The diagonal-block kernel alone on block column k of B (unfactored) matrices, with s_memtime stamps of its
+ * phases: stamps [B,32] int64 (load, factor32 x4 with panel / trailing updates, L out, inverse, W out, publish). */
+int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOLT_HIP_TUNE_H */

@@ -10,16 +10,17 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 x, F, vol = sde_batch(B, n)
 K = ops.fill(ops.cumtrapz(torch.tensor(vol).cuda(), torch.tensor(x).cuda(), square=True))
 Np = ops.padded_n(n); nb = Np // 128
-A = torch.empty(B, Np, Np, device="cuda"); W = torch.empty(B, nb, 128, 128, device="cuda"); Y = torch.empty(B, Np, Np, device="cuda")
+ws = ops.MllWorkspace(B, n, True, "cuda"); resid = torch.randn(B, n, device="cuda")
 inf = torch.empty(B, dtype=torch.int32, device="cuda"); s2 = torch.full((B,), 0.6933, device="cuda")
+GROUPS = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 L = _lib.lib()
 ms_s, ms_u, cnt = (ctypes.c_float * 2)(), (ctypes.c_float * 2)(), (ctypes.c_int * 2)()
-per = (ctypes.c_float * (nb + 8))()
+per = (ctypes.c_float * (4 * nb + 16))()
 tot = np.zeros(nb + 1)
 reps = 3
 for r in range(reps + 1):
-    _lib.check(L.volt_profile_factor_f32(K.data_ptr(), n, n * n, s2.data_ptr(), A.data_ptr(), W.data_ptr(), Y.data_ptr(),
-                                         inf.data_ptr(), B, n, 1, _lib.stream_ptr(), ms_s, ms_u, cnt, per), "profile")
+    _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid.data_ptr(), s2.data_ptr(), ws.ptr, inf.data_ptr(), B, n,
+                                       GROUPS, _lib.stream_ptr(), ms_s, ms_u, cnt, per), "profile")
     if r: tot += np.array(list(per))[:nb + 1]
 tot /= reps
 c = 128.0 ** 3

@@ -20,8 +20,8 @@ def dev(a):
 
 def _baseline_model(kern, train_x, log_y, ls, os_, noise, mean=None):
     from volt_amd.gp import GaussianLikelihood
-    from volt_amd.gpkernels import MaternKernel, RBFKernel, ScaleKernel
-    from volt_amd.models import MaternGP
+    from baselines.gpkernels import MaternKernel, RBFKernel, ScaleKernel
+    from baselines.models import MaternGP
     lh = GaussianLikelihood().cuda()
     m = MaternGP(train_x, log_y, lh).cuda()
     if kern == "rbf":
@@ -83,8 +83,9 @@ def test_dense_kernel_mll_gradients_match_fp64_autograd(kern):
     """loss = -mll(model(x), y); loss.backward() for kernels with trainable parameters: value and every parameter
     gradient vs fp64 autograd of the dense Gaussian log-density on the CPU (d mll / d K from volt_mll_grad_k_f32)."""
     from volt_amd.gp import ExactMarginalLogLikelihood, GaussianLikelihood
-    from volt_amd.gpkernels import SpectralMixtureKernel
-    from volt_amd.models import BMGP, MaternGP, SMGP
+    from baselines.gpkernels import SpectralMixtureKernel
+    from baselines.models import MaternGP, SMGP
+    from volt_amd.models import BMGP
     n = 200
     F, vol = sde_series(n - 1, 21)
     tx = torch.arange(n, dtype=torch.float32) / 252
@@ -159,7 +160,7 @@ def test_exact_posterior_matches_oracle():
 
 def test_train_basic_model_runs_the_reference_loop():
     """TrainBasicModel (train_utils.py:146-190): matern + log-linear mean with the slope prior, and the SM variant."""
-    from volt_amd.train_utils import TrainBasicModel
+    from baselines.train import TrainBasicModel
     n = 120
     F, _ = sde_series(n - 1, 41)
     tx = torch.arange(n, dtype=torch.float32).cuda() / 252

@@ -203,11 +203,21 @@ def test_mll_step_baseline_batches_properties(ops, B, n):
     x, F, vol = sde_batch(B, n)
     Kd = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
     s2v = torch.linspace(0.3, 0.9, B, device="cuda")
+    rows = [0, B // 2, B - 1]                                   # first / middle / last series: both stream groups
+    s2v[rows] = float(vo.noise_from_raw(1e-5))                  # the noise the oracle derives from raw_noise = 1e-5
     y = torch.log(dev(F[:, 1:]))
-    r = (y - y.mean(-1, keepdim=True)).float()
+    ymean = y.mean(-1, keepdim=True).expand_as(y)
+    r = (y - ymean).float()
     o, a, info = ops.mll_step(Kd, r, s2v, want_grad=True)
     o, a = o.clone(), a.clone()
     assert int(info.abs().sum()) == 0 and bool(torch.isfinite(o).all())
+    # ... and three rows of the FULL batch against the fp64 oracle (same tolerances as test_mll_step_vs_oracle)
+    oo = vo.mll_and_grads(Kd[rows].cpu().numpy(), y[rows].cpu().numpy(), ymean[rows].cpu().numpy(), 1e-5)
+    oh, ah = o[rows].cpu().numpy().astype(np.float64), a[rows].cpu().numpy()
+    np.testing.assert_allclose(oh[:, 0], oo["mll"], rtol=2e-5)
+    np.testing.assert_allclose(oh[:, 1], 0.5 * (oo["aa"] - oo["trinv"]) / n, rtol=1e-3)
+    np.testing.assert_allclose(oh[:, 4], oo["trinv"], rtol=1e-4)
+    assert np.abs(ah - oo["alpha"]).max() <= 1e-4 * np.abs(oo["alpha"]).max()
     rd, ad = r.double(), a.double()
     back = torch.empty_like(rd)
     for b0 in range(0, B, 8):                                   # fp64 K v in slices: 8 x N^2 doubles at a time

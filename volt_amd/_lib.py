@@ -7,7 +7,7 @@ import os
 
 import torch  # noqa: F401  -- load torch's libamdhip64 first so the library binds the same HIP runtime
 
-from .build import LIB, build_lib, source_hash
+from .build import LIB, build_lib, source_hash, sources_present
 
 _lib = None
 ABI_VERSION = 2
@@ -36,12 +36,7 @@ _SIGS = {
     "volt_trtri_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_rollout_scratch_bytes": (_sz, [_i32, _i32, _i32]),
     "volt_rollout_bordered_f32": (C.c_int, [_ptr] * 16 + [_i32] * 6 + [_f32] * 3 + [_ptr]),
-    "volt_profile_factor_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr,
-                                          _ptr, _ptr]),
-    "volt_tune_update_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "volt_adam_step_f32": (C.c_int, [_ptr, _i32, C.c_longlong, _ptr, C.c_float, C.c_float, C.c_float, C.c_float, _ptr, _ptr]),
-    "volt_sched_describe": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _ptr, _i32, _ptr]),
-    "volt_tune_diag_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr]),
     "volt_mll_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "volt_mll_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
     "volt_mll_grad_k_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
@@ -53,32 +48,58 @@ _SIGS = {
                            + [_i32, _i32, _ptr]),
 }
 
-EXPORTS = tuple(_SIGS)
+# measurement / tuning hooks: include/volt_hip_tune.h, not part of the drop-in boundary
+_TUNE_SIGS = {
+    "volt_profile_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "volt_tune_update_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
+    "volt_sched_describe": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _ptr, _i32, _ptr]),
+    "volt_tune_diag_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr]),
+}
+
+EXPORTS = tuple(_SIGS)                  # every symbol include/volt_hip.h declares
+TUNE_EXPORTS = tuple(_TUNE_SIGS)        # every symbol include/volt_hip_tune.h declares
 
 
 class VoltHipError(RuntimeError):
     pass
 
 
+def _embedded_hash(path):
+    handle = C.CDLL(path)
+    fn = handle.volt_source_hash
+    fn.restype = C.c_char_p
+    return handle, fn().decode()
+
+
 def lib() -> C.CDLL:
-    """Load (once) and type the library.  Raises if it has not been built."""
+    """Load (once) and type the library.  A binary that is already there is dlopen'ed FIRST and judged by the source
+    hash compiled into it: it is used when that equals the hash of the checked-in sources, or when the sources are not
+    there to compare with (a deployed, read-only tree).  Only a missing or stale binary goes to hipcc (~30 s, behind a
+    file lock).  Raises if neither works: volt_amd has no CPU fallback."""
     global _lib
     if _lib is None:
-        # A source-only checkout, or a git-ignored binary older than the checked-in sources: (re)build once
-        # (hipcc, ~30 s).  build_lib compares the hash of the sources with the one recorded by the last build.
-        try:
-            build_lib(verbose=False)
-        except Exception as e:
-            raise VoltHipError(
-                f"{LIB} is missing or stale and could not be built ({e}): run `python -m volt_amd.build` "
-                "(hipcc, gfx950). volt_amd has no CPU fallback.") from e
-        handle = C.CDLL(LIB)
-        built = handle.volt_source_hash
-        built.restype = C.c_char_p
-        if built().decode() != source_hash():
-            raise VoltHipError(f"{LIB} was built from other sources ({built().decode()} != {source_hash()}): "
-                               "run `python -m volt_amd.build --force`")
-        for name, (res, args) in _SIGS.items():
+        handle = None
+        if os.path.exists(LIB):
+            try:
+                handle, built = _embedded_hash(LIB)
+            except (OSError, AttributeError):
+                handle = None
+            if handle is not None and sources_present() and built != source_hash():
+                import _ctypes                                 # stale: built from other sources than the checked-in ones;
+                _ctypes.dlclose(handle._handle)                # unmap it, or dlopen would hand the same image back after the rebuild
+                handle = None
+        if handle is None:
+            try:
+                build_lib(force=os.path.exists(LIB), verbose=False)
+            except Exception as e:
+                raise VoltHipError(
+                    f"{LIB} is missing or stale and could not be built ({e}): run `python -m volt_amd.build` "
+                    "(hipcc, gfx950). volt_amd has no CPU fallback.") from e
+            handle, built = _embedded_hash(LIB)
+            if built != source_hash():
+                raise VoltHipError(f"{LIB} was built from other sources ({built} != {source_hash()}): "
+                                   "run `python -m volt_amd.build --force`")
+        for name, (res, args) in {**_SIGS, **_TUNE_SIGS}.items():
             fn = getattr(handle, name)           # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
         if handle.volt_abi_version() != ABI_VERSION:

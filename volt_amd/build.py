@@ -18,7 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvolt_hip.so")
 SOURCES = ["fill.hip", "ewma.hip", "chol.hip", "chol64.hip", "trsv.hip", "mll.hip", "rollout.hip", "gpcv.hip", "adam.hip"]
-HEADERS = ["common.h", os.path.join("..", "..", "include", "volt_hip.h")]
+HEADERS = ["common.h", "sched.h", os.path.join("..", "..", "include", "volt_hip.h"),
+           os.path.join("..", "..", "include", "volt_hip_tune.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function"]
 
@@ -28,6 +29,10 @@ def _hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: libvolt_hip.so cannot be built")
+
+
+def sources_present() -> bool:
+    return all(os.path.exists(os.path.join(CSRC, f)) for f in SOURCES + HEADERS)
 
 
 def source_hash() -> str:

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "sched.h"
 #include "../../include/volt_hip.h"
+#include "../../include/volt_hip_tune.h"
 #include <algorithm>
 #include <array>
 #include <map>
@@ -1216,6 +1217,39 @@ __global__ void tune_empty_kernel(float* A) { if (A == nullptr) A[0] = 0.f; }
 
 using namespace volt;
 
+// Schedule parameters: compiled-in defaults (measured on MI355X), each overridable for experiments
+// through its VOLT_* environment variable (include/volt_hip_tune.h) -- read ONCE per process, here and nowhere else.
+struct Tunables {
+    int groups = 2;                  // stream groups of a large batch (2 >= 4 > 8 with one launch per block column)
+    int splitk_target = 512, splitk_minl = 2, splitk_maxs = 8, splitk_groups = 2, splitk_maxb = 22;
+    int sched = 1, sched_minb = 3, sched_maxb = 31, sched_maxb_potrf = 64;
+    int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
+    float sched_frac = 0.6f;
+};
+static const Tunables& tunables() {
+    static const Tunables tn = [] {
+        Tunables t;
+        auto geti = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
+        geti("VOLT_GROUPS", t.groups);
+        geti("VOLT_SPLITK_TARGET", t.splitk_target);
+        geti("VOLT_SPLITK_MINL", t.splitk_minl);
+        geti("VOLT_SPLITK_MAXS", t.splitk_maxs);
+        geti("VOLT_SPLITK_GROUPS", t.splitk_groups);
+        geti("VOLT_SPLITK_MAXB", t.splitk_maxb);
+        geti("VOLT_SCHED", t.sched);
+        geti("VOLT_SCHED_MINB", t.sched_minb);
+        geti("VOLT_SCHED_MAXB", t.sched_maxb);
+        geti("VOLT_SCHED_MAXB_POTRF", t.sched_maxb_potrf);
+        geti("VOLT_SCHED_G", t.sched_g);
+        geti("VOLT_SCHED_S", t.sched_s);
+        geti("VOLT_SCHED_GROUPS", t.sched_groups);
+        geti("VOLT_SCHED_KMIN", t.sched_kmin);
+        if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
+        return t;
+    }();
+    return tn;
+}
+
 // Optional per-launch timing (bench only): every launch is bracketed by two events on ITS stream; the caller
 // synchronises, and per kernel class gets the summed launch durations and the length of the UNION of the launch
 // intervals (on one stream the two agree; with the batch cut into groups on several streams the launches of a class
@@ -1319,7 +1353,7 @@ static const SchedDev* get_sched(int B, int n, bool has_y, const SchedParams& p,
     // its slabs, and only the late launches (long trtri rows, k + 2 blocks against a mean of ~k / 2) are unbalanced enough
     // (ms/step at N = 4096 by first scheduled column, B = 3: 8 2.58, 12 2.57, 16 2.60; B = 6: 12 3.66, 16 3.64, 20 3.70;
     // B = 8: 16 4.03, 20 3.97; two groups of B / 2: 16)
-    static const int kmin_env = getenv("VOLT_SCHED_KMIN") ? atoi(getenv("VOLT_SCHED_KMIN")) : -1;
+    const int kmin_env = tunables().sched_kmin;
     // the factorisation alone (no trtri rows; per-call ms at N = 4096 by first scheduled column, B = 16: 12 3.95, 16 4.04,
     // 20 4.28, off 4.82; B = 32: 12 6.60, 20 6.64, off 7.93; B = 64: 12 12.48, 20 12.21, 24 12.22, off 12.87)
     sd->kmin = kmin_env >= 0 ? kmin_env : !has_y ? (B * (256 / p.G) >= 48 ? 20 : 12) : (p.G < 256 ? 16 : B <= 4 ? 12 : B <= 7 ? 16 : 20);
@@ -1384,11 +1418,11 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
         const int kk = k < n ? k : n - 1;
         const double blocks = (double)B * ((double)(n - kk - 1) * kk + 0.5 * kk * (kk - 1) + kk);   // panel + trtri + look-ahead
         int L = (int)(blocks / (double)g.o.sk.S + 0.999);
-        static const int minl = getenv("VOLT_SPLITK_MINL") ? atoi(getenv("VOLT_SPLITK_MINL")) : 2;
+        const int minl = tunables().splitk_minl;
         if (L < minl) L = minl;
         int S = (kk + L - 1) / L;
         if (S < 1) S = 1;
-        static const int maxs = getenv("VOLT_SPLITK_MAXS") ? atoi(getenv("VOLT_SPLITK_MAXS")) : 8;
+        const int maxs = tunables().splitk_maxs;
         if (S > maxs) S = maxs;
         if (S * B > g.o.sk.cap) S = g.o.sk.cap / B;
         if (S < 1) S = 1;
@@ -1451,7 +1485,7 @@ struct StreamPool {
     hipStream_t aux[MAX_GROUPS - 1];
     hipEvent_t fork, join[MAX_GROUPS - 1];
     std::mutex mu;
-    int want_groups = 2;                 // VOLT_GROUPS, read once (measured with the one-launch-per-column kernels: 2 >= 4 > 8)
+    int want_groups = 2;                 // tunables().groups
     bool ok = false;
 };
 static StreamPool* stream_pool() {
@@ -1466,7 +1500,7 @@ static StreamPool* stream_pool() {
             ok = ok && hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
         }
-        if (const char* e = getenv("VOLT_GROUPS")) p.want_groups = atoi(e);
+        p.want_groups = tunables().groups;
         if (p.want_groups < 1) p.want_groups = 1;
         if (p.want_groups > MAX_GROUPS) p.want_groups = MAX_GROUPS;
         p.ok = ok;
@@ -1503,9 +1537,8 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     // ms/step unsplit -> split: B = 1 4.5 -> 2.0, 2 4.6 -> 2.6, 4 4.7 -> 3.4, 6 4.7 -> 4.4; from B = 8 on a launch has a
     // tile per CU and splitting on ONE stream stops paying: B = 8 stays unsplit, 4.8 ms).  10 <= B <= 20: two split groups
     // on two streams up to B = 20 (B = 12: 8.4 -> 6.1 ms, 16: 8.4 -> 7.1, 20: 9.6 -> 9.1; no gain from 24 on).
-    static const int target = getenv("VOLT_SPLITK_TARGET") ? atoi(getenv("VOLT_SPLITK_TARGET")) : 512;
-    static const int split_groups = getenv("VOLT_SPLITK_GROUPS") ? atoi(getenv("VOLT_SPLITK_GROUPS")) : 2;
-    static const int split_maxb = getenv("VOLT_SPLITK_MAXB") ? atoi(getenv("VOLT_SPLITK_MAXB")) : 22;
+    const Tunables& tn = tunables();
+    const int target = tn.splitk_target, split_groups = tn.splitk_groups, split_maxb = tn.splitk_maxb;
     const bool can_split = o.sk.slab && o.sk.count && force_groups == 0 && target > 1;
     FactorOpts o1 = o;
     o1.sk.S = 1;                                             // > 1: the split schedule, and the slices wanted per launch
@@ -1521,15 +1554,10 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     // two streams from 10 on; the early columns the plain launch.  Measured, N = 4096, ms/step before -> after: B = 3
     // 2.90 -> 2.57, 4 3.24 -> 3.00, 6 4.21 -> 3.64, 7 4.76 -> 3.83, 8 4.60 -> 3.97, 12 5.90 -> 5.43, 20 8.79 -> 8.02,
     // 24 9.99 -> 9.20, 28 11.08 -> 10.46 (16: no change).  B = 1, 2 stay on the all-split schedule below.
-    static const int sched_on = getenv("VOLT_SCHED") ? atoi(getenv("VOLT_SCHED")) : 1;
-    static const int sched_minb = getenv("VOLT_SCHED_MINB") ? atoi(getenv("VOLT_SCHED_MINB")) : 3;
-    static const int sched_maxb = getenv("VOLT_SCHED_MAXB") ? atoi(getenv("VOLT_SCHED_MAXB")) : 31;
-    static const int sched_maxb_potrf = getenv("VOLT_SCHED_MAXB_POTRF") ? atoi(getenv("VOLT_SCHED_MAXB_POTRF")) : 64;
+    const int sched_on = tn.sched, sched_minb = tn.sched_minb, sched_maxb = tn.sched_maxb, sched_maxb_potrf = tn.sched_maxb_potrf;
     if (can_split && sched_on && B >= sched_minb && B <= (o.Y ? sched_maxb : sched_maxb_potrf)) {
-        static const int sg = getenv("VOLT_SCHED_G") ? atoi(getenv("VOLT_SCHED_G")) : 256;
-        static const int ss = getenv("VOLT_SCHED_S") ? atoi(getenv("VOLT_SCHED_S")) : 4;
-        static const float sf = getenv("VOLT_SCHED_FRAC") ? (float)atof(getenv("VOLT_SCHED_FRAC")) : 0.6f;
-        static const int sgroups = getenv("VOLT_SCHED_GROUPS") ? atoi(getenv("VOLT_SCHED_GROUPS")) : 2;
+        const int sg = tn.sched_g, ss = tn.sched_s, sgroups = tn.sched_groups;
+        const float sf = tn.sched_frac;
         const int Gs = (sgroups > 1 && pool && B >= 10 && B % sgroups == 0) ? sgroups : 1;
         SchedParams sp;
         sp.G = sg / Gs;
@@ -1627,6 +1655,27 @@ int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* 
     return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
 }
 
+// The same, with every launch bracketed by HIP events on its own stream (bench.py's roofline leg through
+// volt_profile_step_f32 in mll.hip): identical buffers, reductions and scratch, so the profiled launches ARE the
+// timed step's.  Synchronises the stream.
+int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv, float* Y,
+                          int* info, const float* rpad, float* zpart, float* frob, int B, int N, int groups, void* stream,
+                          float* sk_slab, int* sk_count, int sk_rows, float* ms_sum_host, float* ms_union_host,
+                          int* launches_host, float* per_launch_host) {
+    if (groups < 0 || groups > MAX_GROUPS) return -11;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, 0.f, A, N, Np, 1);
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{rpad, zpart, frob, N}, SplitK{sk_slab, sk_count, 1, 1, sk_rows}};
+    LaunchTimer tm;
+    const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, nullptr, nullptr, &tm, groups);
+    hipError_t e = hipStreamSynchronize(s);            // the groups have joined into s
+    tm.collect(ms_sum_host, ms_union_host, launches_host, 2, per_launch_host);
+    if (rc) return rc;
+    if (e != hipSuccess) return (int)e;
+    return tm.err != hipSuccess ? (int)tm.err : 0;
+}
+
 extern "C" {
 
 int volt_prepare_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, int B,
@@ -1705,6 +1754,7 @@ static size_t potrf_ws_slab_bytes(int B, int Np) {
 
 size_t volt_potrf_workspace_bytes(int B, int Np) {
     if (B < 1 || potrf_ws_rows(B) == 0 || Np < TS || Np % TS) return 0;   // more than 64 matrices fill the chip with whole tiles
+    if (Np / TS < 3) return 0;               // k <= 1: no product is long enough to be cut (slices are >= 2 K-blocks)
     const size_t n = (size_t)Np / TS;
     return potrf_ws_slab_bytes(B, Np) + ((((n + 1) * (n + 1) * B * sizeof(int)) + 255) & ~(size_t)255);
 }
@@ -1733,33 +1783,6 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
 
 int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream) {
     return volt_potrf_ws_f32(A, Winv, info, B, Np, nullptr, 0, stream);
-}
-
-int volt_profile_factor_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv,
-                            float* Y, int* info, int B, int N, int groups, void* stream, float* ms_sum_host,
-                            float* ms_union_host, int* launches_host, float* per_launch_host) {
-    if (!K) return -1;
-    if (ldk < N) return -2;
-    if (!A) return -5;
-    if (!Winv) return -6;
-    if (!info) return -8;
-    if (B < 1) return -9;
-    if (N < 1) return -10;
-    if (groups < 0 || groups > MAX_GROUPS) return -11;
-    if (!ms_sum_host) return -13;
-    if (!ms_union_host) return -14;
-    if (!launches_host) return -15;
-    const int Np = volt_padded_n(N), n = Np / TS;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, 0.f, A, N, Np, 1);
-    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{nullptr, nullptr, nullptr, N}, SplitK{nullptr, nullptr, 1, 1, 0}};
-    LaunchTimer tm;
-    const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, nullptr, nullptr, &tm, groups);
-    hipError_t e = hipStreamSynchronize(s);            // the groups have joined into s
-    tm.collect(ms_sum_host, ms_union_host, launches_host, 2, per_launch_host);
-    if (rc) return rc;
-    if (e != hipSuccess) return (int)e;
-    return tm.err != hipSuccess ? (int)tm.err : 0;
 }
 
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream) {

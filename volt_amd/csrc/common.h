@@ -388,14 +388,24 @@ __device__ __forceinline__ void tri_chunk_p2(const float* cur, float* nxt, f32x1
     VOLT_SB();
 }
 
+// Hand-off waits are bounded by WALL CLOCK (s_memrealtime: a constant 100 MHz counter), not by an iteration count: a
+// preempted or profiled run spins more often, not longer.  3 s -- only a bug or a wedged device gets there.
+constexpr unsigned long long WAIT_LIMIT_TICKS = 300000000ull;
+__device__ __forceinline__ bool wait_nonzero(const int* flag, int sleep) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (sleep == 2) __builtin_amdgcn_s_sleep(2);
+        else __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
+    }
+    return true;
+}
 __device__ __forceinline__ bool flag_wait_one_lane(const int* flag) {
     bool ok = true;
     if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 22)) { ok = false; break; }      // seconds: only a bug can get here
-        }
+        ok = wait_nonzero(flag, 4);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     return ok;       // meaningful in thread 0 only

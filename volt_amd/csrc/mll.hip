@@ -5,6 +5,7 @@
 // (z = Y'r partials, Frobenius partials) is fused into the trtri epilogue in chol.hip.
 #include "common.h"
 #include "../../include/volt_hip.h"
+#include "../../include/volt_hip_tune.h"
 #include <math.h>
 
 namespace volt {
@@ -170,6 +171,11 @@ int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* 
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
                          void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows);
 
+int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv, float* Y,
+                          int* info, const float* rpad, float* zpart, float* frob, int B, int N, int groups, void* stream,
+                          float* sk_slab, int* sk_count, int sk_rows, float* ms_sum_host, float* ms_union_host,
+                          int* launches_host, float* per_launch_host);
+
 namespace {
 struct TailCtx {
     volt::MllWs w;
@@ -207,6 +213,27 @@ void mll_tail(void* vctx, int b0, int Bg, hipStream_t s) {
 const float* volt_internal_mll_y(void* workspace, int B, int N) { return carve(workspace, B, N, 1).Y; }
 
 extern "C" {
+
+int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                          void* workspace, int* info, int B, int N, int groups, void* stream, float* ms_sum_host,
+                          float* ms_union_host, int* launches_host, float* per_launch_host) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!resid) return -4;
+    if (!workspace || ((uintptr_t)workspace & 255)) return -6;
+    if (!info) return -7;
+    if (B < 1 || B > 65535) return -8;
+    if (N < 1) return -9;
+    if (!ms_sum_host) return -12;
+    if (!ms_union_host) return -13;
+    if (!launches_host) return -14;
+    const int Np = volt_padded_n(N);
+    MllWs w = carve(workspace, B, N, 1);
+    hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, resid, w.rpad, N, Np);
+    // groups > 0 forces that many stream groups and (like the round-2 hook) switches the small-batch schedules off
+    return volt_internal_profile(K, ldk, bsk, sigma2, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob, B, N, groups, stream,
+                                 w.sk_slab, w.sk_count, w.sk_rows, ms_sum_host, ms_union_host, launches_host, per_launch_host);
+}
 
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {
     if (B <= 0 || N <= 0) return 0;

@@ -15,8 +15,9 @@
 // drains, __syncthreads, lane 0 releases at agent scope and sets flag[b][i]; a consumer polls that one word relaxed
 // from one lane, then ONE agent-scope acquire, __syncthreads, plain loads.  Block indices are handed out by an
 // atomic ticket in dependency order (all matrices' block 0 first, ...), so a workgroup only ever waits for
-// workgroups that started before it: no co-residency or dispatch-order assumption.  Every spin is bounded; a
-// time-out poisons the output with NaN instead of hanging.  sync[] (tickets, flags) is zeroed by the launcher.
+// workgroups that started before it: no co-residency or dispatch-order assumption.  Every spin is bounded by wall
+// clock; a time-out poisons the output with NaN instead of hanging and raises sync[1], the error word the caller can
+// read back.  sync[] (ticket, error word, flags) is zeroed by the launcher.
 #include "common.h"
 #include "../../include/volt_hip.h"
 
@@ -28,17 +29,11 @@ template <typename T> struct V16;
 template <> struct V16<float> { typedef f32x4 type; static constexpr int N = 4; };
 template <> struct V16<double> { typedef f64x2 type; static constexpr int N = 2; };
 
-constexpr unsigned TRSV_SPIN_LIMIT = 1u << 22;     // ~ seconds; only a bug can reach it
-
 __device__ __forceinline__ bool trsv_wait(const int* flag) {
-    // one lane polls one word, relaxed, agent scope; then one acquire for the workgroup
+    // one lane polls one word, relaxed, agent scope (bounded by wall clock, common.h); then one acquire for the workgroup
     bool ok = true;
     if (threadIdx.x == 0) {
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > TRSV_SPIN_LIMIT) { ok = false; break; }
-        }
+        ok = wait_nonzero(flag, 2);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     return ok;      // meaningful in thread 0 only
@@ -144,7 +139,10 @@ __global__ __launch_bounds__(256) void trsv_kernel(const T* __restrict__ A, cons
             const int dep = j / NH, m = TRANS ? n - 1 - dep : dep;
             if (h == 0) {                                   // first sub-tile of a new dependency block
                 const bool ok = trsv_wait(flags + m);
-                if (tid == 0 && !ok) sFail = 1;
+                if (tid == 0 && !ok) {
+                    sFail = 1;
+                    atomicOr(&sync[1], 1);                  // the error word of the C ABI: this solve timed out
+                }
                 __syncthreads();                            // the acquire covers the workgroup
                 if (tid < TS) sV[dep & 1][tid] = ob[m * TS + tid];
                 __syncthreads();

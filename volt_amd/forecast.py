@@ -73,7 +73,8 @@ def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample,
             vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters, graph=graph)       # all series at once
         else:
             vol = vol_fn(train_x, train_y)                                               # [B, ntrain-1]
-        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean)
+        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean,
+                                            graph=graph)
         vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters, graph=graph)
         vmod.eval()
         pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous().detach()   # [B,S,H]

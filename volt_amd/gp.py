@@ -63,13 +63,21 @@ class NotPSDError(RuntimeError):
 class deferred_checks:
     """Context in which the factorisation's per-matrix ``info`` is NOT read back on the host after every step (that
     read is a device synchronisation, and it makes a training iteration impossible to capture in a hipGraph) but
-    accumulated on the device; ``raise_if_bad()`` reads the count once, after the loop.  Used by the graph-captured
-    training loops of train_utils (``graph=True``); the jitter-retry ladder of psd_safe_cholesky cannot run inside a
-    captured iteration, so a non-PD matrix there is an error the caller answers by rerunning without the graph."""
+    OR-ed into a device-side accumulator; ``any_bad()`` / ``raise_if_bad()`` read it when the caller chooses.  The
+    training loops of train_utils use it (graph-captured loops, and the batched eager loops, which check every few
+    iterations and replay from a snapshot with gpytorch's jitter ladder when a step failed).
+
+    ``immediate = True`` keeps the per-step host check (and the ladder) while still sizing the accumulators: one
+    accumulator per (length, device) of ``info``, so an iteration that factors batches of different shapes (an MLL
+    step and a GPCV step, two models) keeps every flag, and nothing is allocated -- or re-zeroed on replay -- inside
+    a graph capture: run one iteration with ``immediate = True`` under the context first."""
     _active = None
 
+    def __init__(self, immediate=False):
+        self.immediate = immediate
+        self._acc = {}
+
     def __enter__(self):
-        self.bad = None
         self._prev = deferred_checks._active
         deferred_checks._active = self
         return self
@@ -78,19 +86,45 @@ class deferred_checks:
         deferred_checks._active = self._prev
         return False
 
-    def note(self, info):
-        # one launch per step: OR the info words together per matrix (non-zero once any step failed)
+    @classmethod
+    def deferring(cls):
+        """The active context if it is deferring the check, else None."""
+        a = cls._active
+        return a if a is not None and not a.immediate else None
+
+    def _slot(self, info):
         flat = info.reshape(-1)
-        if self.bad is None or self.bad.shape != flat.shape:
-            self.bad = torch.zeros_like(flat)
-        self.bad.bitwise_or_(flat)
+        key = (flat.shape[0], flat.device)
+        acc = self._acc.get(key)
+        if acc is None:
+            if flat.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("deferred_checks: no accumulator for this info shape yet -- run one iteration with "
+                                   "immediate=True under the context before capturing")
+            acc = self._acc[key] = torch.zeros_like(flat)
+        return acc, flat
+
+    def reserve(self, info):
+        self._slot(info)
+
+    def note(self, info):
+        acc, flat = self._slot(info)
+        acc.bitwise_or_(flat)                            # one launch per step; non-zero once any step failed
+
+    def clear(self):
+        for acc in self._acc.values():
+            acc.zero_()
+
+    def any_bad(self) -> int:
+        """Number of matrices with a failed factorisation since the last clear() -- ONE host read."""
+        if not self._acc:
+            return 0
+        return int(torch.stack([(a != 0).sum() for a in self._acc.values()]).sum().item())
 
     def raise_if_bad(self):
-        if self.bad is not None:
-            nbad = int((self.bad != 0).sum().item())
-            if nbad:
-                raise NotPSDError(f"{nbad} matrices failed a factorisation inside the captured loop (not positive definite); "
-                                  "rerun with graph=False to get gpytorch's jitter-retry behaviour")
+        nbad = self.any_bad()
+        if nbad:
+            raise NotPSDError(f"{nbad} matrices failed a factorisation while the check was deferred (not positive "
+                              "definite); rerun without deferral to get gpytorch's jitter-retry behaviour")
 
 
 class NanError(RuntimeError):
@@ -271,7 +305,15 @@ class MultivariateNormal:
         shape = torch.Size(sample_shape) + self.loc.shape
         if base_samples is None:
             base_samples = torch.randn(shape, dtype=self.loc.dtype, device=self.loc.device)
-        return self.loc + (L @ base_samples.unsqueeze(-1)).squeeze(-1)
+        # loc + L z on the library GEMM: rows of z times L' (batched covariances: the batch leads the GEMM)
+        H = L.shape[-1]
+        if L.ndim == 2:
+            lz = ops.gemm_nt(base_samples.reshape(-1, H), L, uplo_b=1).reshape(base_samples.shape)
+        else:
+            nb = L.numel() // (H * H)
+            zb = base_samples.reshape(-1, nb, H).transpose(0, 1).contiguous()              # [T,S,H]
+            lz = ops.gemm_nt(zb, L.reshape(nb, H, H), uplo_b=1).transpose(0, 1).reshape(base_samples.shape)
+        return self.loc + lz.to(self.loc.dtype)
 
     def sample(self, sample_shape=torch.Size(), base_samples=None):
         with torch.no_grad():
@@ -349,55 +391,6 @@ class ExactGP(Module):
             "use GeneratePrediction / Rollouts (voltron/rollout_utils.py) which this package does implement")
 
 
-def exact_posterior(model, x, observation_noise=False):
-    """Exact-GP predictive at x for a model with ``mean_module(x)`` and a two-input ``covar_module(x1, x2)``:
-    mean = m(x) + K_*t K_s^-1 (y - m(X)),  cov = K_** - K_*t K_s^-1 K_t*  (+ noise).  K_s = L L' on the HIP potrf,
-    K_s^-1 = Y Y' with Y = L^-T from the HIP triangular inverse, products on the library GEMM.
-    Targets [S,N] (one shared input set, S target vectors -- nonvol_rollouts' stacked samples) give a batch mean."""
-    with torch.no_grad():
-        xt = model.train_inputs[0]
-        x = x.unsqueeze(-1) if x.ndim == 1 else x
-        y = model.train_targets
-        n = xt.shape[-2]
-        Ktt = _dense(model.covar_module(xt, xt)).to(torch.float32)
-        noise = model.likelihood.noise.reshape(-1)[:1]
-        A = (Ktt + noise * torch.eye(n, device=xt.device)).reshape(1, n, n)
-        f, _ = _safe_factor(A)
-        Y = ops.trtri(f)[0]                                           # L^-T  (upper)
-        Kst = _dense(model.covar_module(x, xt)).to(torch.float32)     # [H,N]
-        G = ops.gemm_nt(Kst, Y.mT.contiguous(), uplo_b=1)             # K_*t L^-T
-        r = (y - model.mean_module(xt)).to(torch.float32).reshape(-1, n)
-        z = ops.gemm_nt(r, Y.mT.contiguous(), uplo_b=1)               # rows L^-1 r
-        mean = model.mean_module(x) + ops.gemm_nt(z, G).reshape(*y.shape[:-1], x.shape[-2])
-        cov = _dense(model.covar_module(x, x)).to(torch.float32) - ops.gemm_nt(G, G)
-        if observation_noise:
-            cov = cov + noise * torch.eye(x.shape[-2], device=x.device)
-        return MultivariateNormal(mean, cov)
-
-
-class GPPosterior:
-    """What botorch's ``model.posterior(X)`` hands back, as far as rollout_utils.py:99,114 uses it:
-    ``.mean`` / ``.variance`` [.., q, 1] and ``.sample(sample_shape)`` -> sample_shape x .. x q x 1."""
-
-    def __init__(self, mvn):
-        self.mvn = mvn
-
-    @property
-    def mean(self):
-        return self.mvn.mean.unsqueeze(-1)
-
-    @property
-    def variance(self):
-        return self.mvn.variance.unsqueeze(-1)
-
-    def rsample(self, sample_shape=torch.Size(), base_samples=None):
-        return self.mvn.rsample(sample_shape, base_samples).unsqueeze(-1)
-
-    def sample(self, sample_shape=torch.Size(), base_samples=None):
-        with torch.no_grad():
-            return self.rsample(sample_shape, base_samples)
-
-
 # --------------------------------------------------------------------------------------- MLL
 class _ExactMLL(torch.autograd.Function):
     """mll[b] = log N(y_b; m_b, K_b + s2_b I) / N  with analytic backward:
@@ -414,11 +407,14 @@ class _ExactMLL(torch.autograd.Function):
         # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
         # NumericalWarning, then NotPSDError.  Same ladder here; the jitter is added inside the fused step.
         out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0)
-        if deferred_checks._active is not None:
-            deferred_checks._active.note(info)
+        chk = deferred_checks.deferring()
+        if chk is not None:
+            chk.note(info)
             bad = 0
         else:
             bad = int((info != 0).sum().item())
+            if deferred_checks._active is not None:
+                deferred_checks._active.reserve(info)
         if bad:
             if torch.isnan(K).any() or torch.isnan(resid).any() or torch.isnan(noise).any():
                 raise NanError("cholesky: NaN in the covariance, the noise or the residual")

@@ -4,12 +4,12 @@ unchanged where gpytorch is not installed (it is not in this image) or should no
 The reference reaches gpytorch by attribute (``gpytorch.means.ConstantMean()``, ``gpytorch.mlls.VariationalELBO(...)``,
 ``with gpytorch.settings.num_gauss_hermite_locs(75):`` -- example.ipynb cell 8, train_utils.py:28,44,50,100,127,
 experiments/weather/GPGenerator.py:62).  ``install()`` registers exactly the names those call sites use; each one is
-the class documented in volt_amd/gp.py, gpkernels.py or variational.py -- nothing here computes anything."""
+the class documented in volt_amd/gp.py or variational.py -- nothing here computes anything."""
 import contextlib
 import sys
 import types
 
-from . import gp, gpkernels, variational
+from . import gp, variational
 
 
 class _NoOpSetting(contextlib.ContextDecorator):
@@ -38,9 +38,7 @@ def build() -> types.ModuleType:
     utils = mod("gpytorch.utils", cholesky=cholesky, errors=errors, warnings=warns)
     subs = {
         "means": mod("gpytorch.means", Mean=gp.Mean, ConstantMean=gp.ConstantMean, LinearMean=gp.LinearMean),
-        "kernels": mod("gpytorch.kernels", Kernel=gp.Kernel, ScaleKernel=gpkernels.ScaleKernel,
-                       RBFKernel=gpkernels.RBFKernel, MaternKernel=gpkernels.MaternKernel,
-                       SpectralMixtureKernel=gpkernels.SpectralMixtureKernel),
+        "kernels": mod("gpytorch.kernels", Kernel=gp.Kernel),
         "likelihoods": mod("gpytorch.likelihoods", GaussianLikelihood=gp.GaussianLikelihood),
         "mlls": mod("gpytorch.mlls", ExactMarginalLogLikelihood=gp.ExactMarginalLogLikelihood,
                     VariationalELBO=variational.VariationalELBO),

@@ -34,39 +34,27 @@ class BMGP(ExactGP):
         return MultivariateNormal(self.mean_module(x), self.covar_module(x))
 
     def posterior_call(self, x):
-        if self.train_targets.ndim > 1:
-            return self._posterior_batched(x)
+        """Exact-GP posterior at the test points: K_s = L L' on the HIP potrf, K_s^-1 = Y Y' with Y = L^-T from the HIP
+        triangular inverse, every product on the library GEMM.  One series -> MultivariateNormal(mean [H], cov [H,H]);
+        T series over the shared grid -> (mean [T,H], cov [T,H,H])."""
         with torch.no_grad():
+            from ..gp import _dense
             xt = self.train_inputs[0]
             y = self.train_targets
-            n = xt.shape[0]
-            Ktt = self.covar_module.forward(xt, xt).reshape(n, n)
-            noise = self.likelihood.noise.reshape(-1)[:1]
-            A = (Ktt + noise * torch.eye(n, device=xt.device)).unsqueeze(0)
-            f, _ = _safe_factor(A)
-            Y = ops.trtri(f)[0]                                           # L^-T
-            Kst = self.covar_module.forward(x, xt)                        # [H,N]
-            G = Kst @ Y                                                    # K_*t L^-T
-            r = (y - self.mean_module(xt)).to(torch.float32)
-            mean = self.mean_module(x) + G @ (Y.t() @ r)
-            cov = self.covar_module.forward(x, x) - G @ G.t()
-            return MultivariateNormal(mean, cov)
-
-    def _posterior_batched(self, x):
-        """T independent posteriors over shared inputs: MultivariateNormal(mean [T,H], cov [T,H,H])."""
-        with torch.no_grad():
-            xt = self.train_inputs[0]
-            y = self.train_targets                                        # [T,N]
-            T, n = y.shape
-            from ..gp import _dense
+            batched = y.ndim > 1
+            T = y.shape[0] if batched else 1
+            n, H = xt.shape[0], x.shape[0]
             Ktt = _dense(self.covar_module(xt, xt)).reshape(T, n, n)
             noise = self.likelihood.noise.reshape(-1).expand(T)
             A = Ktt + noise.reshape(T, 1, 1) * torch.eye(n, device=xt.device)
             f, _ = _safe_factor(A)
-            Y = ops.trtri(f)                                              # [T,N,N]  L^-T
-            Kst = _dense(self.covar_module(x, xt)).reshape(T, x.shape[0], n)
-            G = Kst @ Y
-            r = (y - self.mean_module(xt)).to(torch.float32)
-            mean = self.mean_module(x) + (G @ (Y.mT @ r.unsqueeze(-1))).squeeze(-1)
-            cov = _dense(self.covar_module(x, x)).reshape(T, x.shape[0], x.shape[0]) - G @ G.mT
+            Linv = ops.trtri(f).mT.contiguous()                                            # L^-1, rows K-contiguous
+            Kst = _dense(self.covar_module(x, xt)).reshape(T, H, n)
+            G = ops.gemm_nt(Kst, Linv, uplo_b=1)                                           # K_*t L^-T
+            r = (y - self.mean_module(xt)).to(torch.float32).reshape(T, 1, n)
+            w = ops.gemm_nt(r, Linv, uplo_b=1)                                             # (L^-1 r)'
+            mean = self.mean_module(x).reshape(T, H) + ops.gemm_nt(G, w).reshape(T, H)
+            cov = _dense(self.covar_module(x, x)).reshape(T, H, H) - ops.gemm_nt(G, G)
+            if not batched:
+                mean, cov = mean[0], cov[0]
             return MultivariateNormal(mean, cov)

@@ -1,5 +1,4 @@
 from .BMGP import BMGP                                   # voltron/models/__init__.py:1-6 (hot-path subset)
 from .VoltronGP import VoltronGP
 from .single_task_variational_gp import SingleTaskVariationalGP
-from .BasicGPModels import MaternGP, SMGP
 from .VoltMagpie import VoltMagpie

@@ -97,6 +97,25 @@ class CholeskyFactor:
         return torch.tril(self.A[:, : self.n, : self.n])
 
 
+_POTRF_WS = {}
+
+
+def _potrf_workspace(B: int, Np: int, device):
+    """Caller-owned scratch of volt_potrf_ws_f32, one buffer per (device, stream, B, Np), reused across calls -- the
+    jitter ladder and the many small-matrix call sites would otherwise allocate up to 277 MB per call.  Calls that
+    share a buffer are ordered by their stream.  Returns (aligned pointer or None, bytes)."""
+    nbytes = int(_lib.lib().volt_potrf_workspace_bytes(B, Np))
+    if not nbytes:
+        return None, 0
+    key = (device.index, _lib.stream_ptr(), B, Np)
+    buf = _POTRF_WS.get(key)
+    if buf is None:
+        if len(_POTRF_WS) >= 8:                                 # a handful of shapes is what a run has; drop the oldest
+            _POTRF_WS.pop(next(iter(_POTRF_WS)))
+        buf = _POTRF_WS[key] = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    return ((buf.data_ptr() + 255) // 256) * 256, nbytes
+
+
 def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0.0) -> CholeskyFactor:
     """Batched Cholesky of K + (sigma2 + jitter) I.  K [B,N,N] fp32 or fp64 (only the lower triangle is read); the
     factor keeps K's dtype (fp32: volt_potrf_f32 on v_mfma_f32_32x32x2; fp64: volt_potrf_f64 on v_mfma_f64_16x16x4)."""
@@ -119,10 +138,8 @@ def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0
     _lib.check(prep(K.data_ptr(), K.stride(1), K.stride(0), s2.data_ptr() if s2 is not None else None,
                     float(jitter), A.data_ptr(), B, n, st), "volt_prepare")
     if K.dtype == torch.float32:
-        # scratch for the small-batch schedules (0 bytes from 32 matrices on); the caller owns it, the call does not retain it
-        nbytes = int(L.volt_potrf_workspace_bytes(B, Np))
-        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=K.device) if nbytes else None
-        wp = ((ws.data_ptr() + 255) // 256) * 256 if ws is not None else None
+        # scratch for the small-batch schedules (0 bytes above 64 matrices and below 3 block columns)
+        wp, nbytes = _potrf_workspace(B, Np, K.device)
         _lib.check(L.volt_potrf_ws_f32(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, wp, nbytes, st), "volt_potrf")
     else:
         _lib.check(L.volt_potrf_f64(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
@@ -136,8 +153,10 @@ def _pad_rhs(f: CholeskyFactor, rhs: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def trsv(f: CholeskyFactor, rhs: torch.Tensor, transpose: bool = False) -> torch.Tensor:
-    """L^-1 rhs (or L^-T rhs) in the factor's dtype.  rhs [B,N] -> [B,N].  One launch (csrc/trsv.hip)."""
+def trsv(f: CholeskyFactor, rhs: torch.Tensor, transpose: bool = False, check: bool = False) -> torch.Tensor:
+    """L^-1 rhs (or L^-T rhs) in the factor's dtype.  rhs [B,N] -> [B,N].  One launch (csrc/trsv.hip).
+    ``check`` reads the solve's error word back (a device synchronisation) and raises if a hand-off timed out --
+    without it a time-out is visible only as NaN in the result."""
     _need_gpu(rhs)
     r = _pad_rhs(f, rhs)
     out = torch.empty_like(r)
@@ -150,6 +169,8 @@ def trsv(f: CholeskyFactor, rhs: torch.Tensor, transpose: bool = False) -> torch
         fn = L.volt_trsv_lower_t_f64 if transpose else L.volt_trsv_lower_f64
     _lib.check(fn(f.A.data_ptr(), f.Winv.data_ptr(), r.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, Np,
                   _lib.stream_ptr()), "volt_trsv")
+    if check and int(scratch.view(torch.int32).reshape(-1)[1].item()) != 0:
+        raise _lib.VoltHipError("volt_trsv: a block hand-off timed out (the result holds NaN blocks)")
     return out[:, : f.n]
 
 

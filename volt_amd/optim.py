@@ -43,6 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._params, self._total = ps, end
         return True
 
+    def extra_state_tensors(self):
+        """State outside self.state (train_utils._Snapshot saves / restores it in place): the device step counter."""
+        return [] if self._params is None else [self._state]
+
     @torch.no_grad()
     def step(self, closure=None):
         if self._params is None and not self._build():

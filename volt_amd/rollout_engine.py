@@ -77,8 +77,8 @@ def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
     if solve != "factor":
         raise ValueError(f"unknown train-block solve {solve!r}")
     fct, _ = _safe_factor(ops.fill(U64), jitter)                 # psd_safe_cholesky(K_tr, 1e-4), :35, in fp64
-    q = ops.trsv(fct, U64)                                       # L^-1 u
-    ztr = ops.trsv(fct, r_tr.double())                           # L^-1 r_tr
+    q = ops.trsv(fct, U64, check=True)                           # L^-1 u
+    ztr = ops.trsv(fct, r_tr.double(), check=True)               # L^-1 r_tr
     return (q * q).sum(-1).contiguous(), (q * ztr).sum(-1).contiguous()
 
 

@@ -48,33 +48,33 @@ def _posterior_draw(covar_module, full_x, full_vol, idx_cut, train_diffs, test_m
     train_diffs [S,N,1] (or broadcastable); test_mean_term broadcastable to [S,T,1]; z [S,T,n].
     Returns samples + pred_mean, shape [S,T,n]."""
     cov_mat = covar_module(full_x.unsqueeze(-1), full_vol.unsqueeze(-1)).evaluate()        # :26  (HIP fill)
-    unb = cov_mat.ndim == 2
-    if unb:
+    if cov_mat.ndim == 2:
         cov_mat = cov_mat.unsqueeze(0)
     S = cov_mat.shape[0]
     T = cov_mat.shape[-1] - idx_cut
     K_tr = cov_mat[..., :idx_cut, :idx_cut]                                                # :27
-    K_tr_te = cov_mat[..., :idx_cut, idx_cut:]                                             # :28
+    K_te_tr = cov_mat[..., idx_cut:, :idx_cut]                                             # :28, transposed: rows = test points
     K_te = cov_mat[..., idx_cut:, idx_cut:]                                                # :29
     f, _ = _safe_factor(K_tr, jitter)                                                      # :35  (HIP potrf)
     td = train_diffs.reshape(-1, idx_cut) if train_diffs.ndim > 1 else train_diffs.reshape(1, idx_cut)
     td = td.expand(S, idx_cut)
     sol = ops.cholesky_solve(f, td)                                                        # :36
-    pred_mean = K_tr_te.transpose(-1, -2).matmul(sol.unsqueeze(-1))                        # [S,T,1]
+    # every product below runs on the library's own MFMA GEMM (volt_gemm_nt_f32), not on a vendor BLAS
+    dt = cov_mat.dtype
+    pred_mean = ops.gemm_nt(K_te_tr, sol.unsqueeze(1)).to(dt)                              # [S,T,1] = K_te,tr sol
     pred_mean = pred_mean + test_mean_term                                                 # :39
     if latent_mean is not None:
         pred_mean = pred_mean - theta * (pred_mean - latent_mean)                          # :41-42
     if T == 1:
-        sol2 = ops.cholesky_solve(f, K_tr_te[..., 0])                                      # :44
-        pred_cov = K_te - K_tr_te.transpose(-1, -2).matmul(sol2.unsqueeze(-1))
+        sol2 = ops.cholesky_solve(f, K_te_tr[..., 0, :])                                   # :44
+        pred_cov = K_te - (K_te_tr[..., 0, :] * sol2).sum(-1).reshape(S, 1, 1)
         pred_cov_L = _chol_1x1(pred_cov, jitter)                                           # :46
-    else:
-        Y = ops.trtri(f)                                                                   # L^-T
-        G = K_tr_te.transpose(-1, -2).matmul(Y)                                            # K_te,tr L^-T
-        pred_cov = K_te - G.matmul(G.transpose(-1, -2))
-        fc, _ = _safe_factor(pred_cov, jitter)
-        pred_cov_L = fc.L
-    return pred_cov_L.matmul(z) + pred_mean                                                # :48,:53
+        return pred_cov_L * z + pred_mean                                                  # :48,:53 (1x1 "matmul")
+    Linv = ops.trtri(f).mT.contiguous()                                                    # L^-1 (lower), rows K-contiguous
+    G = ops.gemm_nt(K_te_tr, Linv, uplo_b=1)                                               # K_te,tr L^-T   [S,T,N]
+    pred_cov = K_te - ops.gemm_nt(G, G).to(dt)
+    fc, _ = _safe_factor(pred_cov, jitter)
+    return ops.gemm_nt(fc.L, z.mT.contiguous(), uplo_a=1).to(dt) + pred_mean               # :48,:53
 
 
 def GeneratePrediction(train_x, train_y, test_x, pred_vol, model, latent_mean=None, theta=0.5, *, z=None):

@@ -1,122 +1,245 @@
-"""Training loops of the exact-GP data model -- drop-in for the two ★ loops of
-voltron/train_utils.py (TrainDataModel :98-144, TrainVoltMagpieModel :192-257).
+"""Training loops on the HIP path -- the ``voltron.train_utils`` surface for SURVEY 8 rows a5 (the exact-GP data
+model: TrainVoltMagpieModel :192-257, TrainDataModel :98-144), (f)1 (TrainVolModel :69-95) and (f)4 (LearnGPCV :15-67).
 
-The loop bodies are the reference's, statement for statement: ``optimizer.zero_grad(); output =
-voltron(train_x); loss = -mll(output, y); loss.backward(); optimizer.step()``.  What changes is
-what runs underneath: ``mll`` is volt_amd.gp.ExactMarginalLogLikelihood, one fused HIP step with
-an analytic backward.  LearnGPCV (:15-67, the variational GPCV stage) and TrainVolModel (:69-95) are here
-too, on the same library, and so is TrainBasicModel (:146-190, Matern / spectral-mixture baselines: dense
-d mll / d K from the HIP step, kernel derivatives by autograd).
-
-``TrainVoltMagpieBatch`` is an addition for the multi-series case the reference only loops over
-in Python (experiments/stocks/ForecastGenerator.py:27-41): B independent series in one batched
-step, optionally sharded over ranks with one all-reduce of the summed loss.
+Signatures, defaults, the set of trained parameters and the arithmetic of one iteration are the reference's; the code
+is organised differently: ONE loop driver (``_run_iterations``), ONE table of mean functions (``_MEANS``) and ONE
+exact-GP fit (``_fit_exact``) serve every entry point, and which parameters train is stated by role (the likelihood's
+noise and the mean module's own parameters; the vol forecaster stays frozen) -- the effect of the reference's positional
+``grad_flags`` (:199-227).  ``mll`` is volt_amd.gp.ExactMarginalLogLikelihood: one fused HIP step with an analytic
+backward.  ``TrainVoltMagpieBatch`` / ``TrainVolModelBatch`` fit B independent series in one batched model (the
+reference loops over tickers in Python, experiments/stocks/ForecastGenerator.py:27-41), optionally sharded over ranks
+with one all-reduce of the summed loss.
 """
 import os
+import warnings
 
 import torch
 
 from . import gp
 from .gp import ExactMarginalLogLikelihood, GaussianLikelihood
+from .means import DEWMAMean, EWMAMean, LogLinearMean, MeanRevertingEMAMean, TEWMAMean
+from .models import VoltMagpie, VoltronGP
+
+LR_DATA, LR_VOL, LR_GPCV = 0.1, 0.01, 0.01          # train_utils.py:238 / :81 / :43
+PRINT_EVERY = 50
+CHECK_EVERY = 25                                     # deferred loops: one host read of the info flags per this many iterations
 
 
+# ------------------------------------------------------------------------------------------------ mean functions
+def _loglinear(x, log_y, k, theta, bs):
+    m = LogLinearMean(1, batch_shape=bs)
+    m.initialize_from_data(x, log_y)                 # train_utils.py:102-103, :215-216
+    return m
+
+
+# name -> constructor(train_x, log_y, k, theta, batch_shape).  The moving-average family has no parameters; constant /
+# loglinear / linear means train theirs together with the noise (the True entries of the reference's grad_flags).
+_MEANS = {
+    "ewma": lambda x, y, k, th, bs: EWMAMean(x, y, k),
+    "dewma": lambda x, y, k, th, bs: DEWMAMean(x, y, k),
+    "tewma": lambda x, y, k, th, bs: TEWMAMean(x, y, k),
+    "meanrevert": lambda x, y, k, th, bs: MeanRevertingEMAMean(x, y, k, th),
+    "constant": lambda x, y, k, th, bs: gp.ConstantMean(batch_shape=bs),
+    "loglinear": _loglinear,
+    "linear": lambda x, y, k, th, bs: gp.LinearMean(1, batch_shape=bs),
+}
+
+
+def _set_mean(model, mean_func, train_x, log_y, k=25, theta=0.5, batch_shape=torch.Size()):
+    name = mean_func.lower()
+    if name not in _MEANS:
+        raise ValueError(f"unknown mean_func {mean_func!r}: one of {sorted(_MEANS)}")
+    model.mean_module = _MEANS[name](train_x, log_y, k, theta, batch_shape).to(train_x.device)
+
+
+def _train_noise_and_mean(model, lh, noise0=1e-5):
+    """raw_noise starts at 1e-5 (:222); only it and the mean module's parameters receive gradients."""
+    with torch.no_grad():
+        lh.raw_noise.fill_(noise0)
+    for p in model.parameters():
+        p.requires_grad = False
+    trainable = [lh.raw_noise] + list(model.mean_module.parameters())
+    for p in trainable:
+        p.requires_grad = True
+    return trainable
+
+
+# ------------------------------------------------------------------------------------------------ the loop driver
 def _adam(params, lr, graph):
-    """torch.optim.Adam as the reference builds it (eager loops); for the graph-captured loops the same update as two
-    launches with the step count on the device (optim.FusedAdam: torch's capturable Adam is 13 launches per step and
-    the iteration is launch-bound).  VOLT_TORCH_ADAM=1 keeps torch's in both."""
+    """torch.optim.Adam as the reference builds it; for graph-captured loops the same update as two launches with the
+    step count on the device (optim.FusedAdam: torch's capturable Adam is 13 launches per step and the iteration is
+    launch-bound).  VOLT_TORCH_ADAM=1 keeps torch's in both."""
     if graph and not os.environ.get("VOLT_TORCH_ADAM"):
         from .optim import FusedAdam
         return FusedAdam(params, lr=lr)
     return torch.optim.Adam(params, lr=lr, capturable=bool(graph))
 
 
-def _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=1.0, warm=3):
-    """The reference's loop body ``optimizer.zero_grad(); output = model(x); loss = -mll(output, y); loss.backward();
-    optimizer.step()`` (train_utils.py:243-254 and its siblings) run `train_iters` times.  ``iteration()`` does forward
-    + backward and returns the loss.
+class _Snapshot:
+    """Values of the parameters and of the optimiser's state tensors at one iteration; restored IN PLACE (a captured
+    graph and the optimiser keep their addresses)."""
 
-    graph=False: eagerly, statement for statement.  graph=True: the first `warm` iterations eagerly on a side stream,
-    then ONE iteration is captured into a hipGraph (torch.cuda.CUDAGraph: every HIP launch of the step, the torch glue
-    and the capturable Adam update) and replayed -- at the reference's sizes (N = 399) an iteration is ~10 short launches
-    plus ~0.4 ms of Python, i.e. launch-bound, and the replay removes the Python.  The per-step ``info`` read-back (a device
-    synchronisation) is deferred to one check after the loop (gp.deferred_checks)."""
-    print_every = 50
-    if not graph or train_iters <= warm + 1:
-        loss = None
-        for i in range(train_iters):
-            optimizer.zero_grad()
-            loss = iteration()
-            if printing and i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item() * scale))
-            optimizer.step()
-        return loss
-    with gp.deferred_checks() as chk:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for i in range(warm):
-                optimizer.zero_grad(set_to_none=True)
-                iteration()                                       # (no reference to the loss kept: the autograd graph dies here)
-                optimizer.step()
-        torch.cuda.current_stream().wait_stream(side)
+    def __init__(self, optimizer, it):
+        self.opt = optimizer
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.take(it)
+
+    def _state_tensors(self):
+        out = []
+        for p in self.params:
+            st = self.opt.state.get(p, {})
+            out += [v for _, v in sorted(st.items()) if torch.is_tensor(v)]
+        extra = getattr(self.opt, "extra_state_tensors", None)
+        return out + (extra() if extra else [])
+
+    def take(self, it):
+        self.it = it
+        self.live = [p.data for p in self.params] + self._state_tensors()
+        self.saved = [t.clone() for t in self.live]
+
+    def restore(self):
+        with torch.no_grad():
+            for t, s in zip(self.live, self.saved):
+                t.copy_(s)
+
+
+def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, scale=1.0, warm=3, defer=False):
+    """``train_iters`` times: zero_grad -> ``iteration()`` (forward + backward, returns the loss) -> print every 50th
+    -> optimizer.step() -- the body of train_utils.py:243-254 and its siblings.
+
+    Plain (graph=False, defer=False): eagerly, with the factorisation's ``info`` read back every step (a device
+    synchronisation) so that gpytorch's jitter ladder can run at once.
+    defer=True: the read-back moves to one check per CHECK_EVERY iterations (gp.deferred_checks); when a check finds a
+    failed factorisation the parameters and the optimiser state return to the last clean snapshot and those
+    iterations are replayed with the per-step check -- the trajectory is the plain loop's, without its host round trips.
+    graph=True: after `warm` eager iterations ONE iteration (every HIP launch of the step, the torch glue, the Adam
+    update) is captured into a hipGraph and replayed; a failed factorisation inside the replays is answered the same
+    way: restore the post-warm-up snapshot and finish eagerly with the ladder."""
+    loss = None
+
+    def one(i):
+        nonlocal loss
         optimizer.zero_grad(set_to_none=True)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            static_loss = iteration()
-            optimizer.step()
-        for i in range(warm, train_iters):                        # capturing records an iteration, it does not run it
-            g.replay()
-            if printing and i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, static_loss.item() * scale))
-        chk.raise_if_bad()
-    return static_loss
-from .means import LogLinearMean, EWMAMean, DEWMAMean, TEWMAMean, MeanRevertingEMAMean
-from .models import VoltronGP, VoltMagpie
+        loss = iteration()
+        if printing and i % PRINT_EVERY == 0:
+            print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item() * scale))
+        optimizer.step()
+
+    if (not graph and not defer) or train_iters <= warm + 1:
+        for i in range(train_iters):
+            one(i)
+        return loss
+
+    with gp.deferred_checks(immediate=True) as chk:
+        # warm-up with the per-step check: creates the optimiser state, sizes the deferred accumulators
+        side = torch.cuda.Stream() if graph else None
+        if graph:
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side) if graph else _null():
+            for i in range(warm):
+                one(i)
+        if graph:
+            torch.cuda.current_stream().wait_stream(side)
+        snap = _Snapshot(optimizer, warm)
+        chk.immediate = False
+
+        def replay_eagerly(lo, hi):
+            snap.restore()
+            chk.clear()
+            chk.immediate = True
+            for j in range(lo, hi):
+                one(j)
+            chk.immediate = False
+
+        if graph:
+            loss = None                                               # let the warm-up's autograd graph die before capture
+            optimizer.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_loss = iteration()
+                optimizer.step()
+            for i in range(warm, train_iters):                        # capturing records an iteration, it does not run it
+                g.replay()
+                if printing and i % PRINT_EVERY == 0:
+                    print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, static_loss.item() * scale))
+            loss = static_loss
+            if chk.any_bad():
+                warnings.warn("a factorisation failed inside the captured loop: rerunning it eagerly with the jitter ladder",
+                              gp.NumericalWarning)
+                replay_eagerly(warm, train_iters)
+            return loss
+        i = warm
+        while i < train_iters:
+            hi = min(i + CHECK_EVERY, train_iters)
+            for j in range(i, hi):
+                one(j)
+            if chk.any_bad():                                         # the only host read of this stretch
+                replay_eagerly(snap.it, hi)
+            if hi < train_iters:
+                snap.take(hi)
+            i = hi
+    return loss
 
 
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=False, defer=False, batched=False,
+               post_backward=None, scale=1.0):
+    """Adam on -mll(model(train_x), target); a batched model's per-series losses are summed for ONE backward (the
+    series are independent and Adam is elementwise, so every series gets its own loop's update)."""
+    model.train()
+    lh.train()
+    optimizer = _adam([{'params': params}], lr, graph)
+    mll = ExactMarginalLogLikelihood(lh, model)
+    last = {}
+
+    def iteration():
+        losses = -mll(model(train_x), target)
+        loss = losses.sum() if batched else losses
+        loss.backward()
+        last["losses"] = losses.detach()
+        if post_backward is not None:
+            return post_backward(loss)
+        return loss
+
+    _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=scale, defer=defer)
+    return last.get("losses")
+
+
+# ------------------------------------------------------------------------------------------------ (f)4: GPCV
 def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", graph=False):
-    """The fit of LearnGPCV (train_utils.py:15-58) returning what it builds: (model, likelihood, losses)."""
+    """The fit inside LearnGPCV (train_utils.py:15-58), returning what it builds: (model, likelihood, losses)."""
     from .kernels import BMKernel, FBMKernel
     from .likelihoods import VolatilityGaussianLikelihood
     from .models import SingleTaskVariationalGP
     from .variational import VariationalELBO, num_gauss_hermite_locs
     dt = train_x[1] - train_x[0]
-    scaled_returns = (train_y[..., 1:] - train_y[..., :-1]) / (train_y[..., :-1]) / (dt ** 0.5)
-    yy = scaled_returns
-    batch_shape = yy.shape[:-1]
-
+    yy = (train_y[..., 1:] - train_y[..., :-1]) / train_y[..., :-1] / dt ** 0.5        # scaled returns, :16-18
+    kw = {"batch_shape": yy.shape[:-1]} if yy.ndim > 1 else {}
     likelihood = VolatilityGaussianLikelihood(param="exp")
-    kw = {"batch_shape": batch_shape} if len(batch_shape) else {}
-    if kernel == "bm":
-        covar_module = BMKernel(**kw)
-    elif kernel == "fbm":
-        covar_module = FBMKernel(**kw)
-    model = SingleTaskVariationalGP(
-        init_points=train_x.view(-1, 1), likelihood=likelihood, use_piv_chol_init=False,
-        mean_module=gp.ConstantMean(**kw), covar_module=covar_module,
-        learn_inducing_locations=False, use_whitened_var_strat=False
-    )
+    covar_module = {"bm": BMKernel, "fbm": FBMKernel}[kernel](**kw)
+    model = SingleTaskVariationalGP(init_points=train_x.view(-1, 1), likelihood=likelihood, use_piv_chol_init=False,
+                                    mean_module=gp.ConstantMean(**kw), covar_module=covar_module,
+                                    learn_inducing_locations=False, use_whitened_var_strat=False)
     model.initialize_variational_parameters(likelihood, train_x, y=yy)
-
     model.train()
     likelihood.train()
-
-    optimizer = _adam([
-        {"params": model.parameters()},
-    ], 0.01, graph)
-
-    mll = VariationalELBO(likelihood, model, yy.shape[-1], combine_terms=True)
-
+    optimizer = _adam([{"params": model.parameters()}], LR_GPCV, graph)
+    elbo = VariationalELBO(likelihood, model, yy.shape[-1], combine_terms=True)
     losses = []
 
-    def iteration():                                     # train_utils.py:50-54
+    def iteration():                                     # :50-54
         with num_gauss_hermite_locs(75):
-            output = model(train_x)
-            loss = -mll(output, yy)
+            loss = -elbo(model(train_x), yy)
             if not graph:
                 losses.append(loss.detach())
-            if loss.ndim:
-                loss = loss.sum()                      # independent series: one backward for all of them
+            loss = loss.sum() if loss.ndim else loss     # independent series: one backward for all of them
             loss.backward()
         return loss
 
@@ -129,238 +252,106 @@ def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", gra
 
 
 def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping=False, kernel="bm", graph=False):
-    """voltron/train_utils.py:15-67 -- SURVEY 8(f) row 4: extract the volatility path from prices by fitting a
-    variational GP (BM or FBM prior over log-vol, ``y | f ~ N(0, exp f)``) to the scaled returns.  Same statements
-    as the reference; ``mll`` is volt_amd.variational.VariationalELBO, one HIP step per iteration.
+    """voltron/train_utils.py:15-67: the volatility path of a price series from a variational GP (BM or FBM prior over
+    log-vol, ``y | f ~ N(0, exp f)``) fitted to the scaled returns; one HIP ELBO step per iteration.
     train_y [N+1] prices -> pred_scale [N]; train_y [T,N+1] fits T series at once (batched parameters)."""
     model, likelihood, _ = FitGPCV(train_x, train_y, train_iters=train_iters, printing=printing, kernel=kernel, graph=graph)
-    predictive = model(train_x)
-    pred_scale = likelihood(predictive, return_gaussian=False).scale.mean(0).detach()
+    return likelihood(model(train_x), return_gaussian=False).scale.mean(0).detach()      # :60-67
 
-    return pred_scale
+
+# ------------------------------------------------------------------------------------------------ (f)1: vol forecaster
+def _vol_model(train_x, vol_path, kernel, batch_shape):
+    from .models import BMGP
+    vol_lh = GaussianLikelihood(batch_shape=batch_shape).to(train_x.device)
+    # (the reference's `vol_lh.noise.data = 1e-2` at :71 writes to a temporary: the noise starts at softplus(0) + 1e-4)
+    return BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device), vol_lh
 
 
 def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=False):
-    """voltron/train_utils.py:69-95 -- SURVEY 8(f) row 1: the Brownian-motion GP over log-vol that later
-    supplies pred_vol to Rollouts.  Same loop; the MLL and its gradient wrt the kernel's `vol` and the
-    noise run on the HIP path (K = vol * min(x,x') keeps d mll / d vol in closed form, gp._ExactMLL).
-    Quirk kept: `vol_lh.noise.data = ...` (:71) assigns to a temporary in the reference and changes
-    nothing, so the noise starts at softplus(0) + 1e-4."""
-    from .models import BMGP
-    vol_lh = GaussianLikelihood().to(train_x.device)
-    vol_lh.noise.data = torch.tensor([1e-2])          # no-op, as in the reference
-    vol_model = BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device)
-
-    optimizer = _adam([{'params': vol_model.parameters()}], 0.01, graph)
-    mll = ExactMarginalLogLikelihood(vol_lh, vol_model)
-    log_vol = vol_path.log()
-
-    def iteration():                                     # train_utils.py:84-88
-        output = vol_model(train_x)
-        loss = -mll(output, log_vol)
-        loss.backward()
-        return loss
-
-    _run_iterations(iteration, optimizer, train_iters, printing, graph)
+    """voltron/train_utils.py:69-95: the Brownian-motion GP over log-vol that supplies pred_vol to Rollouts.  The MLL
+    and its gradient wrt the kernel's `vol` and the noise run on the HIP step (K = vol * min(x,x') keeps d mll / d vol
+    in closed form, gp._ExactMLL)."""
+    vol_model, vol_lh = _vol_model(train_x, vol_path, kernel, torch.Size())
+    _fit_exact(vol_model, vol_lh, train_x, vol_path.log(), list(vol_model.parameters()), LR_VOL, train_iters, printing, graph)
     return vol_model, vol_lh
 
 
 def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=False):
-    """TrainVolModel for T series at once: vol_path [T,N] -> one batched BMGP (per-series kernel parameter and noise).
-    The series are independent, so the summed loss gives every series exactly the gradient its own TrainVolModel
-    loop would (Adam is elementwise)."""
-    from .models import BMGP
+    """TrainVolModel for T series at once: vol_path [T,N] -> one batched BMGP (per-series kernel parameter and noise)."""
     T = vol_path.shape[0]
-    vol_lh = GaussianLikelihood(batch_shape=torch.Size([T])).to(train_x.device)
-    vol_model = BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device)
-    optimizer = _adam([{'params': vol_model.parameters()}], 0.01, graph)
-    mll = ExactMarginalLogLikelihood(vol_lh, vol_model)
-    log_vol = vol_path.log()
-
-    def iteration():
-        output = vol_model(train_x)
-        loss = -mll(output, log_vol).sum()
-        loss.backward()
-        return loss
-
-    _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=1.0 / T)
+    vol_model, vol_lh = _vol_model(train_x, vol_path, kernel, torch.Size([T]))
+    _fit_exact(vol_model, vol_lh, train_x, vol_path.log(), list(vol_model.parameters()), LR_VOL, train_iters, printing, graph,
+               defer=not graph, batched=True, scale=1.0 / T)
     return vol_model, vol_lh
 
 
-def TrainBasicModel(train_x, train_y, train_iters=1000, printing=False, model_type="matern", num_mixtures=10,
-                    mean_func="loglinear"):
-    """voltron/train_utils.py:146-190 -- SURVEY 8(f) row 2: the Matern / spectral-mixture baselines on log prices."""
-    from .models import MaternGP, SMGP
-    lh = GaussianLikelihood()
-
-    if model_type == "matern":
-        model = MaternGP(train_x, train_y.log(), lh)
-    else:
-        model = SMGP(train_x, train_y.log(), lh, num_mixtures)
-
-    if mean_func == "loglinear":
-        model.mean_module = LogLinearMean(1)
-        model.mean_module.register_prior("slope_prior", gp.NormalPrior(0, 0.1), 'weights')
-        model.mean_module.initialize_from_data(train_x, train_y.log())
-
-    model.likelihood.raw_noise.data = torch.tensor([1e-5])
-    model = model.to(train_x.device)
-    model.train()
-    lh.train()
-
-    optimizer = torch.optim.Adam([{'params': model.parameters()}], lr=0.1)
-    mll = ExactMarginalLogLikelihood(lh, model)
-    print_every = 50
-    for i in range(train_iters):
-        optimizer.zero_grad()
-        output = model(train_x)
-        loss = -mll(output, train_y.log())
-        loss.backward()
-        if printing:
-            if i % print_every == 0:
-                print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, loss.item()))
-        optimizer.step()
-
-    return model, lh
+# ------------------------------------------------------------------------------------------------ a5: the data model
+def _attach_vol(model, vol_model, vol_lh, dev):
+    if vol_lh is not None:
+        model.vol_lh = vol_lh.to(dev)
+    if vol_model is not None:
+        model.vol_model = vol_model.to(dev)
 
 
 def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, graph=False):
-    voltron_lh = GaussianLikelihood().to(train_x.device)
-    voltron = VoltronGP(train_x, train_y.log(), voltron_lh, vol_path)
-    voltron.mean_module = LogLinearMean(1).to(train_x.device)
-    voltron.mean_module.initialize_from_data(train_x, train_y.log())
-    voltron.likelihood.raw_noise.data = torch.tensor([1e-5]).to(train_x.device)
-    voltron.vol_lh = vol_lh
-    voltron.vol_model = vol_model
-
-    grad_flags = [True, True, True, False, False, False]
-
-    for idx, p in enumerate(voltron.parameters()):
-        p.requires_grad = grad_flags[idx]
-
-    voltron.train()
-    voltron_lh.train()
-
-    optimizer = _adam([{'params': voltron.parameters()}], 0.1, graph)
-    mll = ExactMarginalLogLikelihood(voltron_lh, voltron)
+    """voltron/train_utils.py:98-144: VoltronGP with a log-linear mean; noise, slope and intercept train."""
+    dev = train_x.device
     log_y = train_y.log()
-
-    def iteration():                                     # train_utils.py:245-250
-        output = voltron(train_x)
-        loss = -mll(output, log_y)
-        loss.backward()
-        return loss
-
-    _run_iterations(iteration, optimizer, train_iters, printing, graph)
-    return voltron, voltron_lh
+    lh = GaussianLikelihood().to(dev)
+    model = VoltronGP(train_x, log_y, lh, vol_path)
+    _set_mean(model, "loglinear", train_x, log_y)
+    _attach_vol(model, vol_model, vol_lh, dev)
+    params = _train_noise_and_mean(model, lh)
+    _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph)
+    return model, lh
 
 
 def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, k=25,
                          theta=0.5, mean_func="ewma", graph=False):
-    voltron_lh = GaussianLikelihood().to(train_x.device)
-    voltron = VoltMagpie(train_x, train_y.log(), voltron_lh, vol_path, k=k).to(train_x.device)
-
-    if mean_func.lower() in ["ewma", "dewma", "tewma", "meanrevert"]:
-        # default voltmagpie is an ewma mean so we don't need to redefine anything
-        grad_flags = [True, False, False, False]
-
-        if mean_func.lower() == "dewma":
-            voltron.mean_module = DEWMAMean(train_x, train_y.log(), k).to(train_x.device)
-        elif mean_func.lower() == 'tewma':
-            voltron.mean_module = TEWMAMean(train_x, train_y.log(), k).to(train_x.device)
-        elif mean_func.lower() == 'meanrevert':
-            voltron.mean_module = MeanRevertingEMAMean(train_x, train_y.log(), k, theta).to(train_x.device)
-
-    elif mean_func.lower() == 'constant':
-        voltron.mean_module = gp.ConstantMean().to(train_x.device)
-        grad_flags = [True, True, False, False, False]
-    elif mean_func.lower() == 'loglinear':
-        voltron.mean_module = LogLinearMean(1).to(train_x.device)
-        voltron.mean_module.initialize_from_data(train_x, train_y.log())
-        grad_flags = [True, True, True, False, False, False]
-    elif mean_func.lower() == 'linear':
-        voltron.mean_module = gp.LinearMean(1).to(train_x.device)
-        grad_flags = [True, True, True, False, False, False]
-
-    voltron.likelihood.raw_noise.data = torch.tensor([1e-5]).to(train_x.device)
-    if vol_lh is not None:
-        voltron.vol_lh = vol_lh.to(train_x.device)
-    if vol_model is not None:
-        voltron.vol_model = vol_model.to(train_x.device)
-
-    for idx, p in enumerate(voltron.parameters()):
-        p.requires_grad = grad_flags[idx]
-
-    voltron.train()
-    voltron_lh.train()
-
-    optimizer = _adam([{'params': voltron.parameters()}], 0.1, graph)
-    mll = ExactMarginalLogLikelihood(voltron_lh, voltron)
+    """voltron/train_utils.py:192-257: VoltMagpie with the chosen mean; the noise (and a constant / (log)linear mean's
+    parameters) train, the vol forecaster rides along frozen."""
+    dev = train_x.device
     log_y = train_y.log()
-
-    def iteration():                                     # train_utils.py:245-250
-        output = voltron(train_x)
-        loss = -mll(output, log_y)
-        loss.backward()
-        return loss
-
-    _run_iterations(iteration, optimizer, train_iters, printing, graph)
-    return voltron, voltron_lh
+    lh = GaussianLikelihood().to(dev)
+    model = VoltMagpie(train_x, log_y, lh, vol_path, k=k).to(dev)
+    if mean_func.lower() != "ewma":                                   # VoltMagpie's own mean is the EWMA
+        _set_mean(model, mean_func, train_x, log_y, k, theta)
+    _attach_vol(model, vol_model, vol_lh, dev)
+    params = _train_noise_and_mean(model, lh)
+    _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph)
+    return model, lh
 
 
 def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, printing=False, process_group=None,
-                         shared_noise=False, mean_func="ewma", theta=0.5):
-    """B independent series in one batched model (train_y [B,N] raw prices[1:], vol_path [B,N]).
-    Per-series raw_noise by default (each series is its own GP, as in the reference's Python loop over
-    tickers); ``shared_noise`` ties one likelihood across series AND ranks, whose gradient is then
-    all-reduced.  ``mean_func`` as in TrainVoltMagpieModel (train_utils.py:199-219): the EWMA family has
-    no trainable parameters; 'constant' / 'loglinear' / 'linear' get one parameter set PER SERIES (batch_shape [B]),
-    trained with the noise like the reference's grad_flags say.  Returns (model, likelihood, last per-series losses)."""
+                         shared_noise=False, mean_func="ewma", theta=0.5, graph=False, defer=True):
+    """B independent series in one batched model (train_y [B,N] raw prices[1:], vol_path [B,N]).  Per-series raw_noise
+    by default (each series is its own GP, as in the reference's loop over tickers); ``shared_noise`` ties one
+    likelihood across series AND ranks, whose gradient is then all-reduced.  ``mean_func`` as in
+    TrainVoltMagpieModel; constant / loglinear / linear means get one parameter set PER SERIES.  The per-step ``info``
+    read-back is deferred (``defer``, see _run_iterations); ``graph=True`` captures the iteration (single process only).
+    Returns (model, likelihood, last per-series losses)."""
     from . import distributed as vdist
     B = train_y.shape[0]
     dev = train_x.device
+    log_y = train_y.log()
     lh = GaussianLikelihood(batch_shape=torch.Size() if shared_noise else torch.Size([B])).to(dev)
-    model = VoltMagpie(train_x, train_y.log(), lh, vol_path, k=k).to(dev)
-    mf = mean_func.lower()
-    trainable = []
-    if mf == "dewma":
-        model.mean_module = DEWMAMean(train_x, train_y.log(), k).to(dev)
-    elif mf == "tewma":
-        model.mean_module = TEWMAMean(train_x, train_y.log(), k).to(dev)
-    elif mf == "meanrevert":
-        model.mean_module = MeanRevertingEMAMean(train_x, train_y.log(), k, theta).to(dev)
-    elif mf == "constant":
-        model.mean_module = gp.ConstantMean(batch_shape=torch.Size([B])).to(dev)
-    elif mf == "loglinear":
-        model.mean_module = LogLinearMean(1, batch_shape=torch.Size([B])).to(dev)
-        model.mean_module.initialize_from_data(train_x, train_y.log())
-    elif mf == "linear":
-        model.mean_module = gp.LinearMean(1, batch_shape=torch.Size([B])).to(dev)
-    elif mf != "ewma":
-        raise ValueError(f"unknown mean_func {mean_func!r}")
-    lh.raw_noise.data.fill_(1e-5)
-    for p in model.parameters():
-        p.requires_grad = False
-    lh.raw_noise.requires_grad = True
-    if mf in ("constant", "loglinear", "linear"):
-        trainable = list(model.mean_module.parameters())
-        for p in trainable:
-            p.requires_grad = True
-    model.train()
-    optimizer = torch.optim.Adam([lh.raw_noise] + trainable, lr=0.1)
-    mll = ExactMarginalLogLikelihood(lh, model)
-    losses = None
-    for i in range(train_iters):
-        optimizer.zero_grad()
-        output = model(train_x)
-        losses = -mll(output, train_y.log())
-        loss = losses.sum()
-        loss.backward()
-        total = vdist.all_reduce_scalars(torch.stack([loss.detach(), torch.tensor(float(B), device=loss.device)]),
-                                         process_group)
+    model = VoltMagpie(train_x, log_y, lh, vol_path, k=k).to(dev)
+    if mean_func.lower() != "ewma":
+        _set_mean(model, mean_func, train_x, log_y, k, theta, torch.Size([B]))
+    params = _train_noise_and_mean(model, lh)
+    distributed = vdist._dist() is not None and vdist._dist().get_world_size(process_group) > 1
+    if graph and distributed:
+        raise ValueError("TrainVoltMagpieBatch: graph=True is for single-process runs (the all-reduce stays eager)")
+    count = torch.tensor(float(B), device=dev)
+
+    def reduce(loss):                                     # the path's one collective: summed loss (and a shared gradient)
+        if not distributed:
+            return loss.detach() / B
+        total = vdist.all_reduce_scalars(torch.stack([loss.detach(), count]), process_group)
         if shared_noise:
             vdist.all_reduce_(lh.raw_noise.grad, process_group)
-        if printing and i % 50 == 0:
-            print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, (total[0] / total[1]).item()))
-        optimizer.step()
-    return model, lh, (None if losses is None else losses.detach())      # train_iters = 0 (GPGenerator.py:89-92)
+        return total[0] / total[1]
+
+    losses = _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph, defer=defer and not graph,
+                        batched=True, post_backward=reduce)
+    return model, lh, losses                                          # None for train_iters = 0 (GPGenerator.py:89-92)

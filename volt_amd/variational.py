@@ -133,8 +133,11 @@ class _GPCVElbo(torch.autograd.Function):
         ws = holder.workspace(B, n, want_dk, m.device)
         ops.gpcv_step(K.detach(), (m - mean).detach(), m.detach(), Lq.detach(), y, gh_x, gh_w, ws, want_dk=want_dk,
                       jitter=PRIOR_JITTER, min_var=MIN_VARIANCE, w_ell=w_ell, w_kl=w_kl)
-        if gp.deferred_checks._active is not None:
-            gp.deferred_checks._active.note(ws.info)
+        chk = gp.deferred_checks.deferring()
+        if chk is None and gp.deferred_checks._active is not None:
+            gp.deferred_checks._active.reserve(ws.info)
+        if chk is not None:
+            chk.note(ws.info)
         elif bool((ws.info != 0).any().item()):
             if torch.isnan(K).any() or torch.isnan(m).any() or torch.isnan(Lq).any():
                 raise NanError("GPCV step: NaN in the prior covariance or the variational parameters")
