@@ -34,7 +34,7 @@ extern "C" {
  * and the launch counts:
  *   [0] factor_step_kernel with a factorisation part (diagonal tile + look-ahead + panel tiles (update + solve) +
  *       trtri row k-1 in one grid, k = 0 .. n-1)          [1] factor_step_kernel carrying only the last trtri row.
- * workspace: as for the MLL step (volt_mll_workspace_bytes(B, N, 1) bytes, 256-byte aligned). */
+ * workspace: as for the MLL step with want_grad = 1 (its workspace query, 256-byte aligned). */
 int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
                           void* workspace, int* info, int B, int N, int groups, void* stream,
                           float* ms_sum_host /*[2]*/, float* ms_union_host /*[2]*/, int* launches_host /*[2]*/,
