@@ -338,6 +338,11 @@ def main():
     if rank == 0 and not args.no_rollouts and not args.no_aux_legs:
         roll = rollout_leg(x, F, vol, dev, n)
 
+    # ---- API leg (rank 0, N=1): what a caller of the drop-in surface pays per iteration
+    api = None
+    if rank == 0 and world == 1 and not args.no_aux_legs:
+        api = api_leg(x, F, vol, dev, n, B, dt / args.steps * 1e3)
+
     # ---- CPU baseline leg (rank 0, N=1 only): torch-CPU restatement of the gpytorch path (+ real gpytorch if present)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -367,6 +372,7 @@ def main():
             "schedule": {"groups": (roof or {}).get("launches", 0) // max(1, (roof or {}).get("lockstep", {}).get("launches", 1)),
                          "streams": "library-internal, forked/joined on the caller's stream"},
             "cpu_baseline": cpu,
+            "api_step": api,
             "rollouts": roll,
         }
         line.update(extra)
@@ -376,11 +382,44 @@ def main():
         dist.destroy_process_group()
 
 
+def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):
+    """The drop-in surface at the metric size: one iteration of TrainVoltMagpieBatch -- ``loss = -mll(model(x), y);
+    loss.backward(); optimizer.step()``, voltron/train_utils.py:243-254 -- for B series of length n, per iteration as
+    the difference of two runs (t2 vs t1 iterations: construction and the one-off fill cancel).  eager = the loop with
+    the factorisation's info check deferred (the default of the batched loop); eager_per_step_check = with the host
+    read-back every step, as a literal gpytorch loop does; graph = one captured iteration replayed."""
+    from volt_amd.train_utils import TrainVoltMagpieBatch
+    tx = torch.tensor(x, device=dev)
+    prices = torch.tensor(F[:B, 1:], device=dev)
+    v = torch.tensor(vol[:B], device=dev)
+
+    def run(iters, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        TrainVoltMagpieBatch(tx, prices, v, train_iters=iters, k=EWMA_K, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    out = {"workload": f"TrainVoltMagpieBatch iteration, {B} x N={n}, EWMA(k={EWMA_K}) mean, Adam on raw_noise [B]",
+           "raw_op_ms_per_step": round(raw_ms, 3), "iterations": [t1, t2]}
+    for mode, kw in (("eager", {}), ("eager_per_step_check", {"defer": False}), ("graph", {"graph": True})):
+        run(t1, **kw)                                  # warm: allocator, schedule tables, graph pools
+        a = min(run(t1, **kw) for _ in range(2))
+        b = min(run(t2, **kw) for _ in range(2))
+        ms = (b - a) / (t2 - t1) * 1e3
+        out[mode] = {"ms_per_step": round(ms, 3), "overhead_vs_raw_op": round(ms / raw_ms - 1.0, 4)}
+    return out
+
+
 def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
     """BASELINE config 5 (10k sample paths x 256-step horizon, 64 series over 8 GPUs) at its per-GPU share: 8 series.
-    Times the whole engine call (host preparation + the one kernel launch) and the kernel alone (events on the
-    launch stream).  The kernel is HBM-bound: every step streams the sample's stored factor rows,
-    H^3/6 * 4 bytes per sample in total."""
+    The engine as shipped: per-sample bordered factor extended by ONE entry per step (the volatility kernel's
+    cross-covariance prefix is step-invariant), train block through the closed form K^-1 u = e_last ("closed") or
+    through the reference's own route -- fp64 factorisation of the noise-free train block + two solves,
+    rollout_utils.py:35-36 ("factor": that work is inside its total).  Algorithmic HBM bytes of the kernel: pred_vol and
+    z read, samples written = 12 B per sample-step.  `resubstitute` = the same paths with every sample's triangular
+    system re-solved from its stored rows at every step, the round-2 engine: H^3/6 * 4 B per path that an append-only
+    w_s does not need -- reported as `redundant_bytes`, credited to nothing."""
     from volt_amd import rollout_engine as re_
     from volt_amd.synthetic import rollout_inputs
     G = min(G, F.shape[0])
@@ -390,27 +429,47 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
     logy = torch.log(torch.tensor(F[:G, 1:], device=dev))
     lv = torch.log(torch.tensor(vol[:G], device=dev))
     pvd, zd = torch.tensor(pv, device=dev), torch.tensor(z, device=dev)
-    best_total, best_kernel, info = None, None, None
-    for rep in range(3):
-        tm = {}
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        samples, info = re_.rollout_series(tx, logy, lv, test_x, pvd, zd, 0, EWMA_K, timing=tm)
-        torch.cuda.synchronize()
-        tot = time.perf_counter() - t0
-        ker = tm["start"].elapsed_time(tm["stop"]) * 1e-3
-        if rep and (best_total is None or tot < best_total):
-            best_total, best_kernel = tot, ker
-    alg = G * S * H ** 3 / 6 * 4
-    out = {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5, per-GPU share)",
-           "total_s": round(best_total, 4), "kernel_ms": round(best_kernel * 1e3, 2),
-           "sample_steps_per_s": round(G * S * H / best_total),
-           "non_pd_paths": int((info != 0).sum().item()),
-           "roofline": {"kernel": "rollout_bordered_kernel", "bound": "hbm", "achieved": round(alg / best_kernel / 1e9, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / best_kernel / 1e9 / HBM_PEAK_GBS, 4),
-                        "algorithmic_GB": round(alg / 1e9, 1)}}
-    del samples
-    return out
+
+    def run(**kw):
+        best_total, best_kernel, info = None, None, None
+        for rep in range(3):
+            tm = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            samples, info = re_.rollout_series(tx, logy, lv, test_x, pvd, zd, 0, EWMA_K, timing=tm, **kw)
+            torch.cuda.synchronize()
+            tot = time.perf_counter() - t0
+            ker = tm["start"].elapsed_time(tm["stop"]) * 1e-3
+            if rep and (best_total is None or tot < best_total):
+                best_total, best_kernel = tot, ker
+        bad = int((info != 0).sum().item())
+        return best_total, best_kernel, bad, samples
+
+    tot_c, ker_c, bad_c, smp_c = run(solve="closed")
+    tot_f, ker_f, bad_f, smp_f = run(solve="factor")
+    dev_cf = float((smp_c - smp_f).abs().max().item())
+    del smp_f
+    tot_r, ker_r, bad_r, smp_r = run(solve="closed", resubstitute=True)
+    same = bool(torch.equal(smp_c, smp_r))
+    del smp_r, smp_c
+    alg = G * S * H * 12.0
+    red = G * S * H ** 3 / 6 * 4
+    return {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5, per-GPU share); append-only bordered "
+                        "engine, train block by the closed form (value) and by the fp64 factorisation (factor_route)",
+            "total_s": round(tot_c, 5), "kernel_ms": round(ker_c * 1e3, 3),
+            "sample_steps_per_s": round(G * S * H / tot_c), "non_pd_paths": bad_c,
+            "factor_route": {"total_s": round(tot_f, 5), "kernel_ms": round(ker_f * 1e3, 3),
+                             "sample_steps_per_s": round(G * S * H / tot_f), "non_pd_paths": bad_f,
+                             "max_abs_dev_from_closed": dev_cf,
+                             "includes": f"volt_potrf_f64 of {G} x {n}^2 + two fp64 triangular solves per series"},
+            "roofline": {"kernel": "rollout_bordered_kernel<1,false>", "bound": "hbm", "achieved": round(alg / ker_c / 1e9, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ker_c / 1e9 / HBM_PEAK_GBS, 4),
+                         "algorithmic_GB": round(alg / 1e9, 3),
+                         "note": "one wave per path, H dependent steps each: latency-bound, not bandwidth-bound"},
+            "resubstitute": {"total_s": round(tot_r, 5), "kernel_ms": round(ker_r * 1e3, 3), "non_pd_paths": bad_r,
+                             "bitwise_equal_to_default": same, "redundant_bytes": int(red),
+                             "streamed_GBps": round(red / ker_r / 1e9, 1),
+                             "frac_of_hbm_peak_on_redundant_bytes": round(red / ker_r / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
 def _cpu_worker(idx, threads, Kc, yc, mc, reps, barrier, q):

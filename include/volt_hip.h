@@ -124,16 +124,22 @@ int volt_trsv_lower_t_f64(const double* A, const double* Winv, const double* rhs
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream);
 
 /* ---- a7/a8: sequential posterior rollouts  (voltron/rollout_utils.py:57-93 + :6-53) ----------
- * Bordered-Cholesky engine: the host factors the shared train block once per series (volt_potrf)
- * and passes rho = u'K^-1u, tau = u'K^-1 r_tr; this launch walks all H horizon steps for every
- * sample path: dense per-sample factor rows in `scratch`, full forward substitution per step, EWMA-
- * family mean of the appended point (mean_mode 0 ewma / 1 dewma / 2 tewma / 3 meanrevert, EWMA.py),
- * optional mean reversion (:41-42), jitter ladder of psd_safe_cholesky(pred_cov, jitter) (:46).
- * G series x S samples x H steps (H <= 256).  hist_* [G,k] are the last k values of the (padded)
- * train series / its EMA / EMA(EMA); acc0 [G] the CumTrapz running sum through the last train
- * point; rho, tau, acc0 are fp64 (the kernel works with acc - rho, which fp32 operands would cancel away).  pred_vol, z, samples [G,S,H]; info [G,S]: 0; +step (1-based) of the first non-positive pivot of the
- * per-sample factor (a local jitter was applied); -step if the predictive variance stayed <= 0 after the
+ * Bordered-Cholesky engine: the shared train block of every sample's matrix enters through two scalars per series,
+ * rho = u'K^-1u and tau = u'K^-1 r_tr (the host gets them in closed form or from the fp64 factorisation,
+ * volt_amd/rollout_engine.py); this launch walks all H horizon steps for every sample path: the sample's bordered
+ * factor grown row by row, EWMA-family mean of the appended point (mean_mode 0 ewma / 1 dewma / 2 tewma /
+ * 3 meanrevert, EWMA.py), optional mean reversion (:41-42), jitter ladder of psd_safe_cholesky(pred_cov, jitter) (:46).
+ * G series x S samples x H steps, H <= VOLT_ROLLOUT_MAX_H.
+ *   scratch == NULL  append-only solve: for the volatility kernel the right-hand side prefix and the stored rows
+ *                    are step-invariant, so w_s only grows by one entry per step; nothing is stored or re-read.
+ *   scratch != NULL  (volt_rollout_scratch_bytes(G,S,H) bytes) full forward substitution against the stored packed
+ *                    rows at every step -- bitwise the same paths, H^3/6 * 4 B streamed per path; the cross-check.
+ * hist_* [G,k] are the last k values of the (padded) train series / its EMA / EMA(EMA); acc0 [G] the CumTrapz running
+ * sum through the last train point; rho, tau, acc0 are fp64 (the kernel works with acc - rho, which fp32 operands
+ * would cancel away).  pred_vol, z, samples [G,S,H]; info [G,S]: 0; +step (1-based) of the first non-positive pivot
+ * of the per-sample factor (a local jitter was applied); -step if the predictive variance stayed <= 0 after the
  * jitter ladder (the reference's psd_safe_cholesky raises NotPSDError there). */
+#define VOLT_ROLLOUT_MAX_H 1024
 size_t volt_rollout_scratch_bytes(int G, int S, int H);
 int volt_rollout_bordered_f32(const double* rho, const double* tau, const double* acc0, const float* dx,
                               const float* hist_y, const float* hist_e1, const float* hist_e2,

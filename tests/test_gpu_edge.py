@@ -187,9 +187,32 @@ def test_rollout_statistics_with_independent_draws(ops):
     assert 0.5 * (H - 1) * sd ** 2 < inc.var() < 3.0 * (H - 1) * sd ** 2
 
 
-@pytest.mark.parametrize("S,H,k", [(1, 1, 3), (5, 2, 300), (7, 256, 25)])
+@pytest.mark.parametrize("H,mode,theta", [(1, 0, None), (2, 1, None), (50, 2, None), (256, 0, 0.3), (257, 0, None),
+                                          (300, 1, None), (512, 3, None), (700, 0, None), (1024, 0, 0.1)])
+def test_rollout_append_only_is_bitwise_the_full_resubstitution(ops, H, mode, theta):
+    """The default engine extends w_s by one entry per step; `resubstitute=True` re-solves every sample's triangular
+    system from its stored rows at every step (what the engine did before, H^3/6 * 4 B per path).  Same arithmetic in
+    the same order: the paths must be IDENTICAL, for every mean family, every chunking of the rows (H <= 256 / 512 / 1024)
+    and with mean reversion."""
+    from volt_amd import rollout_engine as re_
+    n, S, k = 200, 9, 25
+    F, vol = sde_series(n, 4)
+    pv, z = rollout_inputs(vol[-1], S, H, seed=H)
+    tx = torch.arange(n, device="cuda") / 252.
+    test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
+    logy = torch.log(dev(F)[1:])[None]
+    kw = dict(latent_mean=logy.mean(), theta=theta) if theta is not None else {}
+    args = (tx, logy, torch.log(dev(vol))[None], test_x, dev(pv)[None], dev(z)[None], mode, k)
+    a, ia = re_.rollout_series(*args, **kw)
+    b, ib = re_.rollout_series(*args, resubstitute=True, **kw)
+    assert bool(torch.isfinite(a).all()) and torch.equal(ia, ib)
+    assert torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("S,H,k", [(1, 1, 3), (5, 2, 300), (7, 256, 25), (3, 600, 25), (2, 1024, 40)])
 def test_rollout_engine_shapes_and_extremes(ops, S, H, k):
-    """S not a multiple of the 4 paths per workgroup, H = 1 and the maximum H = 256, k larger than N."""
+    """S not a multiple of the 4 paths per workgroup, H = 1, H = 256 (one chunk per row), H > 256 (two and four chunks,
+    up to the maximum 1024), k larger than N."""
     from volt_amd import rollout_engine as re_
     n = 140
     F, vol = sde_series(n, 2)

@@ -12,12 +12,12 @@
 //     w_s   = L_s^-1 (k*_s - rho 1),   z_s = L_s^-1 (r_s - tau 1)
 //     mean  = tau + w_s'z_s + m(x*),   var = k** - rho - w_s'w_s
 // The new row of L_s at step idx+1 is w_s of step idx (the new column of K_tr is the previous k*),
-// which is ordinary row-by-row Cholesky.  The per-sample triangular solve is done in full at every
-// step against the stored dense rows of L_s -- O(idx^2) words streamed per step, HBM-bound.
+// which is ordinary row-by-row Cholesky.  w_s itself is append-only for this kernel (see rollout_bordered_kernel);
+// the full per-step re-substitution against the stored dense rows is kept as a cross-check mode.
 //
 // One wave per sample (a sample's recursion is sequential in idx and in the substitution index);
-// 4 samples per workgroup, EWMA histories in LDS.  H <= 256: a lane owns the 4 consecutive entries
-// 4*lane + t, so a stored row is read and written with one 16-byte access per lane.
+// 4 samples per workgroup, EWMA histories in LDS.  H <= 1024: a lane owns the entries 256 c + 4 lane + t of
+// ceil(H / 256) chunks, so a stored row is read and written with 16-byte accesses, 1 KB per wave-instruction.
 #include "common.h"
 #include "../../include/volt_hip.h"
 
@@ -96,6 +96,19 @@ __host__ __device__ inline size_t rollout_sample_floats(int H) {
     return m <= 0 ? 4 : (size_t)4 * (q + 1) * (2 * q + r) + 4;    // rows 1 .. H-1 (+ one slot of slack)
 }
 
+// NC = 256-entry chunks per factor row (H <= 256 NC): a lane owns the entries 256 c + 4 lane + t, so a stored row is
+// read and written with NC 16-byte accesses per lane, each wave-instruction covering 1 KB of contiguous memory.
+//
+// Two ways to get w_s at step idx:
+//   RESUB = false  APPEND-ONLY (default).  For the volatility kernel the right-hand side prefix is step-invariant -- the
+//      covariance between appended point a and ANY later point is U_s[a] (k(x*, x_a) = V[min(a, *)]) -- and the stored
+//      rows never change, so w_s(idx) = [w_s(idx-1), new entry]: one dot product against the row appended last (it is
+//      still in registers), nothing is re-read, no scratch.  O(idx) flops per step, O(H^2) per path.
+//   RESUB = true   FULL RE-SUBSTITUTION against the stored rows at every step -- what a kernel without that invariance would
+//      need.  O(idx^2) words streamed per step (H^3/6 * 4 B per path, HBM-bound).  Same arithmetic in the same order, so
+//      the two produce BITWISE identical paths (tested); kept as the cross-check and as the measured cost of not
+//      using the invariance (bench.py reports it as redundant bytes).
+template <int NC, bool RESUB>
 __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,7 +135,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     const float* pv = p.pred_vol + row;
     const float* zz = p.z + row;
     float* out = p.samples + row;
-    float* Ls = p.Ls + ((size_t)g * p.S + s) * rollout_sample_floats(H);
+    float* Ls = RESUB ? p.Ls + ((size_t)g * p.S + s) * rollout_sample_floats(H) : nullptr;
     // base = U_s[N+a] - rho, carried in fp64: the entries of the Schur complement S_s = C_s - rho 11' are
     // ~ dx vol^2 (1e-4 .. 1e-9) on top of rho ~ V[N-1] ~ 1, so forming U_s and rho in fp32 first loses them
     // (62 of 80,000 paths at N = 4096 lost a pivot that way); the differences themselves are fine in fp32.
@@ -130,62 +143,101 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     float ema_prev = (p.mean_mode == 3) ? p.ema_prev[g] : 0.f;
     int bad = 0;
 
-    float U[4] = {0.f, 0.f, 0.f, 0.f};      // U_s[N+a] - rho  for a = 4 lane + t
-    float rd[4] = {0.f, 0.f, 0.f, 0.f};     // 1 / L_s[a][a]
-    float zs[4] = {0.f, 0.f, 0.f, 0.f};     // z_s[a]
-    float wv[4];
+    // entry (c, t) of these arrays belongs to appended point b = 256 c + 4 lane + t
+    float U[NC][4], rd[NC][4], zs[NC][4], wraw[NC][4];      // U_s - rho;  1 / L_s[b][b];  z_s[b];  (U_s - rho) - sum (un-normalised w)
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) U[c][t] = rd[c][t] = zs[c][t] = wraw[c][t] = 0.f;
 
     for (int idx = 0; idx < H; ++idx) {
-        // ---- w_s = L_s^-1 (U_s - rho): row-oriented forward substitution against stored rows ----
+        float wv[NC][4];
+        if constexpr (RESUB) {
+            // ---- w_s = L_s^-1 (U_s - rho): row-oriented forward substitution against ALL stored rows ----
 #pragma unroll
-        for (int t = 0; t < 4; ++t) wv[t] = U[t];
-        // Rows are streamed in groups of 4 with the next group's loads issued before the current
-        // group is consumed: the substitution itself is a dependent chain (row a needs w[a-1]), but the
-        // addresses are not, so 8 rows per wave stay in flight and the stream runs at memory bandwidth
-        // instead of one memory latency per row.
-        float cur[4][4], nxt[4][4];
-        auto load_rows = [&](float (&dst)[4][4], int a0) {
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = a0 + r;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a < idx && 4 * lane < a) v = *reinterpret_cast<const f32x4*>(Ls + row_off(a) + 4 * lane);
+                for (int t = 0; t < 4; ++t) wv[c][t] = U[c][t];
+            // Rows are streamed in groups of 4 with the next group's loads issued before the current group is
+            // consumed: the substitution is a dependent chain (row a needs w[a-1]) but the addresses are not, so 8
+            // rows per wave stay in flight and the stream runs at memory bandwidth, not one latency per row.
+            float cur[4][NC][4], nxt[4][NC][4];
+            auto load_rows = [&](float (&dst)[4][NC][4], int a0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dst[r][t] = (4 * lane + t < a) ? v[t] : 0.f;   // beyond b < a: never written
-            }
-        };
-        load_rows(cur, 1);                                   // row 0 has no off-diagonal part
-        for (int a0 = 1; a0 < idx; a0 += 4) {
-            load_rows(nxt, a0 + 4);
+                for (int r = 0; r < 4; ++r) {
+                    const int a = a0 + r;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = a0 + r;
-                if (a < idx) {                               // wave-uniform
-                    float part = 0.f;
+                    for (int c = 0; c < NC; ++c) {
+                        const int b0 = 256 * c + 4 * lane;
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (a < idx && b0 < a) v = *reinterpret_cast<const f32x4*>(Ls + row_off(a) + b0);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) part += cur[r][t] * (wv[t] * rd[t]);   // zero beyond b < a
-                    const float dot = wave_sum_f(part);
-                    const int ta = a & 3;
-                    if (lane == (a >> 2)) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (t == ta) wv[t] -= dot;
+                        for (int t = 0; t < 4; ++t) dst[r][c][t] = (b0 + t < a) ? v[t] : 0.f;   // beyond b < a: never written
                     }
                 }
+            };
+            load_rows(cur, 1);                               // row 0 has no off-diagonal part
+            for (int a0 = 1; a0 < idx; a0 += 4) {
+                load_rows(nxt, a0 + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int a = a0 + r;
+                    if (a < idx) {                           // wave-uniform
+                        float part = 0.f;
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) part += cur[r][c][t] * (wv[c][t] * rd[c][t]);   // zero beyond b < a
+                        const float dot = wave_sum_f(part);
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (256 * c + 4 * lane + t == a) wv[c][t] -= dot;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) cur[r][c][t] = nxt[r][c][t];
+            }
+        } else {
+            // ---- append-only: entries b < idx-1 stand; the new one, b = idx-1, is the same dot product the full
+            // substitution would take against row idx-1 -- whose entries are the w_s of the step before, in registers
+            if (idx >= 2) {
+                const int a = idx - 1;
+                float part = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float wfin = wraw[c][t] * rd[c][t];
+                        part += ((256 * c + 4 * lane + t < a) ? wfin : 0.f) * wfin;
+                    }
+                const float dot = wave_sum_f(part);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (256 * c + 4 * lane + t == a) wraw[c][t] -= dot;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) cur[r][t] = nxt[r][t];
+                for (int t = 0; t < 4; ++t) wv[c][t] = wraw[c][t];
         }
         float ww = 0.f, wz = 0.f;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int b = 4 * lane + t;
-            wv[t] = (b < idx) ? wv[t] * rd[t] : 0.f;         // now wv = w_s
-            ww += wv[t] * wv[t];
-            wz += wv[t] * zs[t];
-        }
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int b = 256 * c + 4 * lane + t;
+                wv[c][t] = (b < idx) ? wv[c][t] * rd[c][t] : 0.f;    // now wv = w_s
+                ww += wv[c][t] * wv[c][t];
+                wz += wv[c][t] * zs[c][t];
+            }
         ww = wave_sum_f(ww);
         wz = wave_sum_f(wz);
 
@@ -221,20 +273,25 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         }
         const float ell = sqrtf(d2), rell = 1.f / ell;
         const float znew = ((smp - mstar) - tau - wz) * rell;
-        // row idx of L_s = [w_s, ell]: the off-diagonal part goes to the packed store, ell stays in registers (rd)
-        float* Lrow = Ls + row_off(idx);
-        f32x4 rowv;
+        // row idx of L_s = [w_s, ell]: the off-diagonal part goes to the packed store (re-substitution mode only),
+        // ell stays in registers (rd)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int b = 4 * lane + t;
-            rowv[t] = (b < idx) ? wv[t] : ((b == idx) ? ell : 0.f);
-            if (b == idx) {
-                U[t] = Unew;
-                rd[t] = rell;
-                zs[t] = znew;
+        for (int c = 0; c < NC; ++c) {
+            const int b0 = 256 * c + 4 * lane;
+            f32x4 rowv;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int b = b0 + t;
+                rowv[t] = (b < idx) ? wv[c][t] : ((b == idx) ? ell : 0.f);
+                if (b == idx) {
+                    U[c][t] = Unew;
+                    wraw[c][t] = Unew;                       // append-only: (U_s - rho) before its own row's dot product
+                    rd[c][t] = rell;
+                    zs[c][t] = znew;
+                }
             }
+            if (RESUB && b0 < idx) *reinterpret_cast<f32x4*>(Ls + row_off(idx) + b0) = rowv;
         }
-        if (4 * lane < idx) *reinterpret_cast<f32x4*>(Lrow + 4 * lane) = rowv;
         if (lane == 0) {
             hy[k + idx] = smp;
             he1[k + idx] = ma1;
@@ -324,11 +381,10 @@ int volt_rollout_bordered_f32(const double* rho, const double* tau, const double
     if (!pred_vol) return -12;
     if (!z) return -13;
     if (!samples) return -14;
-    if (!scratch) return -15;
     if (!info) return -16;
     if (G < 0) return -17;
     if (S < 0) return -18;
-    if (H < 1 || H > 256) return -19;
+    if (H < 1 || H > VOLT_ROLLOUT_MAX_H) return -19;
     if (k < 1 || k > 2048) return -20;
     if (mean_mode < 0 || mean_mode > 3) return -21;
     if ((mean_mode == 1 || mean_mode == 2) && !hist_e1) return -6;
@@ -340,10 +396,26 @@ int volt_rollout_bordered_f32(const double* rho, const double* tau, const double
                     samples, scratch, info, G, S, H, k, mean_mode, use_theta, theta, mr_theta, jitter};
     const size_t lds = ((size_t)4 * 3 * (k + H) + k) * sizeof(float);
     if (lds > 160 * 1024) return -20;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_bordered_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(rollout_bordered_kernel, dim3((S + 3) / 4, G), dim3(256), lds, (hipStream_t)stream, p);
+    const dim3 grid((S + 3) / 4, G);
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e;
+#define VOLT_ROLLOUT_LAUNCH1(NC, RS)                                                                                   \
+    do {                                                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_bordered_kernel<NC, RS>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        if (e != hipSuccess) return (int)e;                                                                            \
+        hipLaunchKernelGGL((rollout_bordered_kernel<NC, RS>), grid, dim3(256), lds, s, p);                           \
+    } while (0)
+#define VOLT_ROLLOUT_LAUNCH(NC)                                                                                        \
+    do {                                                                                                               \
+        if (scratch) VOLT_ROLLOUT_LAUNCH1(NC, true);                                                                   \
+        else VOLT_ROLLOUT_LAUNCH1(NC, false);                                                                          \
+    } while (0)
+    if (H <= 256) VOLT_ROLLOUT_LAUNCH(1);
+    else if (H <= 512) VOLT_ROLLOUT_LAUNCH(2);
+    else VOLT_ROLLOUT_LAUNCH(4);
+#undef VOLT_ROLLOUT_LAUNCH
+#undef VOLT_ROLLOUT_LAUNCH1
     VOLT_LAUNCH_CHECK();
     return 0;
 }

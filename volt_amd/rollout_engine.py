@@ -58,7 +58,7 @@ def _family_state(log_y, k, mean_mode, mr_theta=0.5, mr_latent=None):
     return m_tr, _tail(log_y.to(f32), k), hist_e1, hist_e2, ema_prev, mrl, w
 
 
-MAX_H = 256          # horizon limit of volt_rollout_bordered_f32 (a lane owns 4 of the <= 256 appended points)
+MAX_H = 1024         # VOLT_ROLLOUT_MAX_H: a lane owns 4 entries of each of up to four 256-entry chunks of a factor row
 
 
 def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
@@ -83,9 +83,11 @@ def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
 
 
 def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode, k, latent_mean=None, theta=None,
-                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="closed", timing=None):
+                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="closed", timing=None, resubstitute=False):
     """Batched engine entry.  train_x [N]; log_y, log_vol_path [G,N]; test_x [H]; pred_vol, z [G,S,H].
-    Returns (samples [G,S,H] on the device, info [G,S]).  `timing` (a dict) receives events bracketing the kernel."""
+    Returns (samples [G,S,H] on the device, info [G,S]).  `timing` (a dict) receives events bracketing the kernel.
+    ``resubstitute``: re-solve every sample's triangular system from its stored rows at every step (H^3/6 * 4 B of HBM
+    traffic per path) instead of extending it by one entry -- bitwise the same paths; the cross-check of the default."""
     dev = train_x.device
     G, N = log_y.shape
     S, H = pred_vol.shape[-2:]
@@ -109,8 +111,10 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
     rho, tau = train_block_terms(U, r_tr, solve, jitter)
     samples = torch.empty(G, S, H, dtype=f32, device=dev)
     info = torch.empty(G, S, dtype=torch.int32, device=dev)
-    nbytes = _lib.lib().volt_rollout_scratch_bytes(G, S, H)
-    scratch = torch.empty(nbytes // 4, dtype=f32, device=dev)
+    scratch = None
+    if resubstitute:
+        nbytes = _lib.lib().volt_rollout_scratch_bytes(G, S, H)
+        scratch = torch.empty(nbytes // 4, dtype=f32, device=dev)
     lat = None
     if theta is not None:
         lat = torch.as_tensor(latent_mean, dtype=f32, device=dev).reshape(-1).expand(G).contiguous()

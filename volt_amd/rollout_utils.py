@@ -127,6 +127,11 @@ def _model_generate_prediction(model, test_x, pred_vol, n_sample=1):
     return out.squeeze(-1)                                  # (samples + pred_mean).squeeze(-1), VoltMagpie.py:96-99: [T] for n_sample = 1
 
 
+def rollout_engine_max_h():
+    from .rollout_engine import MAX_H
+    return MAX_H
+
+
 def Rollouts(train_x, train_y, test_x, model, nsample=50, method="volt", theta=None, *, pred_vol=None, z=None,
              engine=None):
     """voltron/rollout_utils.py:57-93.  train_x [N], train_y [N+1] raw prices, test_x [H] ->
@@ -144,8 +149,8 @@ def Rollouts(train_x, train_y, test_x, model, nsample=50, method="volt", theta=N
     pred_vol = pred_vol.to(train_x.device)
     if z is not None:
         z = z.to(train_x.device)
-    if engine == "bordered" and ntest > 256:
-        engine = "dense"                         # the bordered kernel holds <= 256 appended points per sample
+    if engine == "bordered" and ntest > rollout_engine_max_h():
+        engine = "dense"                         # the bordered kernel holds <= 1024 appended points per sample
     if engine == "bordered":
         from .rollout_engine import rollouts_bordered
         return rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean, theta)
