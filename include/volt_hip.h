@@ -120,8 +120,10 @@ int volt_trsv_lower_t_f64(const double* A, const double* Winv, const double* rhs
                           double* scratch, int B, int Np, void* stream);
 
 /* ---- a5: triangular inverse for the noise gradient  (replaces autograd cholesky_backward) ---
- * Y = L^-T (upper triangular, row-major [B,Np,Np]); tr(K_s^-1) = ||Y||_F^2. */
+ * Y = L^-T (upper triangular, row-major [B,Np,Np]); tr(K_s^-1) = ||Y||_F^2.  The fp64 twin uses the tiles BELOW the
+ * diagonal of Y as scratch: only the upper triangle (diagonal included) is meaningful on return. */
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream);
+int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np, void* stream);
 
 /* ---- a7/a8: sequential posterior rollouts  (voltron/rollout_utils.py:57-93 + :6-53) ----------
  * Bordered-Cholesky engine: the shared train block of every sample's matrix enters through two scalars per series,
@@ -179,6 +181,15 @@ int volt_adam_step_f32(const void* slots, int nslots, long long total, const flo
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid,
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
+                      int* info, void* workspace, int B, int N, int want_grad, void* stream);
+
+/* The same step in double precision for double-precision models (the reference keeps the caller's dtype,
+ * voltron/kernels/VolKernel.py:28-33; gpytorch computes log_prob in it): K, resid, sigma2, out [B,8], alpha [B,N] are
+ * doubles; volt_potrf_f64 / volt_trsv_*_f64 / volt_trtri_f64 underneath.  Agreement with an fp64 LAPACK evaluation of
+ * the same formulas: 1e-10 relative at N <= 1024, 1e-8 at N = 4096 (tests). */
+size_t volt_mll_workspace_bytes_f64(int B, int N, int want_grad);
+int volt_mll_step_f64(const double* K, int64_t ldk, int64_t bsk, const double* resid,
+                      const double* sigma2, double jitter, double* out /*[B,8]*/, double* alpha /*[B,N]*/,
                       int* info, void* workspace, int B, int N, int want_grad, void* stream);
 
 /* Dense gradient of the MLL wrt the covariance, for kernels whose parameters enter K elementwise (the fractional

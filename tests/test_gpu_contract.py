@@ -417,3 +417,64 @@ def test_one_launch_trsv_oversubscribed(ops):
         sl = slice(b0, b0 + 8)
         back[sl] = (K[sl].double() @ xs[sl].double().unsqueeze(-1)).squeeze(-1) + s2[sl].double().unsqueeze(-1) * xs[sl].double()
     assert float(((back - r.double()).norm(dim=-1) / r.double().norm(dim=-1)).max()) < 2e-3
+
+
+# ------------------------------------------------------------------ fp64 MLL step (SURVEY 7 hard part 2)
+@pytest.mark.parametrize("B,n,tol", [(1, 256, 1e-10), (3, 399, 1e-10), (2, 1024, 1e-10), (2, 2900, 1e-9), (1, 4096, 1e-8)])
+@pytest.mark.parametrize("want_grad", [True, False])
+def test_mll_step_f64_vs_fp64_oracle(ops, B, n, tol, want_grad):
+    """volt_mll_step_f64 on fp64 inputs against the numpy/LAPACK fp64 oracle on the SAME inputs.  Stated tolerances
+    per size (both sides are fp64; the difference is summation order times the conditioning of K + s2 I):
+    1e-10 relative up to N = 1024, 1e-9 at 2900, 1e-8 at 4096 -- for MLL, d/d sigma2, tr K_s^-1 and alpha (rel-to-max)."""
+    x, vol, y, mean = _series_problem(B, n)
+    x64, vol64 = dev(x.astype(np.float64)), dev(vol.astype(np.float64))
+    K = ops.fill(ops.cumtrapz(vol64, x64, square=True))
+    assert K.dtype == torch.float64
+    y64, m64 = y.astype(np.float64), mean.astype(np.float64)
+    s2 = torch.full((B,), float(vo.noise_from_raw(1e-5)), device="cuda", dtype=torch.float64)
+    out, alpha, info = ops.mll_step(K, dev(y64 - m64), s2, want_grad=want_grad)
+    assert out.dtype == torch.float64 and int(info.abs().sum()) == 0
+    o = vo.mll_and_grads(K.cpu().numpy(), y64, m64, 1e-5)
+    out = out.cpu().numpy()
+    np.testing.assert_allclose(out[:, 0], o["mll"], rtol=tol)
+    np.testing.assert_allclose(out[:, 2], o["quad"], rtol=tol * 10)
+    np.testing.assert_allclose(out[:, 3], o["logdet"], rtol=tol)
+    if want_grad:
+        dsig = 0.5 * (o["aa"] - o["trinv"]) / n
+        np.testing.assert_allclose(out[:, 4], o["trinv"], rtol=tol)
+        np.testing.assert_allclose(out[:, 5], o["aa"], rtol=tol * 10)
+        np.testing.assert_allclose(out[:, 1], dsig, rtol=tol * 100)       # a difference of two O(1) traces
+        a = alpha.cpu().numpy()
+        assert np.abs(a - o["alpha"]).max() <= tol * 100 * np.abs(o["alpha"]).max()
+
+
+def test_trtri_f64_vs_lapack(ops):
+    B, n = 2, 700
+    x, F, vol = sde_batch(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol.astype(np.float64)), dev(x.astype(np.float64)), square=True))
+    f = ops.potrf(K, torch.full((B,), 0.3, device="cuda", dtype=torch.float64))
+    Y = ops.trtri(f)
+    assert Y.dtype == torch.float64
+    for b in range(B):
+        L = np.linalg.cholesky(K[b].cpu().numpy() + 0.3 * np.eye(n))
+        ref = np.linalg.inv(L).T
+        assert np.abs(Y[b].cpu().numpy() - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+def test_exact_mll_keeps_fp64_and_its_gradient(ops):
+    """ExactMarginalLogLikelihood on a double-precision covariance computes in double precision (no silent down-cast),
+    value and d/d raw_noise against the fp64 oracle to 1e-10."""
+    from volt_amd import gp
+    n = 512
+    x, vol, y, mean = _series_problem(1, n)
+    K = ops.fill(ops.cumtrapz(dev(vol[0].astype(np.float64)), dev(x.astype(np.float64)), square=True))
+    lik = gp.GaussianLikelihood().cuda().double()
+    with torch.no_grad():
+        lik.raw_noise.fill_(0.25)
+    mll = gp.ExactMarginalLogLikelihood(lik, None)
+    val = mll(gp.MultivariateNormal(dev(mean[0].astype(np.float64)), K), dev(y[0].astype(np.float64)))
+    assert val.dtype == torch.float64
+    val.backward()
+    o = vo.mll_and_grads(K.cpu().numpy(), y[0].astype(np.float64), mean[0].astype(np.float64), 0.25)
+    np.testing.assert_allclose(float(val), o["mll"], rtol=1e-10)
+    np.testing.assert_allclose(float(lik.raw_noise.grad), o["d_raw"], rtol=1e-8)

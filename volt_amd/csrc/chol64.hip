@@ -468,6 +468,80 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, dou
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
 }
 
+// ----------------------------------------------------------------------------- trtri (fp64)
+// Y = L^-T (upper, row-major) by block rows of X = L^-1, as in chol.hip:  X[i,j] = -W_i sum_{m=j}^{i-1} L[i,m] X[m,j].
+// Two launches per block row i, the intermediate through the UNUSED lower-triangle slots of the Y buffer:
+//   phase 1  S(i,j)[c][p] = sum_k Y[j-rows c][k] L[i-rows p][k],  k over columns [128 j, 128 i)   -> slot (i, j) of Y
+//   phase 2  Y[j-rows c][i-cols r] = -sum_p S(i,j)[c][p] W_i[r][p];  and Y[i,i] = W_i^T
+// Both are "NT" products of K-contiguous rows on the 128x128 fp64 core.  (The fp32 path keeps S in the accumulators
+// and fuses the phases, chol.hip; here the tile makes one round trip through HBM -- N^2/2 doubles per matrix.)
+__global__ __launch_bounds__(256) void trtri64_p1_kernel(const double* __restrict__ A, double* __restrict__ Y, int Np, int i,
+                                                         int B) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    int j, b;
+    decode_tile_batch(i, B, j, b);
+    const double* Ab = A + (int64_t)b * Np * Np;
+    double* Yb = Y + (int64_t)b * Np * Np;
+    f64x4 acc[16];
+    zero_acc64(acc);
+    gemm64_nt_128(Yb + (int64_t)j * TS * Np + (int64_t)j * TS, Np, Ab + (int64_t)i * TS * Np + (int64_t)j * TS, Np,
+                  (i - j) * (TS / BK64), acc, smem);
+    double* S = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_ACC64_RC(mt, nt, q)
+                S[(int64_t)r * Np + c] = acc[mt * 4 + nt][q];
+            }
+}
+
+// grid: (i + 1) * B; tile j == i transposes W_i into Y[i,i]
+__global__ __launch_bounds__(256) void trtri64_p2_kernel(const double* __restrict__ Winv, double* __restrict__ Y, int Np,
+                                                         int i, int B) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    const int n = Np / TS;
+    int j, b;
+    decode_tile_batch(i + 1, B, j, b);
+    double* Yb = Y + (int64_t)b * Np * Np;
+    const double* W = Winv + ((int64_t)b * n + i) * TS * TS;
+    if (j == i) {
+        double* sW = reinterpret_cast<double*>(smem);              // 64 x 129 doubles at a time (66 KB)
+        double* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < 64 * TS; e += NT) {
+                const int r = e >> 7, c = e & 127;                 // W row 64 half + r, column c
+                sW[r * (TS + 1) + c] = W[(int64_t)(64 * half + r) * TS + c];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < TS * 64; e += NT) {
+                const int c = e >> 6, r = e & 63;                  // Y row c, column 64 half + r
+                Yd[(int64_t)c * Np + 64 * half + r] = (64 * half + r >= c) ? sW[r * (TS + 1) + c] : 0.0;
+            }
+        }
+        return;
+    }
+    const double* S = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;
+    f64x4 acc[16];
+    zero_acc64(acc);
+    gemm64_nt_128(S, Np, W, TS, TS / BK64, acc, smem);
+    double* Out = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_ACC64_RC(mt, nt, q)
+                Out[(int64_t)r * Np + c] = -acc[mt * 4 + nt][q];
+            }
+}
+
 }  // namespace volt
 
 using namespace volt;
@@ -485,6 +559,23 @@ int volt_prepare_f64(const double* K, int64_t ldk, int64_t bsk, const double* si
     const int Np = volt_padded_n(N), n = Np / TS;
     hipLaunchKernelGGL(prepare64_kernel, dim3(n * (n + 1) / 2, B), dim3(256), 0, (hipStream_t)stream, K, ldk, bsk,
                        sigma2, jitter, A, N, Np);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!Y) return -3;
+    if (B < 0) return -4;
+    if (Np < TS || Np % TS) return -5;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int n = Np / TS;
+    for (int i = 0; i < n; ++i) {
+        if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B), dim3(256), 0, s, A, Y, Np, i, B);
+        hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), 0, s, Winv, Y, Np, i, B);
+    }
     VOLT_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,164 @@
+// fp64 marginal log likelihood + analytic gradient (7 hard part 2: "an fp64 variant with per-dtype
+// tolerances").  The reference keeps the caller's dtype (voltron/kernels/VolKernel.py:28-33; gpytorch's log_prob
+// computes in it), so a double-precision model trains in double precision: same step as mll.hip on the fp64 twins --
+//     A = K + sigma2 I -> volt_potrf_f64 -> z = L^-1 r, alpha = L^-T z (one-launch chained solves, trsv.hip)
+//     -> Y = L^-T (volt_trtri_f64) -> tr K_s^-1 = ||Y||_F^2 -> scalars.
+// The O(N^2) passes are HBM streams; the O(N^3) work runs on v_mfma_f64_16x16x4_f64 (chol64.hip).
+#include "common.h"
+#include "../../include/volt_hip.h"
+#include <math.h>
+
+namespace volt {
+
+__global__ void pad_resid64_kernel(const double* __restrict__ resid, double* __restrict__ rpad, int N, int Np) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Np) rpad[(int64_t)b * Np + i] = (i < N) ? resid[(int64_t)b * N + i] : 0.0;
+}
+
+// ||Y||_F^2 over the upper tiles, rows < N (the identity padding contributes nothing that way).  One workgroup per
+// (128-row block, matrix); deterministic two-stage sum: part[b][rb].
+__global__ __launch_bounds__(256) void frob64_kernel(const double* __restrict__ Y, double* __restrict__ part, int N, int Np) {
+    __shared__ double red[256];
+    const int n = Np / TS, rb = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const double* Yb = Y + (int64_t)b * Np * Np;
+    double acc = 0.0;
+    for (int r = 0; r < TS; ++r) {
+        const int row = rb * TS + r;
+        if (row >= N) break;
+        const double* yr = Yb + (int64_t)row * Np;
+        for (int c = (row & ~255) + tid; c < Np; c += 256) {      // from the diagonal on (upper triangle)
+            if (c >= row) { const double v = yr[c]; acc += v * v; }
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) part[(int64_t)b * n + rb] = red[0];
+}
+
+// out[b, 0..7] = mll, dmll/dsigma2, quad, logdet, trinv, aa, sigma2-used, 0   (the layout of the fp32 step)
+__global__ __launch_bounds__(256) void mll_scalars64_kernel(const double* __restrict__ A, const double* __restrict__ z,
+                                                            const double* __restrict__ alpha_pad,
+                                                            const double* __restrict__ frob, const double* __restrict__ sigma2,
+                                                            double jitter, double* __restrict__ out,
+                                                            double* __restrict__ alpha_out, int N, int Np, int want_grad) {
+    __shared__ double red[256];
+    const int b = blockIdx.x, tid = threadIdx.x, n = Np / TS;
+    const double* Ab = A + (int64_t)b * Np * Np;
+    auto block_sum = [&](double v) -> double {
+        red[tid] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) red[tid] += red[tid + s];
+            __syncthreads();
+        }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double q = 0, ld = 0, aa = 0, tr = 0;
+    for (int i = tid; i < N; i += 256) {
+        const double zi = z[(int64_t)b * Np + i];
+        q += zi * zi;
+        ld += log(Ab[(int64_t)i * Np + i]);
+        if (want_grad) {
+            const double al = alpha_pad[(int64_t)b * Np + i];
+            aa += al * al;
+            alpha_out[(int64_t)b * N + i] = al;
+        }
+    }
+    if (want_grad)
+        for (int i = tid; i < n; i += 256) tr += frob[(int64_t)b * n + i];
+    q = block_sum(q);
+    ld = 2.0 * block_sum(ld);
+    aa = block_sum(aa);
+    tr = block_sum(tr);
+    if (tid == 0) {
+        const double LOG_2PI = 1.8378770664093453;
+        double* o = out + (int64_t)b * 8;
+        o[0] = -0.5 * (q + ld + N * LOG_2PI) / N;
+        o[2] = q;
+        o[3] = ld;
+        o[6] = (sigma2 ? sigma2[b] : 0.0) + jitter;
+        o[7] = 0.0;
+        if (want_grad) {
+            o[1] = 0.5 * (aa - tr) / N;
+            o[4] = tr;
+            o[5] = aa;
+        }
+    }
+}
+
+struct Mll64Ws {
+    double *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *frob;
+    size_t bytes;
+};
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static Mll64Ws carve64(void* base, int B, int N, int want_grad) {
+    const size_t Np = (size_t)volt_padded_n(N), n = Np / TS;
+    size_t off = 0;
+    auto take = [&](size_t doubles) {
+        double* p = base ? reinterpret_cast<double*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += al256(doubles * sizeof(double));
+        return p;
+    };
+    Mll64Ws w;
+    w.A = take((size_t)B * Np * Np);
+    w.Winv = take((size_t)B * n * TS * TS);
+    w.rpad = take((size_t)B * Np);
+    w.z = take((size_t)B * Np);
+    w.scratch = take((size_t)B * Np + 64);
+    w.apad = take((size_t)B * Np);
+    w.Y = want_grad ? take((size_t)B * Np * Np) : nullptr;
+    w.frob = want_grad ? take((size_t)B * n) : nullptr;
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace volt
+
+using namespace volt;
+
+extern "C" {
+
+size_t volt_mll_workspace_bytes_f64(int B, int N, int want_grad) {
+    if (B <= 0 || N <= 0) return 0;
+    return carve64(nullptr, B, N, want_grad).bytes;
+}
+
+int volt_mll_step_f64(const double* K, int64_t ldk, int64_t bsk, const double* resid, const double* sigma2, double jitter,
+                      double* out, double* alpha, int* info, void* workspace, int B, int N, int want_grad, void* stream) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!resid) return -4;
+    if (!out) return -7;
+    if (want_grad && !alpha) return -8;
+    if (!info) return -9;
+    if (!workspace || ((uintptr_t)workspace & 255)) return -10;
+    if (B < 0 || B > 65535) return -11;
+    if (N < 1) return -12;
+    if (B == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    Mll64Ws w = carve64(workspace, B, N, want_grad);
+    int rc;
+    hipLaunchKernelGGL(pad_resid64_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
+    if ((rc = volt_prepare_f64(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
+    if ((rc = volt_potrf_f64(w.A, w.Winv, info, B, Np, stream))) return rc > 0 ? rc : -1;
+    if ((rc = volt_trsv_lower_f64(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
+    if (want_grad) {
+        if ((rc = volt_trsv_lower_t_f64(w.A, w.Winv, w.z, w.apad, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
+        if ((rc = volt_trtri_f64(w.A, w.Winv, w.Y, B, Np, stream))) return rc > 0 ? rc : -1;
+        hipLaunchKernelGGL(frob64_kernel, dim3(n, B), dim3(256), 0, s, w.Y, w.frob, N, Np);
+    }
+    hipLaunchKernelGGL(mll_scalars64_kernel, dim3(B), dim3(256), 0, s, w.A, w.z, w.apad, w.frob, sigma2, jitter, out, alpha,
+                       N, Np, want_grad);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

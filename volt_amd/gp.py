@@ -402,8 +402,14 @@ class _ExactMLL(torch.autograd.Function):
         want_dk = bool(ctx.needs_input_grad[0])       # kernels with trainable parameters (Matern / SM / FBM baselines)
         K = K.detach()
         need_grad = want_dk or any(ctx.needs_input_grad[1:4]) or (scale is not None and ctx.needs_input_grad[5])
-        ws = holder.workspace(B, n, need_grad, K.device)
-        resid = (target - mean).to(torch.float32)
+        if K.dtype != torch.float64:                  # the caller's dtype is kept (VolKernel.py:28-33): fp32 or fp64 step
+            K = K.to(torch.float32)
+        dt = K.dtype
+        if want_dk and dt != torch.float32:
+            raise NotImplementedError("the dense d mll / d K path (FBM kernel) is fp32 only")
+        ws = holder.workspace(B, n, need_grad, K.device, dt)
+        resid = (target - mean).to(dt)
+        noise = noise.to(dt)
         # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
         # NumericalWarning, then NotPSDError.  Same ladder here; the jitter is added inside the fused step.
         out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0)
@@ -420,7 +426,7 @@ class _ExactMLL(torch.autograd.Function):
                 raise NanError("cholesky: NaN in the covariance, the noise or the residual")
             first = int(info[info != 0][0].item())
             for i in range(3):
-                jitter = 1e-6 * (10 ** i)
+                jitter = (1e-6 if dt == torch.float32 else 1e-8) * (10 ** i)      # gpytorch's defaults per dtype
                 out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter)
                 if not bool((info != 0).any().item()):
                     warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
@@ -466,10 +472,10 @@ class ExactMarginalLogLikelihood(Module):
         object.__setattr__(self, "model", model)
         self._ws = None
 
-    def workspace(self, B, n, want_grad, device):
+    def workspace(self, B, n, want_grad, device, dtype=torch.float32):
         ws = self._ws
-        if ws is None or ws.B != B or ws.N != n or ws.want_grad != bool(want_grad) or ws.buf.device != device:
-            self._ws = ws = ops.MllWorkspace(B, n, want_grad, device)
+        if ws is None or not ws.fits(B, n, want_grad, dtype) or ws.buf.device != device:
+            self._ws = ws = ops.MllWorkspace(B, n, want_grad, device, dtype)
         return ws
 
     def forward(self, function_dist, target):
@@ -488,7 +494,8 @@ class ExactMarginalLogLikelihood(Module):
             raise ops._lib.VoltHipError("ExactMarginalLogLikelihood: tensors must live on the MI355X; no CPU fallback")
         noise = self.likelihood.noise.reshape(-1)
         noise = noise.expand(mean2.shape[0]) if noise.numel() == 1 else noise
-        res = _ExactMLL.apply(K3, mean2.to(torch.float32), noise.to(torch.float32), t2.to(torch.float32), self, scale)
+        dt = torch.float64 if K3.dtype == torch.float64 else torch.float32      # computed in the covariance's dtype
+        res = _ExactMLL.apply(K3, mean2.to(dt), noise.to(dt), t2.to(dt), self, scale)
         res = res.reshape(mean.shape[:-1]) if batched else res.reshape(())
         priors = self.model.named_priors() if isinstance(self.model, Module) else ()
         for _, module, prior, closure in priors:                          # gpytorch: + sum log p(theta) / num_data

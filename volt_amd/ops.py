@@ -180,46 +180,51 @@ def cholesky_solve(f: CholeskyFactor, rhs: torch.Tensor) -> torch.Tensor:
 
 
 def trtri(f: CholeskyFactor) -> torch.Tensor:
-    """Y = L^-T as an upper-triangular [B,N,N] tensor (fp32 factors only)."""
-    if f.A.dtype != torch.float32:
-        raise ValueError("trtri: the triangular inverse exists for fp32 factors only")
+    """Y = L^-T as an upper-triangular [B,N,N] tensor in the factor's dtype (volt_trtri_f32 / volt_trtri_f64)."""
     B, Np = f.A.shape[0], f.A.shape[1]
-    Y = torch.empty(B, Np, Np, dtype=torch.float32, device=f.A.device)
-    _lib.check(_lib.lib().volt_trtri_f32(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()),
-               "volt_trtri")
+    Y = torch.empty(B, Np, Np, dtype=f.A.dtype, device=f.A.device)
+    fn = _lib.lib().volt_trtri_f32 if f.A.dtype == torch.float32 else _lib.lib().volt_trtri_f64
+    _lib.check(fn(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()), "volt_trtri")
     return torch.triu(Y[:, : f.n, : f.n])
 
 
 class MllWorkspace:
-    """Caller-owned scratch for volt_mll_step_f32, reusable across steps of the same (B,N)."""
+    """Caller-owned scratch for volt_mll_step_f32 / _f64, reusable across steps of the same (B, N, dtype)."""
 
-    def __init__(self, B: int, N: int, want_grad: bool, device):
-        self.B, self.N, self.want_grad = B, N, bool(want_grad)
-        nbytes = _lib.lib().volt_mll_workspace_bytes(B, N, int(want_grad))
+    def __init__(self, B: int, N: int, want_grad: bool, device, dtype=torch.float32):
+        self.B, self.N, self.want_grad, self.dtype = B, N, bool(want_grad), dtype
+        L = _lib.lib()
+        query = L.volt_mll_workspace_bytes if dtype == torch.float32 else L.volt_mll_workspace_bytes_f64
+        nbytes = query(B, N, int(want_grad))
         self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         self.ptr = (self.buf.data_ptr() + 255) // 256 * 256
-        self.out = torch.empty(B, 8, dtype=torch.float32, device=device)
-        self.alpha = torch.empty(B, N, dtype=torch.float32, device=device)
+        self.out = torch.empty(B, 8, dtype=dtype, device=device)
+        self.alpha = torch.empty(B, N, dtype=dtype, device=device)
         self.info = torch.empty(B, dtype=torch.int32, device=device)
+
+    def fits(self, B, N, want_grad, dtype=torch.float32):
+        return self.B == B and self.N == N and self.want_grad == bool(want_grad) and self.dtype == dtype
 
 
 def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: MllWorkspace | None = None,
              want_grad: bool = True, jitter: float = 0.0):
-    """One MLL(+grad) evaluation with K resident.  Returns (out [B,8], alpha [B,N], info [B]); see
-    include/volt_hip.h for the meaning of out's columns."""
+    """One MLL(+grad) evaluation with K resident, in K's dtype: fp32 -> volt_mll_step_f32 (v_mfma_f32_32x32x2), fp64 ->
+    volt_mll_step_f64 (v_mfma_f64_16x16x4).  Returns (out [B,8], alpha [B,N], info [B]); see include/volt_hip.h for the
+    meaning of out's columns."""
     _need_gpu(K, resid, sigma2)
-    if K.ndim != 3 or K.dtype != torch.float32:
-        raise ValueError("K must be [B,N,N] fp32")
+    if K.ndim != 3 or K.dtype not in (torch.float32, torch.float64):
+        raise ValueError("K must be [B,N,N] fp32 or fp64")
+    dt = K.dtype
     B, n, _ = K.shape
     if K.stride(-1) != 1:
         K = K.contiguous()
-    resid = resid.reshape(B, n).to(torch.float32).contiguous()
-    s2 = sigma2.to(torch.float32).expand(B).contiguous()
-    if ws is None or ws.B != B or ws.N != n or ws.want_grad != bool(want_grad):
-        ws = MllWorkspace(B, n, want_grad, K.device)
-    _lib.check(_lib.lib().volt_mll_step_f32(K.data_ptr(), K.stride(1), K.stride(0), resid.data_ptr(), s2.data_ptr(),
-                                            float(jitter), ws.out.data_ptr(), ws.alpha.data_ptr(), ws.info.data_ptr(),
-                                            ws.ptr, B, n, int(want_grad), _lib.stream_ptr()), "volt_mll_step")
+    resid = resid.reshape(B, n).to(dt).contiguous()
+    s2 = sigma2.to(dt).expand(B).contiguous()
+    if ws is None or not ws.fits(B, n, want_grad, dt):
+        ws = MllWorkspace(B, n, want_grad, K.device, dt)
+    fn = _lib.lib().volt_mll_step_f32 if dt == torch.float32 else _lib.lib().volt_mll_step_f64
+    _lib.check(fn(K.data_ptr(), K.stride(1), K.stride(0), resid.data_ptr(), s2.data_ptr(), float(jitter), ws.out.data_ptr(),
+                  ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n, int(want_grad), _lib.stream_ptr()), "volt_mll_step")
     return ws.out, ws.alpha, ws.info
 
 
