@@ -110,6 +110,9 @@ __host__ __device__ inline size_t rollout_sample_floats(int H) {
 //      using the invariance (bench.py reports it as redundant bytes).
 template <int NC, bool RESUB>
 __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) {
+    // Both instantiations must round identically (the test holds them to bitwise equality), so nothing here is left
+    // to the compiler's choice of what to fuse: contraction off, every multiply-add that should be one is written as one.
+#pragma clang fp contract(off)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x * 4 + wave, g = blockIdx.y;
@@ -187,7 +190,8 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) part += cur[r][c][t] * (wv[c][t] * rd[c][t]);   // zero beyond b < a
+                            for (int t = 0; t < 4; ++t)                                            // zero beyond b < a
+                                part = __fmaf_rn(cur[r][c][t], __fmul_rn(wv[c][t], rd[c][t]), part);
                         const float dot = wave_sum_f(part);
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
@@ -213,8 +217,8 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float wfin = wraw[c][t] * rd[c][t];
-                        part += ((256 * c + 4 * lane + t < a) ? wfin : 0.f) * wfin;
+                        const float wfin = __fmul_rn(wraw[c][t], rd[c][t]);
+                        part = __fmaf_rn((256 * c + 4 * lane + t < a) ? wfin : 0.f, wfin, part);
                     }
                 const float dot = wave_sum_f(part);
 #pragma unroll
@@ -234,9 +238,9 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int b = 256 * c + 4 * lane + t;
-                wv[c][t] = (b < idx) ? wv[c][t] * rd[c][t] : 0.f;    // now wv = w_s
-                ww += wv[c][t] * wv[c][t];
-                wz += wv[c][t] * zs[c][t];
+                wv[c][t] = (b < idx) ? __fmul_rn(wv[c][t], rd[c][t]) : 0.f;    // now wv = w_s
+                ww = __fmaf_rn(wv[c][t], wv[c][t], ww);
+                wz = __fmaf_rn(wv[c][t], zs[c][t], wz);
             }
         ww = wave_sum_f(ww);
         wz = wave_sum_f(wz);
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         const float v2 = v * v;
         const float kss = (float)(base + (double)__fmul_rn(hdx, v2));      // k** - rho; last CumTrapz weight halved
         float pm = tau + wz + mstar;
-        if (p.use_theta) pm -= p.theta * (pm - p.latent[g]);
+        if (p.use_theta) pm = __fmaf_rn(-p.theta, pm - p.latent[g], pm);
         float pvar = kss - ww;
         if (!(pvar > 0.f)) {                                 // psd_safe_cholesky(pred_cov, jitter) ladder
             float jit = p.jitter;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
             if (pvar + jit > 0.f) pvar += jit;
             else { if (bad >= 0) bad = -(idx + 1); pvar = 0.f; }     // ladder exhausted: the reference raises NotPSDError
         }
-        const float smp = sqrtf(pvar) * zz[idx] + pm;
+        const float smp = __fmaf_rn(sqrtf(pvar), zz[idx], pm);
         if (lane == 0) out[idx] = smp;
 
         // ---- append the point to the conditioning set --------------------------------------------
