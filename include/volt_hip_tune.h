@@ -54,6 +54,11 @@ int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac
  * phases: stamps [B,32] int64 (load, factor32 x4 with panel / trailing updates, L out, inverse, W out, publish). */
 int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);
 
+/* The fp64 diagonal-block kernel alone on block column k, with s_memtime stamps of its phases: stamps [B,32] int64
+ * (0 start, 1 loaded, per 32-wide sub-block kb: 2+4kb factored, 3+4kb L out + inverted, 4+4kb panel, 5+4kb trailing;
+ * 18 L out, 19 W computed, 20 W out). */
+int volt_tune_diag_f64(double* A, double* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1508,6 +1508,20 @@ static StreamPool* stream_pool() {
     return pools[dev].ok ? &pools[dev] : nullptr;
 }
 
+// chol64.hip runs its look-ahead on the same pool: one auxiliary stream, the fork event and five of the join events,
+// under the pool's mutex while it enqueues -- like run_factor_groups below.
+struct VoltAux {
+    hipStream_t aux;
+    hipEvent_t fork, ev[5];
+    std::mutex* mu;
+};
+bool volt_internal_aux(VoltAux* out) {
+    StreamPool* p = stream_pool();
+    if (!p) return false;
+    *out = VoltAux{p->aux[0], p->fork, {p->join[0], p->join[1], p->join[2], p->join[3], p->join[4]}, &p->mu};
+    return true;
+}
+
 static int pick_groups(const StreamPool* pool, int B, int force) {
     int want = force > 0 ? force : (pool ? pool->want_groups : 1);
     if (want > MAX_GROUPS) want = MAX_GROUPS;

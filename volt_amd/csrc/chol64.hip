@@ -17,6 +17,9 @@
 // (volt_amd/rollout_engine.py), and gp.psd_safe_cholesky on fp64 input.
 #include "common.h"
 #include "../../include/volt_hip.h"
+#include "../../include/volt_hip_tune.h"
+#include <mutex>
+#include <stdlib.h>
 
 namespace volt {
 
@@ -151,19 +154,27 @@ __global__ __launch_bounds__(256) void prepare64_kernel(const double* __restrict
 }
 
 // ----------------------------------------------------------------------------- P1
-// grid.x = (n-k) * B, k >= 1.  Tile t: rows of block k+t, columns of block k.
-__global__ __launch_bounds__(256) void update64_kernel(double* __restrict__ A, int Np, int k, int B) {
+// A[row0 + t, k] -= sum_{m = kb0}^{kb1-1} L[row0 + t, m] L[k, m]^T for t = 0 .. ntiles-1.   grid = (ntiles * B, 1, S).
+// S > 1 cuts the K range into S slices, one workgroup each, which subtract their partial products with hardware fp64
+// atomics (global_atomic_add_f64): few matrices leave most CUs idle in the late block columns, where a launch has
+// 8 (n - k) tiles of K = 128 k each (8 x 4096, k = 28: 32 tiles on 256 CUs).  The order in which the slices land is
+// not fixed, so with S > 1 the last bits of the factor can differ from run to run (the fp32 path's slab scheme is
+// bitwise repeatable; in fp64 the spread is ~1e-16 relative and the tests hold 1e-9 .. 1e-11).
+__global__ __launch_bounds__(256) void update64_kernel(double* __restrict__ A, int Np, int k, int row0, int ntiles, int kb0,
+                                                       int kb1, int B) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    const int n = Np / TS;
     int t, b;
-    decode_tile_batch(n - k, B, t, b);
+    decode_tile_batch(ntiles, B, t, b);
+    const int S = gridDim.z, sl = blockIdx.z, len = kb1 - kb0;
+    const int c0 = kb0 + sl * len / S, c1 = kb0 + (sl + 1) * len / S;
+    if (c1 <= c0) return;
     double* Ab = A + (int64_t)b * Np * Np;
-    const double* Arows = Ab + (int64_t)(k + t) * TS * Np;
-    const double* Brows = Ab + (int64_t)k * TS * Np;
-    double* C = Ab + (int64_t)(k + t) * TS * Np + (int64_t)k * TS;
+    const double* Arows = Ab + (int64_t)(row0 + t) * TS * Np + (int64_t)c0 * TS;
+    const double* Brows = Ab + (int64_t)k * TS * Np + (int64_t)c0 * TS;
+    double* C = Ab + (int64_t)(row0 + t) * TS * Np + (int64_t)k * TS;
     f64x4 acc[16];
     zero_acc64(acc);
-    gemm64_nt_128(Arows, Np, Brows, Np, k * (TS / BK64), acc, smem);
+    gemm64_nt_128(Arows, Np, Brows, Np, (c1 - c0) * (TS / BK64), acc, smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -172,7 +183,8 @@ __global__ __launch_bounds__(256) void update64_kernel(double* __restrict__ A, i
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 VOLT_ACC64_RC(mt, nt, q)
-                C[(int64_t)r * Np + c] -= acc[mt * 4 + nt][q];
+                if (S == 1) C[(int64_t)r * Np + c] -= acc[mt * 4 + nt][q];
+                else unsafeAtomicAdd(&C[(int64_t)r * Np + c], -acc[mt * 4 + nt][q]);
             }
 }
 
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256) void trsm64_kernel(double* __restrict__ A, con
 //            that lane)
 // Round-2 first version (unblocked LDS loops): 650 us per block; this one: see DESIGN 4.8.
 constexpr int DT64 = TS + 1;
-constexpr int DIAG64_LDS_BYTES = (TS * DT64 + 2 * 32 + 32) * 8;
+constexpr int DIAG64_LDS_BYTES = (TS * DT64 + 128 + 32) * 8;
 
 // acc[tr*2+tc] (16x16 tile at rows 16 tr, cols 16 tc of a 32x32 block) += sign * A[32x32] * B[32x32]^T, A and B row-major
 // blocks of the image:  C[r][c] = sum_p A[r][p] B[c][p]
@@ -308,54 +320,98 @@ __device__ __forceinline__ void acc64_store(const f64x4 (&acc)[4], double* __res
             }
 }
 
-// 32x32 Cholesky of the image block at (32 kb, 32 kb), all 256 threads; L (lower, zeros above) replaces the block.
-__device__ __forceinline__ void chol32_f64(double* __restrict__ sT, double* __restrict__ colbuf, int kb, int& bad) {
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    double* D = sT + (32 * kb) * DT64 + 32 * kb;
-    double a[2][2];
-#pragma unroll
-    for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-        for (int ic = 0; ic < 2; ++ic) a[ia][ic] = D[(ty + 16 * ia) * DT64 + tx + 16 * ic];
-    for (int j = 0; j < 32; ++j) {
-        double* cb = colbuf + (j & 1) * 32;
-        const int jc = j >> 4, jx = j & 15;                    // column j lives in threads tx == jx, slot ic == jc
-        if (tx == jx) {
-#pragma unroll
-            for (int ia = 0; ia < 2; ++ia) cb[ty + 16 * ia] = a[ia][jc];          // unscaled column (row j holds d_j)
-        }
-        __syncthreads();
-        const double d = cb[j];
-        if (!(d > 0.0) && bad == 0) bad = 32 * kb + j + 1;     // uniform: every thread reads the same pivot
-        // 1/sqrt(d) from v_rsq_f64 + two Newton steps (full fp64 division and square root cost ~100 instructions each,
-        // three of them per pivot made this loop the longest part of the kernel); 1/d = rs^2, sqrt(d) = d rs
-        double rs = __builtin_amdgcn_rsq(d);
-        rs = rs * (1.5 - 0.5 * d * rs * rs);
-        rs = rs * (1.5 - 0.5 * d * rs * rs);
-        const double dinv = rs * rs;
-#pragma unroll
-        for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-            for (int ic = 0; ic < 2; ++ic) {
-                const int r = ty + 16 * ia, c = tx + 16 * ic;
-                if (c > j && r >= c) a[ia][ic] -= cb[r] * cb[c] * dinv;
-                else if (c == j && r >= j) a[ia][ic] = (r == j) ? d * rs : a[ia][ic] * rs;   // column j becomes L
-            }
-    }
-#pragma unroll
-    for (int ia = 0; ia < 2; ++ia)
-#pragma unroll
-        for (int ic = 0; ic < 2; ++ic) {
-            const int r = ty + 16 * ia, c = tx + 16 * ic;
-            D[r * DT64 + c] = (c <= r) ? a[ia][ic] : 0.0;
-        }
+// broadcast of a double from one lane: two v_readlane_b32 into an SGPR pair (no LDS round trip, no barrier)
+__device__ __forceinline__ double rl64(double v, int src) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// X = L^-1 for the 32x32 lower block at (32 kb, 32 kb), by lanes 0..31 of wave 0 (one column each, registers);
-// X replaces L in the image.  Call with the block complete in LDS; ends WITHOUT a barrier.
-__device__ __forceinline__ void inv32_f64(double* __restrict__ sT, int kb) {
+// c_i = fma(-l, broadcast(l, lane_i), c_i): the SGPR broadcasts (two v_readlane_b32 per double, into FIXED SGPR pairs
+// s[90:95], declared clobbered) and their FMAs pinned together in one asm block.  Left to the compiler every broadcast
+// of a pivot is hoisted to the top and spilled lane by lane through v_writelane (the fp32 block has the same story,
+// chol.hip rl_fma3); a VALU may read a readlane's SGPR two wait states after it -- groups of three cover each other,
+// shorter ones pad with s_nop.
+__device__ __forceinline__ void rl_fma64_3(double& c0, double& c1, double& c2, double l, int lo, int hi, int l0, int l1, int l2) {
+    asm volatile("v_readlane_b32 s90, %4, %6\n\tv_readlane_b32 s91, %5, %6\n\t"
+                 "v_readlane_b32 s92, %4, %7\n\tv_readlane_b32 s93, %5, %7\n\t"
+                 "v_readlane_b32 s94, %4, %8\n\tv_readlane_b32 s95, %5, %8\n\t"
+                 "v_fma_f64 %0, -%3, s[90:91], %0\n\tv_fma_f64 %1, -%3, s[92:93], %1\n\tv_fma_f64 %2, -%3, s[94:95], %2"
+                 : "+v"(c0), "+v"(c1), "+v"(c2)
+                 : "v"(l), "v"(lo), "v"(hi), "i"(l0), "i"(l1), "i"(l2)
+                 : "s90", "s91", "s92", "s93", "s94", "s95");
+}
+__device__ __forceinline__ void rl_fma64_2(double& c0, double& c1, double l, int lo, int hi, int l0, int l1) {
+    asm volatile("v_readlane_b32 s90, %3, %5\n\tv_readlane_b32 s91, %4, %5\n\t"
+                 "v_readlane_b32 s92, %3, %6\n\tv_readlane_b32 s93, %4, %6\n\t"
+                 "v_fma_f64 %0, -%2, s[90:91], %0\n\ts_nop 0\n\tv_fma_f64 %1, -%2, s[92:93], %1"
+                 : "+v"(c0), "+v"(c1)
+                 : "v"(l), "v"(lo), "v"(hi), "i"(l0), "i"(l1)
+                 : "s90", "s91", "s92", "s93");
+}
+__device__ __forceinline__ void rl_fma64_1(double& c0, double l, int lo, int hi, int l0) {
+    asm volatile("v_readlane_b32 s90, %2, %4\n\tv_readlane_b32 s91, %3, %4\n\ts_nop 1\n\t"
+                 "v_fma_f64 %0, -%1, s[90:91], %0"
+                 : "+v"(c0)
+                 : "v"(l), "v"(lo), "v"(hi), "i"(l0)
+                 : "s90", "s91");
+}
+
+// One WAVE factors the 32x32 diagonal sub-block (kb,kb) with one matrix row per lane in registers -- the idiom of the
+// fp32 diagonal block (chol.hip): per pivot the pivot and the column entries travel by v_readlane (SGPR broadcast),
+// so the 32 dependent pivots cost no barrier and no LDS round trip.  Lanes 0..31 hold the rows of the diagonal
+// sub-block; lanes 32..63 the rows of the panel block (prow,kb) below it, which the very same instructions turn into
+// L[prow,kb] = A[prow,kb] L_kk^-T -- no inverse is needed on the way down.  Several waves run this side by side, each
+// with its own copy of the (tiny) diagonal factorisation and its own panel block; the one with `own` writes L_kk and
+// the reciprocal pivots back.  (The first version -- 256 threads, 2x2 cyclic elements each, one barrier per pivot --
+// took 19.7 us per sub-block, 79 of the kernel's 139 us: scripts/tune_diag64.py.)
+__device__ __forceinline__ void pivot_phase64(double* __restrict__ sT, double* __restrict__ rdiag, int kb, int prow, bool own,
+                                              int& bad) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    const bool up = lane >= 32;
+    double* rowp = up ? sT + (32 * (prow < 0 ? kb : prow) + l31) * DT64 + 32 * kb : sT + (32 * kb + l31) * DT64 + 32 * kb;
+    const bool live = !up || prow >= 0;
+    double a[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a[c] = live ? rowp[c] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        const double d = rl64(a[j], j);                             // pivot: row j of the diagonal half
+        if (!(d > 0.0) && bad == 0) bad = 32 * kb + j + 1;          // wave-uniform
+        double rs = __builtin_amdgcn_rsq(d);                        // 1/sqrt(d): v_rsq_f64 + two Newton steps
+        rs = rs * (1.5 - 0.5 * d * rs * rs);
+        rs = rs * (1.5 - 0.5 * d * rs * rs);
+        const double l = a[j] * rs;                                 // lane r: L[r][j]  (lane j: d rs = sqrt d)
+        a[j] = l;
+        if (own && lane == 0) rdiag[32 * kb + j] = rs;              // 1 / L[j][j] for the inverse
+        // a[r][c] -= L[r][j] L[c][j] for c > j, L[c][j] broadcast from lane c of the diagonal half
+        double lv = l;
+        asm volatile("s_nop 0" : "+v"(lv));                         // a VALU result needs a wait state before v_readlane reads it
+        const unsigned long long lu = __builtin_bit_cast(unsigned long long, lv);
+        const int llo = (int)(unsigned)lu, lhi = (int)(unsigned)(lu >> 32);
+        int c = j + 1;
+#pragma unroll
+        for (; c + 2 < 32; c += 3) rl_fma64_3(a[c], a[c + 1], a[c + 2], lv, llo, lhi, c, c + 1, c + 2);
+        if (c + 1 < 32) rl_fma64_2(a[c], a[c + 1], lv, llo, lhi, c, c + 1);
+        else if (c < 32) rl_fma64_1(a[c], lv, llo, lhi, c);
+    }
+    if (up) {
+        if (prow >= 0) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) rowp[c] = a[c];
+        }
+    } else if (own) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) rowp[c] = (c <= l31) ? a[c] : 0.0;
+    }
+}
+
+// X = L^-1 for the 32x32 lower block at (32 kb, 32 kb), by lanes 0..31 of ONE wave (one column each, registers);
+// X replaces L in the image.  rdiag holds the reciprocal pivots.  Call with the block complete in LDS; ends WITHOUT a barrier.
+__device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double* __restrict__ rdiag, int kb) {
     double* D = sT + (32 * kb) * DT64 + 32 * kb;
-    const int c = threadIdx.x;
+    const int c = threadIdx.x & 63;
     if (c < 32) {
         double x[32];
 #pragma unroll
@@ -363,7 +419,7 @@ __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, int kb) {
             double acc = (r == c) ? 1.0 : 0.0;
 #pragma unroll
             for (int m = 0; m < r; ++m) acc -= D[r * DT64 + m] * x[m];      // x[m] == 0 for m < c
-            x[r] = acc / D[r * DT64 + r];
+            x[r] = acc * rdiag[32 * kb + r];
         }
         // every lane has read all of L it needs (its own column's rows >= c only use L, never X): write after a wave barrier
         __builtin_amdgcn_wave_barrier();
@@ -372,42 +428,60 @@ __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, int kb) {
     }
 }
 
+#define VOLT_STAMP64(i)                                                                \
+    do {                                                                               \
+        if (STAMP && threadIdx.x == 0) stamps[32 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+template <bool STAMP>
 __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, double* __restrict__ Winv,
-                                                     int* __restrict__ info, int Np, int k) {
+                                                     int* __restrict__ info, int Np, int k, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double sT[];
-    double* colbuf = sT + TS * DT64;       // 2 x 32 doubles
+    VOLT_STAMP64(0);
+    double* colbuf = sT + TS * DT64;       // 128 doubles: the reciprocal pivots
     const int n = Np / TS, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     double* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
     double* W = Winv + ((int64_t)b * n + k) * TS * TS;
-    for (int e = tid; e < TS * TS; e += NT) {
-        const int r = e >> 7, c = e & 127;
-        sT[r * DT64 + c] = (c <= r) ? D[(int64_t)r * Np + c] : 0.0;
+    {   // lower triangle in, 8 x 16-byte loads per thread in flight (one load per iteration cost 7 us of latency)
+        constexpr int PER = TS * TS / 2 / NT;                     // 32 double pairs per thread
+#pragma unroll
+        for (int it0 = 0; it0 < PER; it0 += 8) {
+            f64x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
+                v[u] = f64x2{0.0, 0.0};
+                if (c <= r) v[u] = *reinterpret_cast<const f64x2*>(D + (int64_t)r * Np + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
+                sT[r * DT64 + c] = v[u][0];
+                sT[r * DT64 + c + 1] = (c + 1 <= r) ? v[u][1] : 0.0;
+            }
+        }
     }
     __syncthreads();
+    VOLT_STAMP64(1);
     int bad = 0;
+    double* rdiag = colbuf;                // 128 reciprocal pivots
+    // Sub-block column kb: pivot waves w < max(1, 3 - kb) factor (kb,kb) with the panel block (kb+1+w, kb) riding along;
+    // a wave that has no panel block left inverts the previous diagonal sub-block meanwhile (X_kb is only needed for W).
     for (int kb = 0; kb < 4; ++kb) {
-        chol32_f64(sT, colbuf, kb, bad);
+        const int npw = kb < 3 ? 3 - kb : 1;
+        if (wave < npw) {
+            pivot_phase64(sT, rdiag, kb, kb + 1 + wave <= 3 ? kb + 1 + wave : -1, wave == 0, bad);
+        } else if (kb >= 1 && wave == 3) {
+            inv32_f64(sT, rdiag, kb - 1);
+        }
         __syncthreads();
-        // L_kk out (zeros above the diagonal), then X_kb replaces it in the image
+        VOLT_STAMP64(2 + 4 * kb);
+        // L_kk out (zeros above the diagonal)
         for (int e = tid; e < 32 * 32; e += NT) {
             const int r = e >> 5, c = e & 31;
             D[(int64_t)(32 * kb + r) * Np + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
         }
-        __syncthreads();
-        inv32_f64(sT, kb);
-        __syncthreads();
+        VOLT_STAMP64(3 + 4 * kb);
         if (kb == 3) break;
-        // panel: L[i,kb] = A[i,kb] X_kb^T, block row i = kb+1+wave
-        if (kb + 1 + wave <= 3) {
-            const int i = kb + 1 + wave;
-            double* P = sT + (32 * i) * DT64 + 32 * kb;
-            f64x4 acc[4];
-            acc64_zero(acc);
-            mm64_nt<false>(acc, P, sT + (32 * kb) * DT64 + 32 * kb);
-            __builtin_amdgcn_wave_barrier();
-            acc64_store(acc, P, 1.0);
-        }
-        __syncthreads();
         // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to the 4 waves
         int cnt = 0;
         for (int i = kb + 1; i <= 3; ++i)
@@ -421,12 +495,32 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, dou
                 }
             }
         __syncthreads();
+        VOLT_STAMP64(5 + 4 * kb);
     }
-    // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal
-    for (int e = tid; e < TS * TS; e += NT) {
-        const int r = e >> 7, c = e & 127;
-        if ((r >> 5) != (c >> 5)) D[(int64_t)r * Np + c] = (c < r) ? sT[r * DT64 + c] : 0.0;
+    __syncthreads();                       // the L_33 store above reads the image
+    if (wave == 3) inv32_f64(sT, rdiag, 3);
+    __syncthreads();
+    // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal: 16-byte stores, the
+    // LDS reads of 8 of them in flight at a time
+    {
+        constexpr int PER = TS * TS / 2 / NT;
+#pragma unroll
+        for (int it0 = 0; it0 < PER; it0 += 8) {
+            f64x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
+                v[u][0] = (c < r) ? sT[r * DT64 + c] : 0.0;
+                v[u][1] = (c + 1 < r) ? sT[r * DT64 + c + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
+                if ((r >> 5) != (c >> 5)) *reinterpret_cast<f64x2*>(D + (int64_t)r * Np + c) = v[u];
+            }
+        }
     }
+    VOLT_STAMP64(18);
     // ---- W = L^-1, blocked by 32: wave j < 3 owns block column j (the diagonal blocks of W are the X_kb in place)
     f64x4 Wr[3][4];
     if (wave < 3) {
@@ -452,6 +546,7 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, dou
         }
     }
     __syncthreads();                                                          // every L block has been consumed
+    VOLT_STAMP64(19);
     if (wave < 3) {
         const int j = wave;
 #pragma unroll
@@ -461,11 +556,26 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, dou
         }
     }
     __syncthreads();
-    for (int e = tid; e < TS * TS; e += NT) {
-        const int r = e >> 7, c = e & 127;
-        W[r * TS + c] = (c <= r) ? sT[r * DT64 + c] : 0.0;
+    {
+        constexpr int PER = TS * TS / 2 / NT;
+#pragma unroll
+        for (int it0 = 0; it0 < PER; it0 += 8) {
+            f64x2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
+                v[u][0] = (c <= r) ? sT[r * DT64 + c] : 0.0;
+                v[u][1] = (c + 1 <= r) ? sT[r * DT64 + c + 1] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
+                *reinterpret_cast<f64x2*>(W + r * TS + c) = v[u];
+            }
+        }
     }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
+    VOLT_STAMP64(20);
 }
 
 // ----------------------------------------------------------------------------- trtri (fp64)
@@ -480,12 +590,20 @@ __global__ __launch_bounds__(256) void trtri64_p1_kernel(const double* __restric
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     int j, b;
     decode_tile_batch(i, B, j, b);
+    // K slices (gridDim.z > 1: the slot was zeroed, the slices add their partial products with fp64 atomics -- few
+    // matrices would otherwise leave a launch as long as its longest tile on one CU, as in update64_kernel)
+    const int kb = i - j;
+    int nsl = gridDim.z < (kb + 1) / 2 ? gridDim.z : (kb + 1) / 2;
+    if (nsl < 1) nsl = 1;
+    const int sl = blockIdx.z;
+    if (sl >= nsl) return;
+    const int c0 = j + sl * kb / nsl, c1 = j + (sl + 1) * kb / nsl;
     const double* Ab = A + (int64_t)b * Np * Np;
     double* Yb = Y + (int64_t)b * Np * Np;
     f64x4 acc[16];
     zero_acc64(acc);
-    gemm64_nt_128(Yb + (int64_t)j * TS * Np + (int64_t)j * TS, Np, Ab + (int64_t)i * TS * Np + (int64_t)j * TS, Np,
-                  (i - j) * (TS / BK64), acc, smem);
+    gemm64_nt_128(Yb + (int64_t)j * TS * Np + (int64_t)c0 * TS, Np, Ab + (int64_t)i * TS * Np + (int64_t)c0 * TS, Np,
+                  (c1 - c0) * (TS / BK64), acc, smem);
     double* S = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -495,8 +613,24 @@ __global__ __launch_bounds__(256) void trtri64_p1_kernel(const double* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 VOLT_ACC64_RC(mt, nt, q)
-                S[(int64_t)r * Np + c] = acc[mt * 4 + nt][q];
+                if (gridDim.z == 1) S[(int64_t)r * Np + c] = acc[mt * 4 + nt][q];
+                else unsafeAtomicAdd(&S[(int64_t)r * Np + c], acc[mt * 4 + nt][q]);
             }
+}
+
+// zero the strictly-lower tiles of Y (the slots the sliced phase 1 accumulates into); grid (n (n-1) / 2, B)
+__global__ __launch_bounds__(256) void trtri64_zero_kernel(double* __restrict__ Y, int Np) {
+    const int t = blockIdx.x;
+    int ti = (int)((sqrtf(8.f * (float)t + 1.f) + 1.f) * 0.5f);
+    while (ti * (ti - 1) / 2 > t) --ti;
+    while ((ti + 1) * ti / 2 <= t) ++ti;
+    const int tj = t - ti * (ti - 1) / 2;                          // tj < ti
+    double* T = Y + (int64_t)blockIdx.y * Np * Np + (int64_t)ti * TS * Np + (int64_t)tj * TS;
+    const f64x2 z = {0.0, 0.0};
+    for (int e = threadIdx.x; e < TS * TS / 2; e += NT) {
+        const int r = e >> 6, c = (e & 63) * 2;
+        *reinterpret_cast<f64x2*>(T + (int64_t)r * Np + c) = z;
+    }
 }
 
 // grid: (i + 1) * B; tile j == i transposes W_i into Y[i,i]
@@ -546,6 +680,20 @@ __global__ __launch_bounds__(256) void trtri64_p2_kernel(const double* __restric
 
 using namespace volt;
 
+// chol.hip: the library's stream pool (one auxiliary stream, fork event, two more events, the enqueue mutex)
+struct VoltAux {
+    hipStream_t aux;
+    hipEvent_t fork, ev[5];
+    std::mutex* mu;
+};
+bool volt_internal_aux(VoltAux* out);
+
+#define VOLT_TRY64(call)                            \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
 extern "C" {
 
 int volt_prepare_f64(const double* K, int64_t ldk, int64_t bsk, const double* sigma2, double jitter, double* A, int B,
@@ -563,6 +711,22 @@ int volt_prepare_f64(const double* K, int64_t ldk, int64_t bsk, const double* si
     return 0;
 }
 
+int volt_tune_diag_f64(double* A, double* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!info) return -3;
+    if (B < 1) return -4;
+    if (Np < TS || Np % TS) return -5;
+    if (k < 0 || k >= Np / TS) return -6;
+    if (!stamps) return -7;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(diag64_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(diag64_kernel<true>, dim3(B), dim3(256), DIAG64_LDS_BYTES, (hipStream_t)stream, A, Winv, info, Np, k, stamps);
+    VOLT_LAUNCH_CHECK();
+    return 0;
+}
+
 int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np, void* stream) {
     if (!A) return -1;
     if (!Winv) return -2;
@@ -572,8 +736,18 @@ int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int n = Np / TS;
+    static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
+    auto slices = [&](int i) {                                   // row i: i B tiles of 1 .. i K blocks
+        int S = target / (i * B);
+        if (S > (i + 1) / 2) S = (i + 1) / 2;
+        if (S > 16) S = 16;
+        return S < 1 ? 1 : S;
+    };
+    bool any = false;
+    for (int i = 1; i < n; ++i) any = any || slices(i) > 1;
+    if (any) hipLaunchKernelGGL(trtri64_zero_kernel, dim3(n * (n - 1) / 2, B), dim3(256), 0, s, Y, Np);
     for (int i = 0; i < n; ++i) {
-        if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B), dim3(256), 0, s, A, Y, Np, i, B);
+        if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B, 1, slices(i)), dim3(256), 0, s, A, Y, Np, i, B);
         hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), 0, s, Winv, Y, Np, i, B);
     }
     VOLT_LAUNCH_CHECK();
@@ -591,14 +765,72 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
     const int n = Np / TS;
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(diag64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(diag64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             DIAG64_LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    for (int k = 0; k < n; ++k) {
-        if (k > 0) hipLaunchKernelGGL(update64_kernel, dim3((n - k) * B), dim3(256), 0, s, A, Np, k, B);
-        hipLaunchKernelGGL(diag64_kernel, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k);
-        if (k + 1 < n) hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+    // Left-looking with a ONE-COLUMN LOOK-AHEAD on a second stream.  What column k needs from column k-1 is one K block
+    // (m = k-1); everything older can be applied a column early.  The caller's stream walks only the latency chain
+    //     C(k):  last block into the DIAGONAL tile (k,k)  ->  diagonal block (128 dependent pivots, W_k)  ->  panel solve
+    // while the auxiliary stream does the work that is merely wide:
+    //     A(k):  last block into the other tiles (i,k), i > k;  then blocks m < k into ALL tiles of column k+1
+    // (the bulk of the flops, K-sliced with fp64 atomics so that a launch has ~512 workgroups whatever the batch).
+    // Events: a = column done (C -> A), c = panel tiles ready for their solve (A -> C), b[2] = column k+1's old blocks
+    // applied (A -> next C; two of them because A(k) is enqueued before C(k) has waited for A(k-1)'s).
+    static const int look = getenv("VOLT_F64_LOOKAHEAD") ? atoi(getenv("VOLT_F64_LOOKAHEAD")) : 1;
+    static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
+    auto slices = [&](int tiles, int kblocks) {
+        int S = tiles > 0 ? target / tiles : 1;
+        if (S > kblocks / 2) S = kblocks / 2;                          // a slice is at least two K blocks long
+        if (S > 16) S = 16;
+        return S < 1 ? 1 : S;
+    };
+    VoltAux ax;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool two = look && n >= 3 && volt_internal_aux(&ax) && hipStreamIsCapturing(s, &cap) == hipSuccess;
+    if (!two) {
+        for (int k = 0; k < n; ++k) {
+            if (k > 0) {
+                const int S = slices((n - k) * B, k);
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k) * B, 1, S), dim3(256), 0, s, A, Np, k, k, n - k, 0, k, B);
+            }
+            hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
+            if (k + 1 < n) hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+        }
+        VOLT_LAUNCH_CHECK();
+        return 0;
     }
+    std::lock_guard<std::mutex> lock(*ax.mu);
+    hipEvent_t ev_a = ax.ev[0], ev_c = ax.ev[1];
+    hipEvent_t ev_b[2] = {ax.ev[2], ax.ev[3]};
+    VOLT_TRY64(hipEventRecord(ax.fork, s));
+    VOLT_TRY64(hipStreamWaitEvent(ax.aux, ax.fork, 0));
+    for (int k = 0; k < n; ++k) {
+        // ---- A(k) on the auxiliary stream (needs column k-1 complete: event a)
+        if (k >= 1) {
+            VOLT_TRY64(hipStreamWaitEvent(ax.aux, ev_a, 0));
+            if (k + 1 < n) {
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B, 1, 1), dim3(256), 0, ax.aux, A, Np, k, k + 1, n - k - 1,
+                                   k - 1, k, B);                             // block k-1 into the tiles (i,k), i > k
+                VOLT_TRY64(hipEventRecord(ev_c, ax.aux));
+                const int S = slices((n - k - 1) * B, k);
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B, 1, S), dim3(256), 0, ax.aux, A, Np, k + 1, k + 1,
+                                   n - k - 1, 0, k, B);                      // blocks m < k into every tile of column k+1
+                VOLT_TRY64(hipEventRecord(ev_b[k & 1], ax.aux));
+            }
+        }
+        // ---- C(k) on the caller's stream
+        if (k >= 1) {
+            if (k >= 2) VOLT_TRY64(hipStreamWaitEvent(s, ev_b[(k - 1) & 1], 0));   // column k's old blocks are in
+            hipLaunchKernelGGL(update64_kernel, dim3(B, 1, 1), dim3(256), 0, s, A, Np, k, k, 1, k - 1, k, B);   // block k-1 into (k,k)
+        }
+        hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
+        if (k + 1 < n) {
+            if (k >= 1) VOLT_TRY64(hipStreamWaitEvent(s, ev_c, 0));            // the panel tiles have their last block
+            hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+            VOLT_TRY64(hipEventRecord(ev_a, s));                               // column k complete
+        }
+    }
+    // every launch of the auxiliary stream has been waited for by the caller's stream (c before trsm(n-2), b before C(n-1))
     VOLT_LAUNCH_CHECK();
     return 0;
 }
