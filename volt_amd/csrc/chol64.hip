@@ -682,7 +682,7 @@ using namespace volt;
 
 // chol.hip: the library's stream pool (one auxiliary stream, fork event, two more events, the enqueue mutex)
 struct VoltAux {
-    hipStream_t aux;
+    hipStream_t aux, aux2;
     hipEvent_t fork, ev[5];
     std::mutex* mu;
 };
@@ -693,6 +693,28 @@ bool volt_internal_aux(VoltAux* out);
         hipError_t e__ = (call);                    \
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
+
+static int trtri64_slices(int i, int B) {                       // row i: i B tiles of 1 .. i K blocks
+    static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
+    int S = target / (i * B);
+    if (S > (i + 1) / 2) S = (i + 1) / 2;
+    if (S > 16) S = 16;
+    return S < 1 ? 1 : S;
+}
+static void trtri64_begin(double* Y, int B, int Np, hipStream_t s) {
+    const int n = Np / TS;
+    bool any = false;
+    for (int i = 1; i < n; ++i) any = any || trtri64_slices(i, B) > 1;
+    if (any) hipLaunchKernelGGL(trtri64_zero_kernel, dim3(n * (n - 1) / 2, B), dim3(256), 0, s, Y, Np);
+}
+static void trtri64_row(const double* A, const double* Winv, double* Y, int B, int Np, int i, hipStream_t s) {
+    if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B, 1, trtri64_slices(i, B)), dim3(256), 0, s, A, Y, Np, i, B);
+    hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), 0, s, Winv, Y, Np, i, B);
+}
+
+// Factorisation (+ optional triangular inverse Y = L^-T, row k-1 riding on a THIRD stream beside block column k: at
+// small batches the latency chain of the factorisation leaves most CUs idle, and the inverse fills them).
+int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream);
 
 extern "C" {
 
@@ -736,25 +758,19 @@ int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int n = Np / TS;
-    static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
-    auto slices = [&](int i) {                                   // row i: i B tiles of 1 .. i K blocks
-        int S = target / (i * B);
-        if (S > (i + 1) / 2) S = (i + 1) / 2;
-        if (S > 16) S = 16;
-        return S < 1 ? 1 : S;
-    };
-    bool any = false;
-    for (int i = 1; i < n; ++i) any = any || slices(i) > 1;
-    if (any) hipLaunchKernelGGL(trtri64_zero_kernel, dim3(n * (n - 1) / 2, B), dim3(256), 0, s, Y, Np);
-    for (int i = 0; i < n; ++i) {
-        if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B, 1, slices(i)), dim3(256), 0, s, A, Y, Np, i, B);
-        hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), 0, s, Winv, Y, Np, i, B);
-    }
+    trtri64_begin(Y, B, Np, s);
+    for (int i = 0; i < n; ++i) trtri64_row(A, Winv, Y, B, Np, i, s);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
 
 int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stream) {
+    return volt_internal_factor_f64(A, Winv, info, nullptr, B, Np, stream);
+}
+
+}  // extern "C"
+
+int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream) {
     if (!A) return -1;
     if (!Winv) return -2;
     if (!info) return -3;
@@ -796,14 +812,22 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
             hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
             if (k + 1 < n) hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
         }
+        if (Y) {
+            trtri64_begin(Y, B, Np, s);
+            for (int i = 0; i < n; ++i) trtri64_row(A, Winv, Y, B, Np, i, s);
+        }
         VOLT_LAUNCH_CHECK();
         return 0;
     }
     std::lock_guard<std::mutex> lock(*ax.mu);
-    hipEvent_t ev_a = ax.ev[0], ev_c = ax.ev[1];
+    hipEvent_t ev_a = ax.ev[0], ev_c = ax.ev[1], ev_d = ax.ev[4];
     hipEvent_t ev_b[2] = {ax.ev[2], ax.ev[3]};
     VOLT_TRY64(hipEventRecord(ax.fork, s));
     VOLT_TRY64(hipStreamWaitEvent(ax.aux, ax.fork, 0));
+    if (Y) {
+        VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ax.fork, 0));
+        trtri64_begin(Y, B, Np, ax.aux2);
+    }
     for (int k = 0; k < n; ++k) {
         // ---- A(k) on the auxiliary stream (needs column k-1 complete: event a)
         if (k >= 1) {
@@ -818,6 +842,11 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
                 VOLT_TRY64(hipEventRecord(ev_b[k & 1], ax.aux));
             }
         }
+        // ---- row k-1 of the triangular inverse on the third stream (needs column k-1 and W_{k-1}: event a)
+        if (Y && k >= 1) {
+            VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
+            trtri64_row(A, Winv, Y, B, Np, k - 1, ax.aux2);
+        }
         // ---- C(k) on the caller's stream
         if (k >= 1) {
             if (k >= 2) VOLT_TRY64(hipStreamWaitEvent(s, ev_b[(k - 1) & 1], 0));   // column k's old blocks are in
@@ -831,8 +860,17 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
         }
     }
     // every launch of the auxiliary stream has been waited for by the caller's stream (c before trsm(n-2), b before C(n-1))
+    if (Y) {                                                                  // the last row of the inverse, then join
+        VOLT_TRY64(hipEventRecord(ev_a, s));
+        VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
+        trtri64_row(A, Winv, Y, B, Np, n - 1, ax.aux2);
+        VOLT_TRY64(hipEventRecord(ev_d, ax.aux2));
+        VOLT_TRY64(hipStreamWaitEvent(s, ev_d, 0));
+    }
     VOLT_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" {
 
 }  // extern "C"

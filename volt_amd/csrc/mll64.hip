@@ -123,6 +123,8 @@ static Mll64Ws carve64(void* base, int B, int N, int want_grad) {
 
 using namespace volt;
 
+int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream);   // chol64.hip
+
 extern "C" {
 
 size_t volt_mll_workspace_bytes_f64(int B, int N, int want_grad) {
@@ -148,11 +150,11 @@ int volt_mll_step_f64(const double* K, int64_t ldk, int64_t bsk, const double* r
     int rc;
     hipLaunchKernelGGL(pad_resid64_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
     if ((rc = volt_prepare_f64(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
-    if ((rc = volt_potrf_f64(w.A, w.Winv, info, B, Np, stream))) return rc > 0 ? rc : -1;
+    // factorisation and (gradient step) the triangular inverse in one multi-stream schedule (chol64.hip)
+    if ((rc = volt_internal_factor_f64(w.A, w.Winv, info, want_grad ? w.Y : nullptr, B, Np, stream))) return rc > 0 ? rc : -1;
     if ((rc = volt_trsv_lower_f64(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
     if (want_grad) {
         if ((rc = volt_trsv_lower_t_f64(w.A, w.Winv, w.z, w.apad, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
-        if ((rc = volt_trtri_f64(w.A, w.Winv, w.Y, B, Np, stream))) return rc > 0 ? rc : -1;
         hipLaunchKernelGGL(frob64_kernel, dim3(n, B), dim3(256), 0, s, w.Y, w.frob, N, Np);
     }
     hipLaunchKernelGGL(mll_scalars64_kernel, dim3(B), dim3(256), 0, s, w.A, w.z, w.apad, w.frob, sigma2, jitter, out, alpha,
