@@ -343,6 +343,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_aux_legs:
         api = api_leg(x, F, vol, dev, n, B, dt / args.steps * 1e3)
 
+    # ---- fp64 leg (rank 0): the double-precision twins of the step, at the 8-GPU share of the batch
+    f64 = None
+    if rank == 0 and not args.no_aux_legs:
+        f64 = f64_leg(x, F, vol, dev, n, min(8, B))
+
     # ---- CPU baseline leg (rank 0, N=1 only): torch-CPU restatement of the gpytorch path (+ real gpytorch if present)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -373,6 +378,7 @@ def main():
                          "streams": "library-internal, forked/joined on the caller's stream"},
             "cpu_baseline": cpu,
             "api_step": api,
+            "fp64": f64,
             "rollouts": roll,
         }
         line.update(extra)
@@ -380,6 +386,51 @@ def main():
     if dist is not None:
         dist.barrier()                       # rank 0 ran the roofline legs: leave together
         dist.destroy_process_group()
+
+
+FP64_MFMA_PEAK_TF = 78.6     # v_mfma_f64_16x16x4_f64, dense (vendor figure; 64 cycles per instruction per SIMD)
+
+
+def f64_leg(x, F, vol, dev, n, B):
+    """The fp64 path (a double-precision model keeps its dtype, voltron/kernels/VolKernel.py:28-33): one batched
+    factorisation (volt_potrf_f64, N^3/3 flop per matrix) and one MLL+grad step (volt_mll_step_f64, 2N^3/3) on B series."""
+    from volt_amd import _lib, ops
+    xd = torch.tensor(x, device=dev, dtype=torch.float64)
+    K = ops.fill(ops.cumtrapz(torch.tensor(vol[:B], device=dev, dtype=torch.float64), xd, square=True))
+    s2 = torch.full((B,), 0.6932, device=dev, dtype=torch.float64)
+    r = torch.log(torch.tensor(F[:B, 1:], device=dev, dtype=torch.float64))
+    r = r - r.mean(-1, keepdim=True)
+    Np = ops.padded_n(n)
+    f = ops.potrf(K, s2)
+    Aprep = torch.empty_like(f.A)
+    L = _lib.lib()
+    _lib.check(L.volt_prepare_f64(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, Aprep.data_ptr(), B, n, _lib.stream_ptr()), "prepare")
+    ws = ops.MllWorkspace(B, n, True, dev, torch.float64)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timeit(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def potrf():
+        f.A.copy_(Aprep)
+        _lib.check(L.volt_potrf_f64(f.A.data_ptr(), f.Winv.data_ptr(), f.info.data_ptr(), B, Np, _lib.stream_ptr()), "potrf")
+    t_copy = timeit(lambda: f.A.copy_(Aprep))
+    t_potrf = timeit(potrf) - t_copy
+    t_step = timeit(lambda: ops.mll_step(K, r, s2, ws))
+    fl = B * Np ** 3 / 3
+    return {"workload": f"{B} series of N={n} in fp64 (v_mfma_f64_16x16x4_f64)",
+            "potrf_ms": round(t_potrf, 3), "potrf_tflops": round(fl / t_potrf / 1e9, 2),
+            "potrf_frac_of_fp64_mfma_peak": round(fl / t_potrf / 1e9 / FP64_MFMA_PEAK_TF, 4),
+            "mll_grad_step_ms": round(t_step, 3), "mll_grad_step_tflops": round(2 * fl / t_step / 1e9, 2),
+            "mll_grad_step_frac_of_fp64_mfma_peak": round(2 * fl / t_step / 1e9 / FP64_MFMA_PEAK_TF, 4),
+            "not_pd": int((ws.info != 0).sum().item())}
 
 
 def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):

@@ -14,10 +14,11 @@
  *     one pool of auxiliary streams and fork/join events per device, created on first use and kept for the
  *     life of the process (the batched factorisation runs groups of matrices on them, forked from and joined
  *     back into `stream`); calls on one device serialise on the host while they ENQUEUE, never on the device.
- *     And one cache of launch schedules per (device, batch size, block columns, inverse?): a few hundred KB of
- *     read-only tables in device memory the library allocates itself on the first factorisation of that shape
- *     (3 <= B < 32, csrc/sched.h) and keeps; a miss while `stream` is being captured into a graph allocates
- *     nothing and uses the table-free schedule.  Nothing else is retained between calls.
+ *     And one HOST-side cache of launch schedules per (device, batch size, block columns, inverse?): a few hundred KB
+ *     of tables in pinned host memory, built on the first factorisation of that shape (3 <= B <= 64, csrc/sched.h) and
+ *     copied asynchronously into the CALLER's workspace on every call that uses them -- the library owns no device
+ *     memory.  A cache miss while `stream` is being captured into a graph allocates nothing and uses the table-free
+ *     schedule.  Nothing else is retained between calls.
  *   - Return value: 0 = enqueued; -k = argument k (1-based) is invalid; >0 = hipError_t of a
  *     failed launch.  A matrix that is not positive definite is NOT an error return: LAPACK-style
  *     `info[b]` (0, or the 1-based index of the first non-positive / NaN pivot) is written to a

@@ -952,6 +952,8 @@ struct SplitK {
     int S;               // slice slots per tile in the grid
     int L;               // K blocks (of 128) per slice: a tile of kb blocks is cut into min(S, ceil(kb / L)) slices
     int cap;             // tile-slab rows ((n+1) tiles each) this group may use: S * B <= cap
+    int4* tab = nullptr; // caller scratch for the balanced schedule's item tables (mid-size batches), tab_bytes long
+    size_t tab_bytes = 0;
 };
 
 // Slabs are stored WRITE-THROUGH (sc1): the data goes to memory without a release fence.  A release
@@ -1322,17 +1324,20 @@ struct FactorOpts {
     const struct SchedDev* sched = nullptr;   // non-null: the host-balanced schedule (mid-size batches), needs sk.slab
 };
 
-// A balanced schedule on the device: the items of all n (+1 with a triangular inverse) launches back to back
+// A balanced schedule: the items of all n (+1 with a triangular inverse) launches back to back, in PINNED HOST memory.
+// The device copy lives in the CALLER's scratch (SplitK::tab) and is uploaded per call -- the library owns no device
+// memory.
 struct SchedDev {
-    int4* items = nullptr;
+    int4* items = nullptr;                   // pinned host
+    size_t bytes = 0;
     std::vector<int> item_off;               // per launch: where its items start (one more entry closes the last)
     int S = 0;
     int pad_lds = 0;                         // dynamic LDS bytes per workgroup: > 0 keeps it to one workgroup per CU
     int kmin = 0;                            // block columns below this run the plain one-tile-per-workgroup launch
 };
 
-// Built once per (device, B, n, inverse?, parameters) and kept for the life of the library, like the stream pool.  A
-// miss while the stream is being captured into a graph returns nullptr (no allocation, no synchronous copy inside a
+// Built once per (device, B, n, inverse?, parameters) and kept for the life of the library, like the stream pool
+// (host memory only).  A miss while the stream is being captured into a graph returns nullptr (no allocation inside a
 // capture): the caller falls back to the schedules that need no tables.
 static const SchedDev* get_sched(int B, int n, bool has_y, const SchedParams& p, hipStream_t s) {
     static std::mutex mu;
@@ -1364,12 +1369,13 @@ static const SchedDev* get_sched(int B, int n, bool has_y, const SchedParams& p,
     }
     sd->item_off.push_back((int)items.size());
     static_assert(sizeof(SchedItem) == sizeof(int4), "items are read as int4");
-    if (hipMalloc((void**)&sd->items, items.size() * sizeof(SchedItem)) != hipSuccess ||
-        hipMemcpy(sd->items, items.data(), items.size() * sizeof(SchedItem), hipMemcpyHostToDevice) != hipSuccess) {
+    sd->bytes = items.size() * sizeof(SchedItem);
+    if (hipHostMalloc((void**)&sd->items, sd->bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
-        if (sd->items) (void)hipFree(sd->items);
         delete sd;
         sd = nullptr;
+    } else {
+        memcpy(sd->items, items.data(), sd->bytes);
     }
     cache[key] = sd;                                         // a failure is remembered too: no retry per call
     return sd;
@@ -1384,6 +1390,7 @@ struct Group {
     FactorOpts o;
     int B;
     hipStream_t s;
+    hipEvent_t tab_ready = nullptr;          // the schedule tables' upload (its own stream): waited for before the first launch that reads them
 };
 
 // Timer classes: 0 = factor_step_kernel with a factorisation part (block columns 0..n-1, trtri row k-1 aboard),
@@ -1396,6 +1403,7 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     const int grid = B + npre + (n - k - 1) * B + (itri >= 0 ? (itri + 1) * B : 0);
     if (g.o.sched && k >= g.o.sched->kmin) {                 // mid-size batch, late columns: the host's list, longest piece first
         const SchedDev& sd = *g.o.sched;
+        if (k == sd.kmin && g.tab_ready) (void)hipStreamWaitEvent(g.s, g.tab_ready, 0);
         SplitK sk = g.o.sk;
         sk.S = sd.S;
         sk.L = 1;
@@ -1405,10 +1413,10 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
             const int cnt = sd.item_off[kk + 1] - sd.item_off[kk];
             if (g.o.src.K && kk < n)
                 hipLaunchKernelGGL(factor_step_sched_kernel<true>, dim3(cnt), dim3(256), sd.pad_lds, g.s, g.A, g.Winv, g.o.Y,
-                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, sd.items + sd.item_off[kk]);
+                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, g.o.sk.tab + sd.item_off[kk]);
             else
                 hipLaunchKernelGGL(factor_step_sched_kernel<false>, dim3(cnt), dim3(256), sd.pad_lds, g.s, g.A, g.Winv, g.o.Y,
-                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, sd.items + sd.item_off[kk]);
+                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, g.o.sk.tab + sd.item_off[kk]);
             if (tm) tm->end(g.s);
         }
         return;
@@ -1582,7 +1590,9 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
         const SchedDev* sd = get_sched(B / Gs, n, o.Y != nullptr, sp, s);
         // short matrices never reach the scheduled columns; below 8 matrices the alternative is the all-split schedule,
         // which is the better one while most columns are early ones (B = 4, n = 16: 0.92 ms all-split, 1.04 hybrid)
-        if (sd && n > sd->kmin + (B < 8 ? 7 : 1)) {
+        // the tables go into the caller's scratch, ahead of everything that forks from `s` (pinned source: a plain
+        // asynchronous copy, also inside a graph capture)
+        if (sd && n > sd->kmin + (B < 8 ? 7 : 1) && o.sk.tab && sd->bytes <= o.sk.tab_bytes) {
             // (the early columns as all-split launches instead of plain ones were measured too: no better, B = 7 4.13 vs 3.82)
             G = Gs;
             o1.sk.S = 2;                                     // > 1: the counters are cleared below, the slab is shared out
@@ -1591,19 +1601,33 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     }
     int rc = begin_factor(Winv, info, B, n, s, o1.sk.S > 1 ? o1.sk.count : nullptr);
     if (rc) return rc;
+    std::unique_lock<std::mutex> lock;
+    if (pool && (G > 1 || o1.sched)) lock = std::unique_lock<std::mutex>(pool->mu);
+    if (pool && (G > 1 || o1.sched)) VOLT_TRY(hipEventRecord(pool->fork, s));
+    // The schedule tables go into the caller's scratch on the pool's LAST stream, beside the early block columns (which
+    // do not read them): in the caller's stream the copy cost B = 3 .. 16 two to four per cent of a step.
+    hipEvent_t tab_ready = nullptr;
+    if (o1.sched) {
+        hipStream_t up = pool ? pool->aux[MAX_GROUPS - 2] : s;
+        if (pool) VOLT_TRY(hipStreamWaitEvent(up, pool->fork, 0));       // behind every earlier reader of that scratch
+        VOLT_TRY(hipMemcpyAsync(o1.sk.tab, o1.sched->items, o1.sched->bytes, hipMemcpyHostToDevice, up));
+        if (pool) {
+            tab_ready = pool->join[MAX_GROUPS - 2];
+            VOLT_TRY(hipEventRecord(tab_ready, up));
+        }
+    }
     if (tm) tm->start(s);
     if (G == 1) {
-        const Group g{A, Winv, info, o1, B, s};
+        Group g{A, Winv, info, o1, B, s};
+        g.tab_ready = tab_ready;
         for (int k = 0; k < n; ++k) enqueue_step(g, Np, k, tm);
         if (post) post(post_ctx, 0, B, s);
         VOLT_LAUNCH_CHECK();
         return tm && tm->err != hipSuccess ? (int)tm->err : 0;
     }
-    std::lock_guard<std::mutex> lock(pool->mu);
     const int Bg = B / G;
     const int64_t mat = (int64_t)Np * Np;
     Group grp[MAX_GROUPS];
-    VOLT_TRY(hipEventRecord(pool->fork, s));
     for (int g = 0; g < G; ++g) {
         FactorOpts og = o1;
         const int b0 = g * Bg;
@@ -1623,6 +1647,7 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
             og.red.frob += (int64_t)b0 * (n * (n + 1) / 2);
         }
         grp[g] = Group{A + b0 * mat, Winv + (int64_t)b0 * n * TS * TS, info + b0, og, Bg, g == 0 ? s : pool->aux[g - 1]};
+        grp[g].tab_ready = tab_ready;
         if (g > 0) VOLT_TRY(hipStreamWaitEvent(grp[g].s, pool->fork, 0));
     }
     for (int k = 0; k < n; ++k)
@@ -1659,15 +1684,24 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
     return 0;
 }
 
+// Upper bound of the balanced schedule's tables for B matrices of n block columns (0 where it never runs): n + 1 launches
+// of at most B diagonal items + 4 slices of B (n + 1) tiles.
+size_t volt_internal_sched_bytes(int B, int n) {
+    if (B < 3 || B > 64 || n < 8) return 0;
+    return (((size_t)(n + 1) * B * (1 + 4 * (size_t)(n + 1)) * sizeof(SchedItem)) + 255) & ~(size_t)255;
+}
+
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows) {
+                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows,
+                         void* tab, size_t tab_bytes) {
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
     // block column 0 (its diagonal tile is factored straight out of A) is copied; everything else is read from K
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
-    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N}, SplitK{sk_slab, sk_count, 1, 1, sk_rows}};
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, Y, TriReduce{rpad, zpart, frob, N},
+                 SplitK{sk_slab, sk_count, 1, 1, sk_rows, (int4*)tab, tab_bytes}};
     return run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx);
 }
 
@@ -1676,13 +1710,14 @@ int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* 
 // timed step's.  Synchronises the stream.
 int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv, float* Y,
                           int* info, const float* rpad, float* zpart, float* frob, int B, int N, int groups, void* stream,
-                          float* sk_slab, int* sk_count, int sk_rows, float* ms_sum_host, float* ms_union_host,
-                          int* launches_host, float* per_launch_host) {
+                          float* sk_slab, int* sk_count, int sk_rows, void* tab, size_t tab_bytes, float* ms_sum_host,
+                          float* ms_union_host, int* launches_host, float* per_launch_host) {
     if (groups < 0 || groups > MAX_GROUPS) return -11;
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, 0.f, A, N, Np, 1);
-    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{rpad, zpart, frob, N}, SplitK{sk_slab, sk_count, 1, 1, sk_rows}};
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{rpad, zpart, frob, N},
+                 SplitK{sk_slab, sk_count, 1, 1, sk_rows, (int4*)tab, tab_bytes}};
     LaunchTimer tm;
     const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, nullptr, nullptr, &tm, groups);
     hipError_t e = hipStreamSynchronize(s);            // the groups have joined into s
@@ -1768,11 +1803,14 @@ static size_t potrf_ws_slab_bytes(int B, int Np) {
     return (((size_t)potrf_ws_rows(B) * (Np / TS + 1) * TS * TS * sizeof(float)) + 255) & ~(size_t)255;
 }
 
+static size_t potrf_ws_count_bytes(int B, int Np) {
+    const size_t n = (size_t)Np / TS;
+    return (((n + 1) * (n + 1) * B * sizeof(int)) + 255) & ~(size_t)255;
+}
 size_t volt_potrf_workspace_bytes(int B, int Np) {
     if (B < 1 || potrf_ws_rows(B) == 0 || Np < TS || Np % TS) return 0;   // more than 64 matrices fill the chip with whole tiles
     if (Np / TS < 3) return 0;               // k <= 1: no product is long enough to be cut (slices are >= 2 K-blocks)
-    const size_t n = (size_t)Np / TS;
-    return potrf_ws_slab_bytes(B, Np) + ((((n + 1) * (n + 1) * B * sizeof(int)) + 255) & ~(size_t)255);
+    return potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np) + volt_internal_sched_bytes(B, Np / TS);
 }
 
 int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {
@@ -1782,7 +1820,7 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
     if (B < 0) return -4;
     if (Np < TS || Np % TS) return -5;
     if (B == 0) return 0;
-    SplitK sk{nullptr, nullptr, 1, 1, 0};
+    SplitK sk{nullptr, nullptr, 1, 1, 0, nullptr, 0};
     const size_t need = volt_potrf_workspace_bytes(B, Np);
     if (ws) {
         if (((uintptr_t)ws & 255) != 0) return -6;
@@ -1791,6 +1829,9 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
             sk.slab = reinterpret_cast<float*>(ws);
             sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
             sk.cap = potrf_ws_rows(B);
+            sk.tab_bytes = volt_internal_sched_bytes(B, Np / TS);
+            sk.tab = sk.tab_bytes ? reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) +
+                                                            potrf_ws_count_bytes(B, Np)) : nullptr;
         }
     }
     FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}, sk};

@@ -117,10 +117,16 @@ struct MllWs {
     float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob, *sk_slab;
     int sk_rows;
     int* sk_count;
+    void* tab;               // the balanced schedule's item tables (chol.hip), tab_bytes long
+    size_t tab_bytes;
     size_t bytes;
 };
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace volt
+size_t volt_internal_sched_bytes(int B, int n);   // chol.hip
+namespace volt {
 
 static MllWs carve(void* base, int B, int N, int want_grad) {
     const size_t Np = (size_t)volt_padded_n(N), n = Np / TS;
@@ -155,6 +161,8 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
         w.sk_slab = nullptr;
         w.sk_count = nullptr;
     }
+    w.tab_bytes = w.sk_rows ? volt_internal_sched_bytes(B, (int)n) : 0;
+    w.tab = w.tab_bytes ? take(w.tab_bytes / sizeof(float)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -169,12 +177,13 @@ using namespace volt;
 typedef void (*volt_group_post_fn)(void* ctx, int b0, int Bg, hipStream_t s);
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
-                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows);
+                         void* stream, volt_group_post_fn post, void* post_ctx, float* sk_slab, int* sk_count, int sk_rows,
+                         void* tab, size_t tab_bytes);
 
 int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv, float* Y,
                           int* info, const float* rpad, float* zpart, float* frob, int B, int N, int groups, void* stream,
-                          float* sk_slab, int* sk_count, int sk_rows, float* ms_sum_host, float* ms_union_host,
-                          int* launches_host, float* per_launch_host);
+                          float* sk_slab, int* sk_count, int sk_rows, void* tab, size_t tab_bytes, float* ms_sum_host,
+                          float* ms_union_host, int* launches_host, float* per_launch_host);
 
 namespace {
 struct TailCtx {
@@ -232,7 +241,8 @@ int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float*
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, resid, w.rpad, N, Np);
     // groups > 0 forces that many stream groups and (like the round-2 hook) switches the small-batch schedules off
     return volt_internal_profile(K, ldk, bsk, sigma2, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob, B, N, groups, stream,
-                                 w.sk_slab, w.sk_count, w.sk_rows, ms_sum_host, ms_union_host, launches_host, per_launch_host);
+                                 w.sk_slab, w.sk_count, w.sk_rows, w.tab, w.tab_bytes, ms_sum_host, ms_union_host, launches_host,
+                                 per_launch_host);
 }
 
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {
@@ -261,7 +271,7 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
                                    want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx, w.sk_slab,
-                                   w.sk_count, w.sk_rows)))
+                                   w.sk_count, w.sk_rows, w.tab, w.tab_bytes)))
         return rc > 0 ? rc : -1;
     VOLT_LAUNCH_CHECK();
     return 0;
