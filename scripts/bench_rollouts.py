@@ -1,6 +1,6 @@
 """Rollout engine timing on the GPU box (BASELINE config 5 per-GPU share: 8 series x 10k paths x 256 steps
-at N=4096 by default).  Prints sample-steps/s and the HBM roofline fraction of the per-sample kernel
-(algorithmic bytes = H^3/6 * 4 per sample: the dense forward substitution streams the factor rows)."""
+at N=4096 by default): the append-only engine (default) and, once, the full re-substitution (the round-2 engine,
+H^3/6 * 4 redundant bytes per path) -- under `rocprofv3 --kernel-trace --stats` both kernels show up by name."""
 import argparse, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -42,8 +42,12 @@ for g in range(min(G, 2)):
             val = (ys[-1] - full[-2]) + full[-1] + np.sqrt(0.5 / 252. * float(pv[g, s, i]) ** 2) * z[g, s, i]
             err = max(err, abs(val - float(samples[g, s, i])))
             ys = np.append(ys, np.float32(samples[g, s, i].item()))
-print(json.dumps({"series": G, "N": n, "samples": S, "horizon": H, "total_s": round(dt, 4),
+torch.cuda.synchronize(); t0 = time.perf_counter()
+s2, i2 = re_.rollout_series(tx, logy, lv, test_x, pvd, zd, 0, a.k, resubstitute=True)
+torch.cuda.synchronize(); dt_r = time.perf_counter() - t0
+print(json.dumps({"series": G, "N": n, "samples": S, "horizon": H, "total_s": round(dt, 5),
                   "sample_steps_per_s": round(G * S * H / dt), "non_pd_paths": bad,
                   "max_abs_dev_from_exact_one_step": err,
-                  "algorithmic_GB": round(G * S * H ** 3 / 6 * 4 / 1e9, 2),
-                  "GBps_if_kernel_only": round(G * S * H ** 3 / 6 * 4 / 1e9 / dt, 1)}))
+                  "algorithmic_GB": round(G * S * H * 12 / 1e9, 3),
+                  "resubstitute_total_s": round(dt_r, 4), "resubstitute_redundant_GB": round(G * S * H ** 3 / 6 * 4 / 1e9, 2),
+                  "bitwise_equal": bool(torch.equal(samples, s2))}))

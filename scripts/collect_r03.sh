@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-3 evidence in one go (GPU box, through gpurun): bench line, rocprofv3 kernel-trace summaries of the same command
+# in both schedules, the rollout and fp64 kernels' stats, PMC traffic passes, and the tables DESIGN.md quotes.
+# usage: scripts/collect_r03.sh [part ...]   parts: bench trace roll f64 pmc tables   (default: all)
+R=$PWD
+OUT=$R/gpurun_out/r03
+mkdir -p $OUT
+export TMPDIR=/tmp
+PARTS=${@:-bench trace roll f64 pmc tables}
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-aux-legs --no-rollouts"
+for P in $PARTS; do case $P in
+bench)
+  python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json;;
+trace)
+  cd /tmp
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t2 -o t2 -- python $R/bench.py $ARGS > $OUT/t2.log 2>&1
+  VOLT_GROUPS=1 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t1 -o t1 -- python $R/bench.py $ARGS > $OUT/t1.log 2>&1
+  cd $R
+  python scripts/trace_union.py $OUT/t2 > $OUT/timed_schedule_union.txt
+  python scripts/trace_union.py $OUT/t1 > $OUT/lockstep_union.txt
+  cp $(find $OUT/t2 -name "*kernel_stats.csv" | head -1) $OUT/timed_schedule_kernel_stats.csv
+  cp $(find $OUT/t1 -name "*kernel_stats.csv" | head -1) $OUT/lockstep_kernel_stats.csv
+  cat $OUT/timed_schedule_union.txt $OUT/lockstep_union.txt;;
+roll)
+  cd /tmp
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/roll -o roll -- python $R/scripts/bench_rollouts.py > $OUT/rollouts_bench.txt 2>&1
+  cd $R
+  cp $(find $OUT/roll -name "*kernel_stats.csv" | head -1) $OUT/rollouts_kernel_stats.csv
+  tail -5 $OUT/rollouts_bench.txt; head -5 $OUT/rollouts_kernel_stats.csv;;
+f64)
+  cd /tmp
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f64 -o f64 -- python $R/scripts/bench_f64_step.py r03 > $OUT/f64_table.txt 2>&1
+  cd $R
+  cp $(find $OUT/f64 -name "*kernel_stats.csv" | head -1) $OUT/f64_kernel_stats.csv
+  grep "^{" $OUT/f64_table.txt; python scripts/tune_diag64.py > $OUT/diag64_phases.txt 2>&1; tail -18 $OUT/diag64_phases.txt;;
+pmc)
+  VOLT_GROUPS=1 PMC_PASSES="sq1 fetch write" scripts/pmc.sh r03 --no-aux-legs --no-rollouts
+  python scripts/pmc_traffic.py gpurun_out/pmc_r03 4096 64 7 > gpurun_out/pmc_r03/traffic.log 2>&1
+  cp profiles/pmc_traffic.json $OUT/pmc_traffic.json; cp gpurun_out/pmc_r03/summary.txt $OUT/pmc_lockstep_summary.txt;;
+tables)
+  (echo "# scripts/small_batch.sh: ms/step of the MLL+grad step, N=4096"; bash scripts/small_batch.sh 1 2 3 4 6 8 12 16 24 32) | tee $OUT/small_batch_table.txt
+  (echo "# scripts/configs_table.sh: the MLL+grad step at BASELINE's other configurations"; bash scripts/configs_table.sh) | tee $OUT/configs_table.txt;;
+esac; done
+rm -rf $OUT/t1 $OUT/t2 $OUT/roll $OUT/f64
+ls -la $OUT
