@@ -543,3 +543,58 @@ def test_fused_adam_matches_torch_adam():
     assert int(oc._state[0]) == 30
     for a, c in zip(pa, pc):
         assert torch.allclose(a, c, rtol=2e-5, atol=2e-6), float((a - c).abs().max())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_deferred_check_replays_a_failed_stretch(va, graph, monkeypatch):
+    """The batched loops do not read the factorisation's `info` back every step (train_utils._run_iterations): a
+    failure found at the next check sends the parameters and the optimiser state back to the last clean snapshot and
+    that stretch is replayed with the per-step check.  Inject ONE spurious failure flag in the middle of a run: the
+    trained parameters must equal an undisturbed run's (the replay itself sees no failure), in the eager-deferred loop
+    and in the graph-captured one."""
+    from volt_amd import ops, train_utils
+    from volt_amd.train_utils import TrainVoltMagpieBatch
+    B, n, iters = 3, 200, 70
+    x, F, vol = sde_batch(B, n, seed=3)
+    tx, prices, v = dev(x), dev(F[:, 1:]), dev(vol)
+    ref_model, ref_lh, ref_losses = TrainVoltMagpieBatch(tx, prices, v, train_iters=iters, k=20, defer=False)
+    real = ops.mll_step
+    calls = {"n": 0, "injected": 0}
+
+    def flaky(K, resid, sigma2, ws=None, want_grad=True, jitter=0.0):
+        out, alpha, info = real(K, resid, sigma2, ws, want_grad=want_grad, jitter=jitter)
+        calls["n"] += 1
+        if calls["n"] == 33 and not graph:                  # one step of the deferred stretch reports a failed pivot
+            info[1] = 7
+            out[1, :2] = float("nan")                       # ... and hands garbage to the optimiser
+            calls["injected"] += 1
+        return out, alpha, info
+    monkeypatch.setattr(ops, "mll_step", flaky)
+    monkeypatch.setattr(train_utils, "CHECK_EVERY", 20)
+    m, lh, losses = TrainVoltMagpieBatch(tx, prices, v, train_iters=iters, k=20, graph=graph)
+    if not graph:
+        assert calls["injected"] == 1 and calls["n"] > iters          # the stretch was replayed
+    assert bool(torch.isfinite(lh.raw_noise).all())
+    assert torch.allclose(lh.raw_noise.detach(), ref_lh.raw_noise.detach(), rtol=2e-4, atol=2e-4)
+    assert torch.allclose(losses, ref_losses, rtol=1e-4, atol=1e-5)
+
+
+def test_batched_model_has_a_vol_forecaster(va):
+    """voltron/models/VoltMagpie.py:51-55 gives a batched model a (botorch multitask) vol model; here it is the batched
+    BMGP -- SamplePrediction / MeanPrediction work on batched models and agree with the per-series models."""
+    from volt_amd.gp import GaussianLikelihood
+    from volt_amd.models import VoltMagpie
+    T, n, H = 3, 120, 5
+    x, F, vol = sde_batch(T, n, seed=11)
+    tx = dev(x)
+    test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
+    mb = VoltMagpie(tx, torch.log(dev(F[:, 1:])), GaussianLikelihood(batch_shape=torch.Size([T])).cuda(), dev(vol), k=20)
+    assert mb.vol_model is not None
+    pred, pv = mb.MeanPrediction(test_x, return_vol=True)
+    assert tuple(pv.shape) == (T, H) and tuple(pred.shape)[:2] == (T, H) and bool(torch.isfinite(pred).all())
+    for t in range(T):
+        m1 = VoltMagpie(tx, torch.log(dev(F[t, 1:])), GaussianLikelihood().cuda(), dev(vol[t]), k=20)
+        pv1 = m1.vol_model.eval()(test_x).mean.exp()
+        assert torch.allclose(pv[t], pv1, rtol=2e-4, atol=1e-6)
+    smp = mb.SamplePrediction(test_x)
+    assert bool(torch.isfinite(smp).all())
