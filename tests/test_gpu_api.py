@@ -580,21 +580,22 @@ def test_deferred_check_replays_a_failed_stretch(va, graph, monkeypatch):
 
 
 def test_batched_model_has_a_vol_forecaster(va):
-    """voltron/models/VoltMagpie.py:51-55 gives a batched model a (botorch multitask) vol model; here it is the batched
-    BMGP -- SamplePrediction / MeanPrediction work on batched models and agree with the per-series models."""
+    """voltron/models/VoltronGP.py:46-50 gives a batched model a (botorch multitask) vol model; here it is the batched
+    BMGP -- SamplePrediction / MeanPrediction work on batched models, and the forecast vol agrees with per-series models."""
     from volt_amd.gp import GaussianLikelihood
-    from volt_amd.models import VoltMagpie
+    from volt_amd.models import VoltMagpie, VoltronGP
     T, n, H = 3, 120, 5
     x, F, vol = sde_batch(T, n, seed=11)
     tx = dev(x)
     test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
-    mb = VoltMagpie(tx, torch.log(dev(F[:, 1:])), GaussianLikelihood(batch_shape=torch.Size([T])).cuda(), dev(vol), k=20)
-    assert mb.vol_model is not None
+    mb = VoltronGP(tx, torch.log(dev(F[:, 1:])), GaussianLikelihood(batch_shape=torch.Size([T])).cuda(), dev(vol))
+    assert mb.vol_model is not None and VoltMagpie(tx, torch.log(dev(F[:, 1:])), GaussianLikelihood(
+        batch_shape=torch.Size([T])).cuda(), dev(vol)).vol_model is not None
     pred, pv = mb.MeanPrediction(test_x, return_vol=True)
-    assert tuple(pv.shape) == (T, H) and tuple(pred.shape)[:2] == (T, H) and bool(torch.isfinite(pred).all())
+    assert tuple(pv.shape) == (T, H) and tuple(pred.shape) == (T, H) and bool(torch.isfinite(pred).all())
     for t in range(T):
-        m1 = VoltMagpie(tx, torch.log(dev(F[t, 1:])), GaussianLikelihood().cuda(), dev(vol[t]), k=20)
+        m1 = VoltronGP(tx, torch.log(dev(F[t, 1:])), GaussianLikelihood().cuda(), dev(vol[t]))
         pv1 = m1.vol_model.eval()(test_x).mean.exp()
         assert torch.allclose(pv[t], pv1, rtol=2e-4, atol=1e-6)
     smp = mb.SamplePrediction(test_x)
-    assert bool(torch.isfinite(smp).all())
+    assert tuple(smp.shape) == (T, H) and bool(torch.isfinite(smp).all())
