@@ -272,3 +272,39 @@ def test_class_surfaces_match_the_reference():
                     got = [p.name for p in inspect.signature(cls.__init__).parameters.values()
                            if p.kind == p.POSITIONAL_OR_KEYWORD][1:]
                     assert got[:len(want)] == want, (rel, node.name, got, want)
+
+
+def test_bench_refuses_gpus_it_cannot_see():
+    """`python bench.py --gpus N` on a box with fewer than N GPUs (here: none) exits non-zero with a clear message and
+    prints NO JSON line -- it never reports an N-GPU figure from fewer ranks."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "VOLT_BENCH_ONE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    assert out.returncode == 2
+    assert "needs 2 visible GPUs" in out.stderr
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_deferred_checks_keep_one_accumulator_per_shape():
+    """gp.deferred_checks: factorisations of different batch shapes inside one iteration (an MLL step and a GPCV step,
+    two models) keep their failure flags apart; nothing is dropped when the shape changes."""
+    from volt_amd import gp
+    with gp.deferred_checks() as chk:
+        assert gp.deferred_checks.deferring() is chk
+        chk.note(torch.tensor([0, 3, 0], dtype=torch.int32))
+        chk.note(torch.tensor([0], dtype=torch.int32))                    # another shape: the first accumulator stays
+        chk.note(torch.tensor([0, 0, 0], dtype=torch.int32))
+        assert chk.any_bad() == 1
+        chk.note(torch.tensor([5], dtype=torch.int32))
+        assert chk.any_bad() == 2
+        with pytest.raises(gp.NotPSDError):
+            chk.raise_if_bad()
+        chk.clear()
+        assert chk.any_bad() == 0
+        chk.immediate = True
+        assert gp.deferred_checks.deferring() is None and gp.deferred_checks._active is chk
+    assert gp.deferred_checks._active is None
