@@ -243,14 +243,16 @@ def main():
         inf = torch.empty(B, dtype=torch.int32, device=dev)
         resid_p = (y - ops.ewma(y, EWMA_K)[..., :-1]).contiguous()
 
-        def profile(groups, reps=3):
+        def profile(groups, reps=4):
             ms_sum, ms_un, cnt = (ctypes.c_float * 2)(), (ctypes.c_float * 2)(), (ctypes.c_int * 2)()
             tot_s, tot_u = np.zeros(2), np.zeros(2)
-            for _ in range(reps):
+            for rep in range(reps + 1):                      # the first pass (event creation, cold tables) is not counted
                 # the step's own workspace: same buffers, fused reductions and scratch as the timed steps
                 _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid_p.data_ptr(), s2.data_ptr(), ws.ptr,
                                                    inf.data_ptr(), B, n, groups, _lib.stream_ptr(), ms_sum, ms_un, cnt,
                                                    None), "profile")
+                if rep == 0:
+                    continue
                 tot_s += np.array(list(ms_sum))
                 tot_u += np.array(list(ms_un))
             return tot_s / reps, tot_u / reps, list(cnt)
