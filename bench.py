@@ -248,9 +248,9 @@ def main():
             tot_s, tot_u = np.zeros(2), np.zeros(2)
             for rep in range(reps + 1):                      # the first pass (event creation, cold tables) is not counted
                 # the step's own workspace: same buffers, fused reductions and scratch as the timed steps
-                _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid_p.data_ptr(), s2.data_ptr(), ws.ptr,
-                                                   inf.data_ptr(), B, n, groups, _lib.stream_ptr(), ms_sum, ms_un, cnt,
-                                                   None), "profile")
+                _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid_p.data_ptr(), s2.data_ptr(), ws.out.data_ptr(),
+                                                   ws.alpha.data_ptr(), ws.ptr, inf.data_ptr(), B, n, groups,
+                                                   _lib.stream_ptr(), ms_sum, ms_un, cnt, None), "profile")
                 if rep == 0:
                     continue
                 tot_s += np.array(list(ms_sum))

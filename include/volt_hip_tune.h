@@ -24,19 +24,19 @@ extern "C" {
 #endif
 
 /* ---- measurement only (bench.py's roofline leg) -------------------------------------------------
- * Runs exactly the factorisation + triangular inverse of the gradient step (the MLL entry point of volt_hip.h with
- * want_grad = 1) ON THAT STEP'S OWN WORKSPACE -- same buffers, the fused z / Frobenius reductions in the trtri
- * epilogues, the split-K scratch of the small-batch schedules -- in the schedule the step uses (`groups` = 0: the
- * library's default; > 0: that many stream groups, 1 = lockstep, whole batch per launch on one stream), with every
- * launch bracketed by HIP events on the stream it is launched on.  The O(N^2) tail (sum_zpart, y_times_z, scalars) is
- * not run.  Synchronises, and writes to HOST arrays, per kernel class, the summed launch durations, the length of the
- * UNION of the launch intervals (what the class occupied of the wall clock when launches of several groups overlap)
- * and the launch counts:
+ * Runs exactly the gradient step (the MLL entry point of volt_hip.h with want_grad = 1) ON THAT STEP'S OWN WORKSPACE AND
+ * OUTPUTS -- same buffers, the fused z / Frobenius reductions in the trtri epilogues, the split-K scratch of the
+ * small-batch schedules, the O(N^2) tail (sum_zpart, y_times_z, scalars) each group runs on its stream beside the other
+ * groups' launches -- in the schedule the step uses (`groups` = 0: the library's default; > 0: that many stream groups,
+ * 1 = lockstep, whole batch per launch on one stream), with every factorisation launch bracketed by HIP events on the
+ * stream it is launched on.  Synchronises, and writes to HOST arrays, per kernel class, the summed launch durations,
+ * the length of the UNION of the launch intervals (what the class occupied of the wall clock when launches of several
+ * groups overlap) and the launch counts:
  *   [0] factor_step_kernel with a factorisation part (diagonal tile + look-ahead + panel tiles (update + solve) +
  *       trtri row k-1 in one grid, k = 0 .. n-1)          [1] factor_step_kernel carrying only the last trtri row.
- * workspace: as for the MLL step with want_grad = 1 (its workspace query, 256-byte aligned). */
+ * out [B,8], alpha [B,N], workspace: as for the MLL step with want_grad = 1. */
 int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
-                          void* workspace, int* info, int B, int N, int groups, void* stream,
+                          float* out, float* alpha, void* workspace, int* info, int B, int N, int groups, void* stream,
                           float* ms_sum_host /*[2]*/, float* ms_union_host /*[2]*/, int* launches_host /*[2]*/,
                           float* per_launch_host /* NULL, or [every launch, in enqueue order] durations in ms */);
 

@@ -19,8 +19,9 @@ per = (ctypes.c_float * (4 * nb + 16))()
 tot = np.zeros(nb + 1)
 reps = 3
 for r in range(reps + 1):
-    _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid.data_ptr(), s2.data_ptr(), ws.ptr, inf.data_ptr(), B, n,
-                                       GROUPS, _lib.stream_ptr(), ms_s, ms_u, cnt, per), "profile")
+    _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid.data_ptr(), s2.data_ptr(), ws.out.data_ptr(),
+                                       ws.alpha.data_ptr(), ws.ptr, inf.data_ptr(), B, n, GROUPS, _lib.stream_ptr(), ms_s, ms_u,
+                                       cnt, per), "profile")
     if r: tot += np.array(list(per))[:nb + 1]
 tot /= reps
 c = 128.0 ** 3

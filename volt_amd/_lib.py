@@ -53,7 +53,8 @@ _SIGS = {
 
 # measurement / tuning hooks: include/volt_hip_tune.h, not part of the drop-in boundary
 _TUNE_SIGS = {
-    "volt_profile_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    "volt_profile_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr, _ptr,
+                                        _ptr, _ptr]),
     "volt_tune_update_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _i32, _i32, _ptr]),
     "volt_sched_describe": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, C.c_float, _ptr, _i32, _ptr]),
     "volt_tune_diag_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr]),

@@ -1707,11 +1707,13 @@ int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* 
 
 // The same, with every launch bracketed by HIP events on its own stream (bench.py's roofline leg through
 // volt_profile_step_f32 in mll.hip): identical buffers, reductions and scratch, so the profiled launches ARE the
-// timed step's.  Synchronises the stream.
+// timed step's -- including, through `post`, the O(N^2) tail each group runs on its own stream beside the other groups'
+// factor launches (it is not timed itself, but it shares the GPU with the launches that are).  Synchronises the stream.
 int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv, float* Y,
                           int* info, const float* rpad, float* zpart, float* frob, int B, int N, int groups, void* stream,
-                          float* sk_slab, int* sk_count, int sk_rows, void* tab, size_t tab_bytes, float* ms_sum_host,
-                          float* ms_union_host, int* launches_host, float* per_launch_host) {
+                          float* sk_slab, int* sk_count, int sk_rows, void* tab, size_t tab_bytes, volt_group_post_fn post,
+                          void* post_ctx, float* ms_sum_host, float* ms_union_host, int* launches_host,
+                          float* per_launch_host) {
     if (groups < 0 || groups > MAX_GROUPS) return -11;
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
@@ -1719,7 +1721,7 @@ int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float*
     FactorOpts o{KSource{K, ldk, bsk, sigma2, 0.f, N}, Y, TriReduce{rpad, zpart, frob, N},
                  SplitK{sk_slab, sk_count, 1, 1, sk_rows, (int4*)tab, tab_bytes}};
     LaunchTimer tm;
-    const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, nullptr, nullptr, &tm, groups);
+    const int rc = run_factor_groups(A, Winv, info, B, Np, s, o, post, post_ctx, &tm, groups);
     hipError_t e = hipStreamSynchronize(s);            // the groups have joined into s
     tm.collect(ms_sum_host, ms_union_host, launches_host, 2, per_launch_host);
     if (rc) return rc;

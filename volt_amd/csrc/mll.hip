@@ -182,8 +182,9 @@ int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* 
 
 int volt_internal_profile(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float* A, float* Winv, float* Y,
                           int* info, const float* rpad, float* zpart, float* frob, int B, int N, int groups, void* stream,
-                          float* sk_slab, int* sk_count, int sk_rows, void* tab, size_t tab_bytes, float* ms_sum_host,
-                          float* ms_union_host, int* launches_host, float* per_launch_host);
+                          float* sk_slab, int* sk_count, int sk_rows, void* tab, size_t tab_bytes, volt_group_post_fn post,
+                          void* post_ctx, float* ms_sum_host, float* ms_union_host, int* launches_host,
+                          float* per_launch_host);
 
 namespace {
 struct TailCtx {
@@ -223,28 +224,6 @@ const float* volt_internal_mll_y(void* workspace, int B, int N) { return carve(w
 
 extern "C" {
 
-int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
-                          void* workspace, int* info, int B, int N, int groups, void* stream, float* ms_sum_host,
-                          float* ms_union_host, int* launches_host, float* per_launch_host) {
-    if (!K) return -1;
-    if (ldk < N) return -2;
-    if (!resid) return -4;
-    if (!workspace || ((uintptr_t)workspace & 255)) return -6;
-    if (!info) return -7;
-    if (B < 1 || B > 65535) return -8;
-    if (N < 1) return -9;
-    if (!ms_sum_host) return -12;
-    if (!ms_union_host) return -13;
-    if (!launches_host) return -14;
-    const int Np = volt_padded_n(N);
-    MllWs w = carve(workspace, B, N, 1);
-    hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, resid, w.rpad, N, Np);
-    // groups > 0 forces that many stream groups and (like the round-2 hook) switches the small-batch schedules off
-    return volt_internal_profile(K, ldk, bsk, sigma2, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob, B, N, groups, stream,
-                                 w.sk_slab, w.sk_count, w.sk_rows, w.tab, w.tab_bytes, ms_sum_host, ms_union_host, launches_host,
-                                 per_launch_host);
-}
-
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {
     if (B <= 0 || N <= 0) return 0;
     return carve(nullptr, B, N, want_grad).bytes;
@@ -275,6 +254,31 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
         return rc > 0 ? rc : -1;
     VOLT_LAUNCH_CHECK();
     return 0;
+}
+
+int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                          float* out, float* alpha, void* workspace, int* info, int B, int N, int groups, void* stream,
+                          float* ms_sum_host, float* ms_union_host, int* launches_host, float* per_launch_host) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!resid) return -4;
+    if (!out) return -6;
+    if (!alpha) return -7;
+    if (!workspace || ((uintptr_t)workspace & 255)) return -8;
+    if (!info) return -9;
+    if (B < 1 || B > 65535) return -10;
+    if (N < 1) return -11;
+    if (!ms_sum_host) return -14;
+    if (!ms_union_host) return -15;
+    if (!launches_host) return -16;
+    const int Np = volt_padded_n(N);
+    MllWs w = carve(workspace, B, N, 1);
+    hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, resid, w.rpad, N, Np);
+    TailCtx ctx{w, sigma2, 0.f, out, alpha, N, Np, 1};
+    // groups > 0 forces that many stream groups and (like the round-2 hook) switches the small-batch schedules off
+    return volt_internal_profile(K, ldk, bsk, sigma2, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob, B, N, groups, stream,
+                                 w.sk_slab, w.sk_count, w.sk_rows, w.tab, w.tab_bytes, mll_tail, &ctx, ms_sum_host,
+                                 ms_union_host, launches_host, per_launch_host);
 }
 
 }  // extern "C"
