@@ -23,27 +23,10 @@
 
 namespace volt {
 
-// fp64 sum over the 64 lanes, result in every lane: DPP moves of the two halves inside 16-lane rows (no LDS-pipe
-// shuffles: six ds_bpermute pairs per sum were a fifth of a rollout step's instructions), then four SGPR broadcasts.
-template <int CTRL>
-__device__ __forceinline__ double dpp_add_d(double x) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, true);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, true);
-    return x + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-__device__ __forceinline__ double lane_d(double x, int src) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 __device__ __forceinline__ double wave_sum_d(double x) {
-    x = dpp_add_d<0xB1>(x);      // quad_perm [1,0,3,2]
-    x = dpp_add_d<0x4E>(x);      // quad_perm [2,3,0,1]
-    x = dpp_add_d<0x141>(x);     // row_half_mirror
-    x = dpp_add_d<0x140>(x);     // row_mirror: every lane of a 16-lane row now holds the row sum
-    return (lane_d(x, 0) + lane_d(x, 16)) + (lane_d(x, 32) + lane_d(x, 48));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
 }
 
 
@@ -139,11 +122,6 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     float* he1 = hy + hl;
     float* he2 = he1 + hl;
     float* sw = lds + (size_t)4 * 3 * hl;                   // taps, shared by the 4 waves
-    // the path's pred_vol and z rows are staged in LDS up front: read from memory one scalar per step they put a
-    // memory latency on every one of the H dependent steps
-    float* pv = sw + k + (size_t)wave * 2 * H;
-    float* zz = pv + H;
-    const size_t row = ((size_t)g * p.S + (s < p.S ? s : 0)) * H;
     for (int j = threadIdx.x; j < k; j += 256) sw[j] = p.w[j];
     if (s < p.S) {
         for (int j = lane; j < k; j += 64) {
@@ -151,15 +129,14 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
             he1[j] = (p.mean_mode == 1 || p.mean_mode == 2) ? p.hist_e1[(size_t)g * k + j] : 0.f;
             he2[j] = (p.mean_mode == 2) ? p.hist_e2[(size_t)g * k + j] : 0.f;
         }
-        for (int j = lane; j < H; j += 64) {
-            pv[j] = p.pred_vol[row + j];
-            zz[j] = p.z[row + j];
-        }
     }
     __syncthreads();
     if (s >= p.S) return;
 
     const float tau = (float)p.tau[g], dx = p.dx[g], hdx = dx * 0.5f;
+    const size_t row = ((size_t)g * p.S + s) * H;
+    const float* pv = p.pred_vol + row;
+    const float* zz = p.z + row;
     float* out = p.samples + row;
     float* Ls = RESUB ? p.Ls + ((size_t)g * p.S + s) * rollout_sample_floats(H) : nullptr;
     // base = U_s[N+a] - rho, carried in fp64: the entries of the Schur complement S_s = C_s - rho 11' are
@@ -421,7 +398,7 @@ int volt_rollout_bordered_f32(const double* rho, const double* tau, const double
     if (G == 0 || S == 0) return 0;
     RolloutParams p{rho, tau, acc0, dx, hist_y, hist_e1, hist_e2, ema_prev, mr_latent, latent, w, pred_vol, z,
                     samples, scratch, info, G, S, H, k, mean_mode, use_theta, theta, mr_theta, jitter};
-    const size_t lds = ((size_t)4 * 3 * (k + H) + k + (size_t)4 * 2 * H) * sizeof(float);
+    const size_t lds = ((size_t)4 * 3 * (k + H) + k) * sizeof(float);
     if (lds > 160 * 1024) return -20;
     const dim3 grid((S + 3) / 4, G);
     hipStream_t s = (hipStream_t)stream;
