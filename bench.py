@@ -303,6 +303,8 @@ def main():
         pws_bytes = int(L_.volt_potrf_workspace_bytes(B, Np))   # scratch of the late-column schedule (what ops.potrf passes)
         pws = torch.empty(pws_bytes + 256, dtype=torch.uint8, device=dev) if pws_bytes else None
         pws_ptr = ((pws.data_ptr() + 255) // 256) * 256 if pws is not None else None
+        if pws is not None:
+            _lib.check(L_.volt_potrf_workspace_init_f32(pws_ptr, pws_bytes, B, Np, _lib.stream_ptr()), "potrf workspace init")
 
         def potrf_once():
             _lib.check(L_.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n,

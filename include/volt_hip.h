@@ -14,11 +14,11 @@
  *     one pool of auxiliary streams and fork/join events per device, created on first use and kept for the
  *     life of the process (the batched factorisation runs groups of matrices on them, forked from and joined
  *     back into `stream`); calls on one device serialise on the host while they ENQUEUE, never on the device.
- *     And one HOST-side cache of launch schedules per (device, batch size, block columns, inverse?): a few hundred KB
- *     of tables in pinned host memory, built on the first factorisation of that shape (3 <= B <= 64, csrc/sched.h) and
- *     copied asynchronously into the CALLER's workspace on every call that uses them -- the library owns no device
- *     memory.  A cache miss while `stream` is being captured into a graph allocates nothing and uses the table-free
- *     schedule.  Nothing else is retained between calls.
+ *     And HOST-side only: a cache of launch schedules per (batch size, block columns, inverse?) -- a few hundred KB of
+ *     tables in pinned host memory (3 <= B <= 64, csrc/sched.h) -- and a note of which caller workspaces
+ *     volt_mll_workspace_init_f32 / volt_potrf_workspace_init_f32 copied a table into.  The library owns NO device
+ *     memory; a workspace that was not initialised (or whose table region was overwritten since: every table-driven
+ *     launch checks it, info = INT_MIN + 1) simply gets the table-free schedules.
  *   - Return value: 0 = enqueued; -k = argument k (1-based) is invalid; >0 = hipError_t of a
  *     failed launch.  A matrix that is not positive definite is NOT an error return: LAPACK-style
  *     `info[b]` (0, or the 1-based index of the first non-positive / NaN pivot) is written to a
@@ -95,6 +95,10 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
  * K-slices (csrc/chol.hip: split-K below 3 matrices, the balanced schedule of csrc/sched.h for the late block columns
  * of 3..31) -- one 4096^2 matrix 4.4 -> 1.3 ms.  ws == NULL is volt_potrf_f32. */
 size_t volt_potrf_workspace_bytes(int B, int Np);
+/* Once per scratch buffer (and again should the caller have overwritten it): copies the launch-schedule table for
+ * (B, Np) into its table region, asynchronously on `stream`.  Optional -- scratch that was never initialised runs the
+ * table-free schedules (3 .. 64 matrices: 2-25 % slower in the late block columns). */
+int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void* stream);
 int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream);
 
 /* fp64 twins on v_mfma_f64_16x16x4_f64 (the reference keeps the caller's dtype, VolKernel.py:28-33; the
@@ -180,6 +184,10 @@ int volt_adam_step_f32(const void* slots, int nslots, long long total, const flo
  * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written.
  * workspace: volt_mll_workspace_bytes(B,N,want_grad) bytes, 256-byte aligned. */
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
+/* Once per workspace (and again should the caller have overwritten it): copies the launch-schedule table for this
+ * shape into the workspace, asynchronously on `stream`.  Optional, like volt_potrf_workspace_init_f32; it matters
+ * for 3 .. 31 series (the workspace of volt_gpcv_step_f32 begins with an MLL workspace: same call, want_grad = 1). */
+int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, void* stream);
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid,
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
                       int* info, void* workspace, int B, int N, int want_grad, void* stream);

@@ -478,3 +478,35 @@ def test_exact_mll_keeps_fp64_and_its_gradient(ops):
     o = vo.mll_and_grads(K.cpu().numpy(), y[0].astype(np.float64), mean[0].astype(np.float64), 0.25)
     np.testing.assert_allclose(float(val), o["mll"], rtol=1e-10)
     np.testing.assert_allclose(float(lik.raw_noise.grad), o["d_raw"], rtol=1e-8)
+
+
+# ------------------------------------------------------------------ schedule tables live in caller scratch
+def test_workspace_tables_are_optional_and_checked(ops):
+    """The balanced schedule's tables are copied into the caller's workspace by volt_mll_workspace_init_f32 (the library
+    owns no device memory).  A workspace that was never initialised runs the table-free schedules and gives the same
+    answer; one whose table was overwritten after the init is REPORTED (info = INT_MIN + 1), never followed."""
+    from volt_amd import _lib
+    B, n = 6, 3000                                  # 24 block columns: the late ones run the balanced schedule
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    r = dev(y - mean)
+    s2 = torch.full((B,), SIG2, device="cuda")
+    ws = ops.MllWorkspace(B, n, True, K.device)                      # initialised
+    out1 = ops.mll_step(K, r, s2, ws)[0].clone()
+    assert int(ws.info.abs().sum()) == 0
+    _check_vs_oracle(K[:1].cpu().numpy(), y, mean, 1e-5, out1.cpu().numpy(), ws.alpha.cpu().numpy(), [0])
+    L = _lib.lib()
+    raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 256, dtype=torch.uint8, device="cuda")   # never initialised
+    ptr = (raw.data_ptr() + 255) // 256 * 256
+    out2, alpha2 = torch.empty(B, 8, device="cuda"), torch.empty(B, n, device="cuda")
+    info2 = torch.empty(B, dtype=torch.int32, device="cuda")
+    _lib.check(L.volt_mll_step_f32(K.data_ptr(), n, n * n, r.data_ptr(), s2.data_ptr(), 0.0, out2.data_ptr(), alpha2.data_ptr(),
+                                   info2.data_ptr(), ptr, B, n, 1, _lib.stream_ptr()), "step")
+    assert int(info2.abs().sum()) == 0
+    assert torch.allclose(out2[:, :6], out1[:, :6], rtol=2e-5, atol=1e-6)
+    ws.buf.zero_()                                                   # the caller tramples its initialised workspace
+    ops.mll_step(K, r, s2, ws)
+    assert bool((ws.info == -2147483647).all())
+    _lib.check(L.volt_mll_workspace_init_f32(ws.ptr, B, n, 1, _lib.stream_ptr()), "re-init")
+    out3 = ops.mll_step(K, r, s2, ws)[0]
+    assert int(ws.info.abs().sum()) == 0 and torch.equal(out3, out1)

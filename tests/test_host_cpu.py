@@ -39,11 +39,13 @@ def test_argument_validation_without_a_device():
     assert L.volt_potrf_ws_f32(1, 1, 1, 1, 100, None, 0, None) == -5
     assert L.volt_potrf_workspace_bytes(65, 4096) == 0 and L.volt_potrf_workspace_bytes(1, 100) == 0
     assert L.volt_potrf_workspace_bytes(1, 128) == 0 and L.volt_potrf_workspace_bytes(4, 256) == 0   # nothing long enough to cut
-    tables = (33 * 8 * (1 + 4 * 33) * 16 + 255) // 256 * 256        # the balanced schedule's item tables live in caller scratch too
+    tables = ((33 * 8 * (1 + 4 * 33) + 16) * 16 + 255) // 256 * 256  # the balanced schedule's tables (+ a 16-slot header) live in caller scratch too
     assert L.volt_potrf_workspace_bytes(8, 4096) == 64 * 33 * 65536 + (33 * 33 * 8 * 4 + 255) // 256 * 256 + tables
     assert L.volt_potrf_workspace_bytes(64, 4096) > 128 * 33 * 65536
     assert L.volt_mll_workspace_bytes(64, 4096, 1) > L.volt_mll_workspace_bytes(64, 4096, 0) > 0
     assert L.volt_rollout_scratch_bytes(2, 3, 4) == 2 * 3 * 16 * 4
+    assert L.volt_mll_workspace_init_f32(None, 8, 4096, 1, None) == -1 and L.volt_potrf_workspace_init_f32(None, 0, 8, 100, None) == -4
+    assert L.volt_potrf_workspace_init_f32(None, 0, 100, 4096, None) == 0          # no scratch for that shape: nothing to do
     with pytest.raises(_lib.VoltHipError):
         _lib.check(-3, "x")
 

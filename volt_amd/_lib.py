@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- load torch's libamdhip64 first so the library bin
 from .build import LIB, build_lib, source_hash, sources_present
 
 _lib = None
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i32, _i64, _f32, _f64, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
@@ -26,6 +26,7 @@ _SIGS = {
     "volt_prepare_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _f32, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_workspace_bytes": (C.c_size_t, [_i32, _i32]),
+    "volt_potrf_workspace_init_f32": (C.c_int, [_ptr, C.c_size_t, _i32, _i32, _ptr]),
     "volt_potrf_ws_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
     "volt_prepare_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, _f64, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
@@ -41,6 +42,7 @@ _SIGS = {
     "volt_rollout_bordered_f32": (C.c_int, [_ptr] * 16 + [_i32] * 6 + [_f32] * 3 + [_ptr]),
     "volt_adam_step_f32": (C.c_int, [_ptr, _i32, C.c_longlong, _ptr, C.c_float, C.c_float, C.c_float, C.c_float, _ptr, _ptr]),
     "volt_mll_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "volt_mll_workspace_init_f32": (C.c_int, [_ptr, _i32, _i32, _i32, _ptr]),
     "volt_mll_step_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _f32, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
     "volt_mll_grad_k_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_rollout_shared_f32": (C.c_int, [_ptr] * 8 + [_i32] * 5 + [_f32, _ptr]),

@@ -1145,9 +1145,20 @@ template <bool FROMK>
 __global__ __launch_bounds__(256, 1) void factor_step_sched_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                                   float* __restrict__ Y, int* __restrict__ info, int Np,
                                                                   int k, int i_tri, int B, KSource src, TriReduce red,
-                                                                  SplitK sk, const int4* __restrict__ items) {
+                                                                  SplitK sk, const int4* __restrict__ items, int4 key0,
+                                                                  int4 key1) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     const int n = Np / TS, S = sk.S;
+    {   // the caller's scratch must still hold the table this launch was sized for (volt_*_workspace_init): anything
+        // else in there is reported, never followed
+        const int4 h0 = sk.tab[0], h1 = sk.tab[1];
+        if (h0.x != key0.x || h0.y != key0.y || h0.z != key0.z || h0.w != key0.w || h1.x != key1.x || h1.y != key1.y ||
+            h1.z != key1.z || h1.w != key1.w) {
+            if (blockIdx.x == 0)
+                for (int b = threadIdx.x; b < B; b += NT) info[b] = (int)0x80000001;
+            return;
+        }
+    }
     int* count = sk.count + (int64_t)k * B * (n + 1);        // this launch's counters
     const int4 d = items[blockIdx.x];
     const int kind = d.x & 7, b = d.x >> 3;
@@ -1325,11 +1336,13 @@ struct FactorOpts {
 };
 
 // A balanced schedule: the items of all n (+1 with a triangular inverse) launches back to back, in PINNED HOST memory.
-// The device copy lives in the CALLER's scratch (SplitK::tab) and is uploaded per call -- the library owns no device
-// memory.
+// The device copy lives in the CALLER's scratch (SplitK::tab), copied there once by volt_*_workspace_init -- the library
+// owns no device memory.
+constexpr int SCHED_HDR = 16;                  // int4 slots ahead of the items: the table's identity (two are used)
 struct SchedDev {
-    int4* items = nullptr;                   // pinned host
-    size_t bytes = 0;
+    int4* items = nullptr;                   // pinned host: SCHED_HDR header slots, then the items
+    size_t bytes = 0;                        // header + items
+    int4 key[2];                             // {magic, B, n, inverse?}, {G, S, 1000 frac, min_len}: what the kernels check
     std::vector<int> item_off;               // per launch: where its items start (one more entry closes the last)
     int S = 0;
     int pad_lds = 0;                         // dynamic LDS bytes per workgroup: > 0 keeps it to one workgroup per CU
@@ -1369,16 +1382,65 @@ static const SchedDev* get_sched(int B, int n, bool has_y, const SchedParams& p,
     }
     sd->item_off.push_back((int)items.size());
     static_assert(sizeof(SchedItem) == sizeof(int4), "items are read as int4");
-    sd->bytes = items.size() * sizeof(SchedItem);
+    sd->bytes = (SCHED_HDR + items.size()) * sizeof(SchedItem);
+    sd->key[0] = int4{0x564f4c54, B, n, has_y ? 1 : 0};
+    sd->key[1] = int4{p.G, p.S, (int)(p.frac * 1000.f), p.min_len};
     if (hipHostMalloc((void**)&sd->items, sd->bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         delete sd;
         sd = nullptr;
     } else {
-        memcpy(sd->items, items.data(), sd->bytes);
+        memset(sd->items, 0, SCHED_HDR * sizeof(SchedItem));
+        sd->items[0] = sd->key[0];
+        sd->items[1] = sd->key[1];
+        memcpy(sd->items + SCHED_HDR, items.data(), items.size() * sizeof(SchedItem));
     }
     cache[key] = sd;                                         // a failure is remembered too: no retry per call
     return sd;
+}
+
+// Which balanced schedule B matrices of n block columns get (false: none).  Gs = stream groups it runs in, sp = the
+// parameters of the per-group table; `cap` = slab rows the caller's scratch has.
+static bool sched_choice(int B, int n, bool has_y, int cap, int& Gs, SchedParams& sp) {
+    const Tunables& tn = tunables();
+    if (!tn.sched || cap < 1 || B < tn.sched_minb || B > (has_y ? tn.sched_maxb : tn.sched_maxb_potrf)) return false;
+    Gs = (tn.sched_groups > 1 && B >= 10 && B % tn.sched_groups == 0) ? tn.sched_groups : 1;
+    sp = SchedParams();
+    sp.G = tn.sched_g / Gs;
+    sp.S = std::max(1, std::min(tn.sched_s, cap / B));       // the groups share the slab: cap / Gs rows for B / Gs matrices
+    sp.frac = tn.sched_frac;
+    (void)n;
+    return true;
+}
+
+// The tables live in the CALLER's scratch, put there once by volt_*_workspace_init (below) -- the library owns no device
+// memory and copies nothing per call.  What it keeps is a host-side note of which scratch regions it initialised with
+// which table; a factorisation uses the balanced schedule only for a region it finds here (anything else gets the
+// table-free schedules), and every table-driven launch checks the header in the region against the table it expects,
+// so scratch that was overwritten since is reported (info = INT_MIN + 1), never followed.
+static std::mutex g_installed_mu;
+static std::map<std::pair<int, const void*>, const SchedDev*> g_installed;
+
+static int sched_install(void* tab, size_t tab_bytes, int B, int n, bool has_y, int cap, hipStream_t s) {
+    int Gs = 1;
+    SchedParams sp;
+    if (!tab || !sched_choice(B, n, has_y, cap, Gs, sp)) return 0;
+    const SchedDev* sd = get_sched(B / Gs, n, has_y, sp, s);
+    if (!sd || sd->bytes > tab_bytes) return 0;
+    hipError_t e = hipMemcpyAsync(tab, sd->items, sd->bytes, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_installed_mu);
+    g_installed[{dev, tab}] = sd;
+    return 0;
+}
+static const SchedDev* sched_installed(const void* tab) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_installed_mu);
+    auto it = g_installed.find({dev, tab});
+    return it == g_installed.end() ? nullptr : it->second;
 }
 
 // Everything one group of matrices needs: the batch is cut into contiguous groups that run the same
@@ -1390,7 +1452,6 @@ struct Group {
     FactorOpts o;
     int B;
     hipStream_t s;
-    hipEvent_t tab_ready = nullptr;          // the schedule tables' upload (its own stream): waited for before the first launch that reads them
 };
 
 // Timer classes: 0 = factor_step_kernel with a factorisation part (block columns 0..n-1, trtri row k-1 aboard),
@@ -1403,7 +1464,6 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
     const int grid = B + npre + (n - k - 1) * B + (itri >= 0 ? (itri + 1) * B : 0);
     if (g.o.sched && k >= g.o.sched->kmin) {                 // mid-size batch, late columns: the host's list, longest piece first
         const SchedDev& sd = *g.o.sched;
-        if (k == sd.kmin && g.tab_ready) (void)hipStreamWaitEvent(g.s, g.tab_ready, 0);
         SplitK sk = g.o.sk;
         sk.S = sd.S;
         sk.L = 1;
@@ -1413,10 +1473,12 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
             const int cnt = sd.item_off[kk + 1] - sd.item_off[kk];
             if (g.o.src.K && kk < n)
                 hipLaunchKernelGGL(factor_step_sched_kernel<true>, dim3(cnt), dim3(256), sd.pad_lds, g.s, g.A, g.Winv, g.o.Y,
-                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, g.o.sk.tab + sd.item_off[kk]);
+                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, g.o.sk.tab + SCHED_HDR + sd.item_off[kk], sd.key[0],
+                                   sd.key[1]);
             else
                 hipLaunchKernelGGL(factor_step_sched_kernel<false>, dim3(cnt), dim3(256), sd.pad_lds, g.s, g.A, g.Winv, g.o.Y,
-                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, g.o.sk.tab + sd.item_off[kk]);
+                                   g.info, Np, kk, it, B, g.o.src, g.o.Y ? g.o.red : nored, sk, g.o.sk.tab + SCHED_HDR + sd.item_off[kk], sd.key[0],
+                                   sd.key[1]);
             if (tm) tm->end(g.s);
         }
         return;
@@ -1578,21 +1640,14 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     // two streams from 10 on; the early columns the plain launch.  Measured, N = 4096, ms/step before -> after: B = 3
     // 2.90 -> 2.57, 4 3.24 -> 3.00, 6 4.21 -> 3.64, 7 4.76 -> 3.83, 8 4.60 -> 3.97, 12 5.90 -> 5.43, 20 8.79 -> 8.02,
     // 24 9.99 -> 9.20, 28 11.08 -> 10.46 (16: no change).  B = 1, 2 stay on the all-split schedule below.
-    const int sched_on = tn.sched, sched_minb = tn.sched_minb, sched_maxb = tn.sched_maxb, sched_maxb_potrf = tn.sched_maxb_potrf;
-    if (can_split && sched_on && B >= sched_minb && B <= (o.Y ? sched_maxb : sched_maxb_potrf)) {
-        const int sg = tn.sched_g, ss = tn.sched_s, sgroups = tn.sched_groups;
-        const float sf = tn.sched_frac;
-        const int Gs = (sgroups > 1 && pool && B >= 10 && B % sgroups == 0) ? sgroups : 1;
+    if (can_split) {
+        int Gs = 1;
         SchedParams sp;
-        sp.G = sg / Gs;
-        sp.S = std::max(1, std::min(ss, o.sk.cap / B));      // the groups share the slab: cap / Gs rows for B / Gs matrices
-        sp.frac = sf;
-        const SchedDev* sd = get_sched(B / Gs, n, o.Y != nullptr, sp, s);
+        const SchedDev* sd = o.sk.tab ? sched_installed(o.sk.tab) : nullptr;     // what volt_*_workspace_init put there
         // short matrices never reach the scheduled columns; below 8 matrices the alternative is the all-split schedule,
         // which is the better one while most columns are early ones (B = 4, n = 16: 0.92 ms all-split, 1.04 hybrid)
-        // the tables go into the caller's scratch, ahead of everything that forks from `s` (pinned source: a plain
-        // asynchronous copy, also inside a graph capture)
-        if (sd && n > sd->kmin + (B < 8 ? 7 : 1) && o.sk.tab && sd->bytes <= o.sk.tab_bytes) {
+        if (sd && sched_choice(B, n, o.Y != nullptr, o.sk.cap, Gs, sp) && (Gs == 1 || pool) &&
+            sd == get_sched(B / Gs, n, o.Y != nullptr, sp, s) && n > sd->kmin + (B < 8 ? 7 : 1)) {
             // (the early columns as all-split launches instead of plain ones were measured too: no better, B = 7 4.13 vs 3.82)
             G = Gs;
             o1.sk.S = 2;                                     // > 1: the counters are cleared below, the slab is shared out
@@ -1602,24 +1657,11 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     int rc = begin_factor(Winv, info, B, n, s, o1.sk.S > 1 ? o1.sk.count : nullptr);
     if (rc) return rc;
     std::unique_lock<std::mutex> lock;
-    if (pool && (G > 1 || o1.sched)) lock = std::unique_lock<std::mutex>(pool->mu);
-    if (pool && (G > 1 || o1.sched)) VOLT_TRY(hipEventRecord(pool->fork, s));
-    // The schedule tables go into the caller's scratch on the pool's LAST stream, beside the early block columns (which
-    // do not read them): in the caller's stream the copy cost B = 3 .. 16 two to four per cent of a step.
-    hipEvent_t tab_ready = nullptr;
-    if (o1.sched) {
-        hipStream_t up = pool ? pool->aux[MAX_GROUPS - 2] : s;
-        if (pool) VOLT_TRY(hipStreamWaitEvent(up, pool->fork, 0));       // behind every earlier reader of that scratch
-        VOLT_TRY(hipMemcpyAsync(o1.sk.tab, o1.sched->items, o1.sched->bytes, hipMemcpyHostToDevice, up));
-        if (pool) {
-            tab_ready = pool->join[MAX_GROUPS - 2];
-            VOLT_TRY(hipEventRecord(tab_ready, up));
-        }
-    }
+    if (pool && G > 1) lock = std::unique_lock<std::mutex>(pool->mu);
+    if (pool && G > 1) VOLT_TRY(hipEventRecord(pool->fork, s));
     if (tm) tm->start(s);
     if (G == 1) {
-        Group g{A, Winv, info, o1, B, s};
-        g.tab_ready = tab_ready;
+        const Group g{A, Winv, info, o1, B, s};
         for (int k = 0; k < n; ++k) enqueue_step(g, Np, k, tm);
         if (post) post(post_ctx, 0, B, s);
         VOLT_LAUNCH_CHECK();
@@ -1647,7 +1689,6 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
             og.red.frob += (int64_t)b0 * (n * (n + 1) / 2);
         }
         grp[g] = Group{A + b0 * mat, Winv + (int64_t)b0 * n * TS * TS, info + b0, og, Bg, g == 0 ? s : pool->aux[g - 1]};
-        grp[g].tab_ready = tab_ready;
         if (g > 0) VOLT_TRY(hipStreamWaitEvent(grp[g].s, pool->fork, 0));
     }
     for (int k = 0; k < n; ++k)
@@ -1688,7 +1729,12 @@ static int run_trtri(const float* A, const float* Winv, float* Y, int B, int Np,
 // of at most B diagonal items + 4 slices of B (n + 1) tiles.
 size_t volt_internal_sched_bytes(int B, int n) {
     if (B < 3 || B > 64 || n < 8) return 0;
-    return (((size_t)(n + 1) * B * (1 + 4 * (size_t)(n + 1)) * sizeof(SchedItem)) + 255) & ~(size_t)255;
+    return ((((size_t)(n + 1) * B * (1 + 4 * (size_t)(n + 1)) + SCHED_HDR) * sizeof(SchedItem)) + 255) & ~(size_t)255;
+}
+
+// used by mll.hip (volt_mll_workspace_init_f32)
+int volt_internal_sched_install(void* tab, size_t tab_bytes, int B, int n, int has_y, int cap, void* stream) {
+    return sched_install(tab, tab_bytes, B, n, has_y != 0, cap, (hipStream_t)stream);
 }
 
 // used by mll.hip
@@ -1813,6 +1859,19 @@ size_t volt_potrf_workspace_bytes(int B, int Np) {
     if (B < 1 || potrf_ws_rows(B) == 0 || Np < TS || Np % TS) return 0;   // more than 64 matrices fill the chip with whole tiles
     if (Np / TS < 3) return 0;               // k <= 1: no product is long enough to be cut (slices are >= 2 K-blocks)
     return potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np) + volt_internal_sched_bytes(B, Np / TS);
+}
+
+int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void* stream) {
+    if (B < 1) return -3;
+    if (Np < TS || Np % TS) return -4;
+    const size_t need = volt_potrf_workspace_bytes(B, Np);
+    if (!need) return 0;
+    if (!ws || ((uintptr_t)ws & 255)) return -1;
+    if (ws_bytes < need) return -2;
+    const size_t tb = volt_internal_sched_bytes(B, Np / TS);
+    if (!tb) return 0;
+    return sched_install(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np), tb, B, Np / TS,
+                         false, potrf_ws_rows(B), (hipStream_t)stream);
 }
 
 int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {

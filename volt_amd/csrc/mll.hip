@@ -126,6 +126,7 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace volt
 size_t volt_internal_sched_bytes(int B, int n);   // chol.hip
+int volt_internal_sched_install(void* tab, size_t tab_bytes, int B, int n, int has_y, int cap, void* stream);
 namespace volt {
 
 static MllWs carve(void* base, int B, int N, int want_grad) {
@@ -227,6 +228,15 @@ extern "C" {
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad) {
     if (B <= 0 || N <= 0) return 0;
     return carve(nullptr, B, N, want_grad).bytes;
+}
+
+int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, void* stream) {
+    if (!workspace || ((uintptr_t)workspace & 255)) return -1;
+    if (B < 1 || B > 65535) return -2;
+    if (N < 1) return -3;
+    MllWs w = carve(workspace, B, N, want_grad);
+    if (!w.tab) return 0;
+    return volt_internal_sched_install(w.tab, w.tab_bytes, B, volt_padded_n(N) / TS, want_grad, w.sk_rows, stream);
 }
 
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2, float jitter,

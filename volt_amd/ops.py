@@ -113,6 +113,8 @@ def _potrf_workspace(B: int, Np: int, device):
         if len(_POTRF_WS) >= 8:                                 # a handful of shapes is what a run has; drop the oldest
             _POTRF_WS.pop(next(iter(_POTRF_WS)))
         buf = _POTRF_WS[key] = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        _lib.check(_lib.lib().volt_potrf_workspace_init_f32(((buf.data_ptr() + 255) // 256) * 256, nbytes, B, Np,
+                                                            _lib.stream_ptr()), "volt_potrf_workspace_init")
     return ((buf.data_ptr() + 255) // 256) * 256, nbytes
 
 
@@ -198,6 +200,9 @@ class MllWorkspace:
         nbytes = query(B, N, int(want_grad))
         self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         self.ptr = (self.buf.data_ptr() + 255) // 256 * 256
+        if dtype == torch.float32:                      # the launch-schedule table of this shape, once (mid-size batches)
+            with torch.cuda.device(self.buf.device):
+                _lib.check(L.volt_mll_workspace_init_f32(self.ptr, B, N, int(want_grad), _lib.stream_ptr()), "volt_mll_workspace_init")
         self.out = torch.empty(B, 8, dtype=dtype, device=device)
         self.alpha = torch.empty(B, N, dtype=dtype, device=device)
         self.info = torch.empty(B, dtype=torch.int32, device=device)
@@ -262,6 +267,8 @@ class GpcvWorkspace:
         nbytes = _lib.lib().volt_gpcv_workspace_bytes(B, N, int(want_dk))
         self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         self.ptr = (self.buf.data_ptr() + 255) // 256 * 256
+        with torch.cuda.device(self.buf.device):        # it begins with an MLL workspace: the schedule table of that step
+            _lib.check(_lib.lib().volt_mll_workspace_init_f32(self.ptr, B, N, 1, _lib.stream_ptr()), "volt_mll_workspace_init")
         f32 = dict(dtype=torch.float32, device=device)
         self.out = torch.empty(B, 12, **f32)
         self.grad_m = torch.empty(B, N, **f32)
