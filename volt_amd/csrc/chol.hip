@@ -1619,6 +1619,12 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     // chip with a second group and pays its launches twice (64 x N=399: 0.289 ms/step as one group, 0.387 as two; 64 x
     // 1000: 0.884 / 0.926; 64 x 1400: 1.85 / 1.62; 512 x 399: 1.12 / 1.09)
     if (force_groups == 0 && (int64_t)B * (n + 1) < 700) G = 1;
+    // Inside a graph capture the groups become branches of the graph, and how the runtime maps them back onto streams at
+    // replay is not ours to say: 64 x 4096 replayed at 22.5 ms in some processes and at 34.8 ms in others.  One group is
+    // predictable (25.5 ms); captured loops are for the launch-bound sizes, which run as one group anyway.
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone;
+    if (capturing && force_groups == 0) G = 1;
     // Small batches: cut the long products into K-slices so that a launch has ~`target` workgroups (measured, N = 4096,
     // ms/step unsplit -> split: B = 1 4.5 -> 2.0, 2 4.6 -> 2.6, 4 4.7 -> 3.4, 6 4.7 -> 4.4; from B = 8 on a launch has a
     // tile per CU and splitting on ONE stream stops paying: B = 8 stays unsplit, 4.8 ms).  10 <= B <= 20: two split groups
@@ -1632,7 +1638,7 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
         G = 1;
         o1.sk.S = target;
     }
-    if (can_split && B >= 10 && B < split_maxb && pool && split_groups > 1 && B % split_groups == 0) {
+    if (can_split && !capturing && B >= 10 && B < split_maxb && pool && split_groups > 1 && B % split_groups == 0) {
         G = split_groups;
         o1.sk.S = target / G;
     }
@@ -1646,7 +1652,7 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
         const SchedDev* sd = o.sk.tab ? sched_installed(o.sk.tab) : nullptr;     // what volt_*_workspace_init put there
         // short matrices never reach the scheduled columns; below 8 matrices the alternative is the all-split schedule,
         // which is the better one while most columns are early ones (B = 4, n = 16: 0.92 ms all-split, 1.04 hybrid)
-        if (sd && sched_choice(B, n, o.Y != nullptr, o.sk.cap, Gs, sp) && (Gs == 1 || pool) &&
+        if (sd && sched_choice(B, n, o.Y != nullptr, o.sk.cap, Gs, sp) && (Gs == 1 || (pool && !capturing)) &&
             sd == get_sched(B / Gs, n, o.Y != nullptr, sp, s) && n > sd->kmin + (B < 8 ? 7 : 1)) {
             // (the early columns as all-split launches instead of plain ones were measured too: no better, B = 7 4.13 vs 3.82)
             G = Gs;
