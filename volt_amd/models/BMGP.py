@@ -3,7 +3,7 @@
 SURVEY 8(f) row 1: it supplies ``pred_vol`` at voltron/rollout_utils.py:66 through
 ``model.vol_model(test_x).sample(...)``.  Training-mode call -> prior MVN (for an MLL); eval-mode
 call -> exact-GP posterior at the test points, computed with the same HIP Cholesky / triangular
-inverse as the data model (K_s^-1 = Y Y^T, Y = L^-T) plus two plain library matmuls.
+inverse as the data model (K_s^-1 = Y Y^T, Y = L^-T), the products on the library's own MFMA GEMM (ops.gemm_nt).
 The botorch-based MultitaskBMGP (:30-56) is out of scope.
 
 Addition: ``train_y`` [T,N] builds T independent vol models over shared inputs in one object (batched kernel
