@@ -510,3 +510,25 @@ def test_workspace_tables_are_optional_and_checked(ops):
     _lib.check(L.volt_mll_workspace_init_f32(ws.ptr, B, n, 1, _lib.stream_ptr()), "re-init")
     out3 = ops.mll_step(K, r, s2, ws)[0]
     assert int(ws.info.abs().sum()) == 0 and torch.equal(out3, out1)
+
+
+def test_mll_step_f64_at_the_strong_scaling_share(ops):
+    """8 x 4096 in fp64 -- the batch the bench's fp64 leg times, through the chain / bulk three-stream schedule with
+    K-sliced atomics: per-series residual (K + s2 I) alpha = r in fp64, and first / last series against the fp64 oracle."""
+    B, n = 8, 4096
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol.astype(np.float64)), dev(x.astype(np.float64)), square=True))
+    y64, m64 = y.astype(np.float64), mean.astype(np.float64)
+    s2 = torch.full((B,), float(vo.noise_from_raw(1e-5)), device="cuda", dtype=torch.float64)
+    r = dev(y64 - m64)
+    out, alpha, info = ops.mll_step(K, r, s2)
+    assert int(info.abs().sum()) == 0 and out.dtype == torch.float64
+    back = (K @ alpha.unsqueeze(-1)).squeeze(-1) + s2.unsqueeze(-1) * alpha          # test-side check, not product code
+    assert float(((back - r).norm(dim=-1) / r.norm(dim=-1)).max()) < 1e-10
+    assert torch.unique(out[:, 0]).numel() == B
+    rows = [0, B - 1]
+    o = vo.mll_and_grads(K[rows].cpu().numpy(), y64[rows], m64[rows], 1e-5)
+    oh = out[rows].cpu().numpy()
+    np.testing.assert_allclose(oh[:, 0], o["mll"], rtol=1e-8)
+    np.testing.assert_allclose(oh[:, 4], o["trinv"], rtol=1e-8)
+    np.testing.assert_allclose(oh[:, 1], 0.5 * (o["aa"] - o["trinv"]) / n, rtol=1e-6)
