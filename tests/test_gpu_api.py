@@ -599,3 +599,27 @@ def test_batched_model_has_a_vol_forecaster(va):
         assert torch.allclose(pv[t], pv1, rtol=2e-4, atol=1e-6)
     smp = mb.SamplePrediction(test_x)
     assert tuple(smp.shape) == (T, H) and bool(torch.isfinite(smp).all())
+
+
+def test_batched_driver_isolates_a_failing_series(va, tmp_path, capsys):
+    """One ticker whose volatility path is NaN must not take the window down: the batched pass fails, the window is redone
+    series by series, the bad ticker gets NaN samples and a "Failed:" line (the reference's per-ticker try / except,
+    experiments/stocks/GenerateMultiMeanPreds.py:185-198), the others finite forecasts."""
+    from volt_amd.forecast import GenerateStockPredictionsBatch, realised_vol
+    B, T, ntrain, H, S = 3, 66, 64, 4, 5
+    x, F, vol = sde_batch(B, T - 1, seed=5)
+    closes = dev(F)
+
+    def vol_fn(train_x, train_y):
+        v = realised_vol(train_x, train_y)
+        v[train_y[:, 5] == closes[1, 5]] = float("nan")          # ticker BBB, in the batch of three and alone
+        return v
+    with pytest.warns(Warning):
+        out = GenerateStockPredictionsBatch(["AAA", "BBB", "CCC"], closes[:, :-1], forecast_horizon=H, train_iters=3, nsample=S,
+                                            ntrain=ntrain, mean="ewma", save=True, k=10, ntimes=1, vol_iters=2, vol_fn=vol_fn,
+                                            par_dir=str(tmp_path))
+    assert tuple(out.shape) == (B, S, H)
+    assert bool(torch.isnan(out[1]).all()) and bool(torch.isfinite(out[0]).all()) and bool(torch.isfinite(out[2]).all())
+    assert "Failed:  BBB" in capsys.readouterr().out
+    saved = torch.load(next((tmp_path / "BBB").iterdir()))
+    assert bool(torch.isnan(saved).all())

@@ -16,10 +16,12 @@ estimator kept for quick smoke runs.
 from __future__ import annotations
 
 import os
+import warnings
 
 import torch
 
 from . import rollout_engine
+from .gp import NanError, NotPSDError, NumericalWarning
 from .distributed import shard_range
 from .rollout_utils import _posterior_draw
 from .train_utils import LearnGPCV, TrainVoltMagpieBatch, TrainVolModelBatch
@@ -58,36 +60,61 @@ def _standard_mean_prediction(model, train_x, log_y, vol, test_x, pred_vol, z):
     return out
 
 
+def _window_pass(train_x, test_x, train_y, nsample, mean, k, gpcv_iters, vol_iters, data_iters, theta, vol_fn, generator,
+                 graph, debug=None):
+    """One window for the series in train_y [b, ntrain] (prices): GPCV -> data model -> vol forecasters -> rollouts,
+    every stage for all b series at once.  Returns samples [b, S, H] on the device."""
+    dev = train_y.device
+    b, H = train_y.shape[0], test_x.numel()
+    if vol_fn is None:
+        vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters, graph=graph)           # all series at once
+    else:
+        vol = vol_fn(train_x, train_y)                                                   # [b, ntrain-1]
+    model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean,
+                                        graph=graph)
+    vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters, graph=graph)
+    vmod.eval()
+    pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous().detach()   # [b,S,H]
+    z = torch.randn(b, nsample, H, device=dev, generator=generator)
+    latent = train_y.log().mean(-1) if theta is not None else None                       # rollout_utils.py:60-63
+    if mean in _MODES:                                                                   # Rollouts, :110-112
+        samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
+                                                      _MODES[mean], k, latent_mean=latent, theta=theta)
+        if bool((info < 0).any()):                      # psd_safe_cholesky(pred_cov) would have raised for these paths (:46)
+            raise NotPSDError("rollouts: predictive variance not positive after the jitter ladder")
+    else:                                                                                # VOLT + standard mean, :113-119
+        samples = _standard_mean_prediction(model, train_x, train_y[:, 1:].log(), vol, test_x, pred_vol, z)
+    if debug is not None:
+        debug.update(vol=vol, pred_vol=pred_vol, z=z, model=model, train_y=train_y)
+    return samples.detach()                                                              # .detach(): :118
+
+
 def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample, mean, k, gpcv_iters, vol_iters,
                       data_iters, theta, vol_fn, generator, save, path_fn, debug=None, graph=False):
-    """One batched pass per window: GPCV -> data model -> vol forecasters -> rollouts, every stage for all series of
-    this rank at once.  series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e].
+    """One batched pass per window (series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e]).
+    A numerical failure anywhere in the batched pass (NotPSDError / NanError after the jitter ladders) must not take the
+    other series down with it: the window is then redone one series at a time, and a series that still fails gets NaN
+    samples and a "Failed:" line -- what the reference's per-ticker try / except does
+    (experiments/stocks/GenerateMultiMeanPreds.py:185-198).
     ``debug`` (a dict) receives the last window's intermediates (vol, pred_vol, z, model) for tests."""
-    dev = series.device
     B = series.shape[0]
     H = test_x.numel()
+    args = (nsample, mean, k, gpcv_iters, vol_iters, data_iters, theta, vol_fn, generator, graph)
     last = None
     for last_day in end_idxs:
         train_y = series[:, last_day - ntrain:last_day].float()                          # [B, ntrain] prices
-        if vol_fn is None:
-            vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters, graph=graph)       # all series at once
-        else:
-            vol = vol_fn(train_x, train_y)                                               # [B, ntrain-1]
-        model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean,
-                                            graph=graph)
-        vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters, graph=graph)
-        vmod.eval()
-        pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous().detach()   # [B,S,H]
-        z = torch.randn(B, nsample, H, device=dev, generator=generator)
-        latent = train_y.log().mean(-1) if theta is not None else None                   # rollout_utils.py:60-63
-        if mean in _MODES:                                                               # Rollouts, :110-112
-            samples, info = rollout_engine.rollout_series(train_x, train_y[:, 1:].log(), vol.log(), test_x, pred_vol, z,
-                                                          _MODES[mean], k, latent_mean=latent, theta=theta)
-        else:                                                                            # VOLT + standard mean, :113-119
-            samples = _standard_mean_prediction(model, train_x, train_y[:, 1:].log(), vol, test_x, pred_vol, z)
-        if debug is not None:
-            debug.update(vol=vol, pred_vol=pred_vol, z=z, model=model, train_y=train_y)
-        last = samples.detach().cpu()                                                    # .detach(): :118
+        try:
+            samples = _window_pass(train_x, test_x, train_y, *args, debug=debug)
+        except (NotPSDError, NanError) as err:
+            warnings.warn(f"window ending at {last_day}: the batched pass failed ({err}); redoing it series by series",
+                          NumericalWarning)
+            samples = torch.full((B, nsample, H), float("nan"), device=series.device)
+            for b in range(B):
+                try:
+                    samples[b] = _window_pass(train_x, test_x, train_y[b:b + 1], *args)[0]
+                except (NotPSDError, NanError):
+                    print("Failed: ", names[b], mean, k)
+        last = samples.cpu()
         if save:
             for b, name in enumerate(names):
                 path = path_fn(name, last_day)
