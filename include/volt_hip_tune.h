@@ -60,6 +60,12 @@ int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, l
  * 18 L out, 19 W computed, 20 W out). */
 int volt_tune_diag_f64(double* A, double* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream);
 
+/* The one-launch step for short series (csrc/chol.hip, small_step_kernel): while `stamps` (device, 16 int64 per workgroup
+ * of the launch, one per piece) is set, every workgroup of the following steps records s_memrealtime (100 MHz) at
+ * 0 entry, 1 first wait over, 2 second wait over, 3 work done, 4 published, 5 tail done / exit; the spine also 6..9 slab
+ * flag j seen, 10 last slab solved, 11 all waves there, 12 last rank-32 update done, 13 pivot image written, 14 tile out.  NULL switches it off. */
+int volt_tune_small_stamps(long long* stamps);
+
 #ifdef __cplusplus
 }
 #endif

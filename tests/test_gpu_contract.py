@@ -512,6 +512,76 @@ def test_workspace_tables_are_optional_and_checked(ops):
     assert int(ws.info.abs().sum()) == 0 and torch.equal(out3, out1)
 
 
+@pytest.mark.parametrize("B,n", [(1, 399), (3, 100), (8, 399), (64, 399), (5, 257), (16, 512), (130, 300)])
+def test_short_series_run_as_one_launch(ops, B, n):
+    """Up to four block columns (N <= 512, the reference's ntrain = 400: experiments/stocks/ForecastGenerator.py:53-91)
+    the whole gradient step is ONE launch (small_step_kernel: step-numbered flags between the pieces, the tiles below a
+    diagonal block solved by substitution behind its pivots, tails by the last-row pieces of each series).  Checked
+    against the fp64 oracle and against the launch-per-column path, which an uninitialised workspace still gets;
+    repeated calls on one workspace (the step counter in the state advances) keep giving the same bits."""
+    from volt_amd import _lib
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    r = dev(y - mean)
+    s2 = torch.full((B,), SIG2, device="cuda")
+    ws = ops.MllWorkspace(B, n, True, K.device)
+    out1 = ops.mll_step(K, r, s2, ws)[0].clone()
+    alpha1 = ws.alpha.clone()
+    assert int(ws.info.abs().sum()) == 0
+    rows = sorted({0, B // 2, B - 1})
+    _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out1.cpu().numpy(), alpha1.cpu().numpy(), rows)
+    L = _lib.lib()
+    raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 256, dtype=torch.uint8, device="cuda")   # never initialised
+    ptr = (raw.data_ptr() + 255) // 256 * 256
+    out2, alpha2 = torch.empty(B, 8, device="cuda"), torch.empty(B, n, device="cuda")
+    info2 = torch.empty(B, dtype=torch.int32, device="cuda")
+    _lib.check(L.volt_mll_step_f32(K.data_ptr(), n, n * n, r.data_ptr(), s2.data_ptr(), 0.0, out2.data_ptr(), alpha2.data_ptr(),
+                                   info2.data_ptr(), ptr, B, n, 1, _lib.stream_ptr()), "step")
+    assert int(info2.abs().sum()) == 0
+    assert torch.allclose(out2[:, :6], out1[:, :6], rtol=2e-5, atol=1e-6)
+    assert float((alpha2 - alpha1).abs().max()) <= 1e-4 * float(alpha1.abs().max())
+    for _ in range(5):
+        out3 = ops.mll_step(K, r, s2, ws)[0]
+    assert torch.equal(out3, out1) and torch.equal(ws.alpha, alpha1)
+    # other inputs through the SAME workspace and back: the hand-offs between the pieces go through write-through stores
+    # and sc1 loads, not L2-wide invalidates -- nothing of the previous step may be read again
+    x_b, vol_b, y_b, mean_b = _series_problem(B, n, seed=7)
+    K_b = ops.fill(ops.cumtrapz(dev(vol_b), dev(x_b), square=True))
+    r_b = dev(y_b - mean_b)
+    fresh = ops.mll_step(K_b, r_b, s2, ops.MllWorkspace(B, n, True, K.device))
+    out_fresh, alpha_fresh = fresh[0].clone(), fresh[1].clone()
+    for _ in range(3):
+        out_b = ops.mll_step(K_b, r_b, s2, ws)[0].clone()
+        assert torch.equal(out_b, out_fresh) and torch.equal(ws.alpha, alpha_fresh)
+        assert torch.equal(ops.mll_step(K, r, s2, ws)[0], out1) and torch.equal(ws.alpha, alpha1)
+
+
+def test_short_series_state_is_checked_and_failures_reported(ops):
+    """The one-launch step follows its state only behind the header volt_mll_workspace_init_f32 wrote: a trampled workspace
+    is REPORTED (info = INT_MIN + 1) and works again after a re-init; a matrix that is not positive definite reports its
+    first failed pivot like the launch-per-column path, and the other series of the batch are untouched by it."""
+    from volt_amd import _lib
+    B, n = 4, 399
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    r = dev(y - mean)
+    s2 = torch.full((B,), SIG2, device="cuda")
+    ws = ops.MllWorkspace(B, n, True, K.device)
+    out1 = ops.mll_step(K, r, s2, ws)[0].clone()
+    ws.buf.zero_()
+    ops.mll_step(K, r, s2, ws)
+    assert bool((ws.info == -2147483647).all())
+    _lib.check(_lib.lib().volt_mll_workspace_init_f32(ws.ptr, B, n, 1, _lib.stream_ptr()), "re-init")
+    assert torch.equal(ops.mll_step(K, r, s2, ws)[0], out1) and int(ws.info.abs().sum()) == 0
+    Kbad = K.clone()
+    Kbad[2, 200, 200] = -1.0                                         # pivot 201 of series 2 fails
+    out = ops.mll_step(Kbad, r, s2, ws)[0]
+    assert ws.info.tolist() == [0, 0, 201, 0]
+    keep = [0, 1, 3]
+    assert torch.equal(out[keep], out1[keep])
+    assert torch.equal(ops.mll_step(K, r, s2, ws)[0], out1) and int(ws.info.abs().sum()) == 0
+
+
 def test_mll_step_f64_at_the_strong_scaling_share(ops):
     """8 x 4096 in fp64 -- the batch the bench's fp64 leg times, through the chain / bulk three-stream schedule with
     K-sliced atomics: per-series residual (K + s2 I) alpha = r in fp64, and first / last series against the fp64 oracle."""

@@ -422,8 +422,12 @@ __device__ __forceinline__ void pivot_phase(float* __restrict__ sT, int kb, int 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t w_rsrc(float* W) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, TS * TS * 4, 0x00020000);
 }
+// AUX = 16 (sc1): written through at agent scope -- what a workgroup on another XCD reads with an sc1 load once it has
+// seen the flag, with no L2-wide write-back / invalidate on either side (small_step_kernel's slab hand-off).
+constexpr int AUX_SC1 = 16;
+template <int AUX = 0>
 __device__ __forceinline__ void w_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, soff, AUX);
 }
 // One wave: X = L_kk^-1 in place of L_kk in the image, and out to the diagonal block kb of W in memory -- all but
 // W[0][0], the ready flag, which is published last.  The two 16x16 diagonal quarters are inverted SIDE BY SIDE, X11 in
@@ -431,7 +435,10 @@ __device__ __forceinline__ void w_store(__amdgpu_buffer_rsrc_t rs, int voff, int
 // for every lane of a half-wave and come as LDS broadcast reads -- one ds_read + one FMA per term and no row
 // registers, where the pivot loop's readlane idiom would need two instructions and serve one quarter at a time.  The
 // off-diagonal quarter X21 = -X22 L21 X11 runs on the matrix cores.
+template <bool SLABS = false>
 __device__ __forceinline__ void x_block(float* __restrict__ sT, int kb, __amdgpu_buffer_rsrc_t rs) {
+    constexpr int AUX = SLABS ? AUX_SC1 : 0;
+    constexpr bool store00 = SLABS;
     const int lane = threadIdx.x & 63, l15 = lane & 15, g = lane >> 4, h = lane >> 5;
     const bool up = (lane & 16) != 0;                                       // lanes 16..31, 48..63: no column of their own
     float* Dk = sT + (32 * kb) * DT + 32 * kb;
@@ -468,14 +475,14 @@ __device__ __forceinline__ void x_block(float* __restrict__ sT, int kb, __amdgpu
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         Dk[(16 + 4 * g + q) * DT + l15] = -r21[q];
-        w_store(rs, wbase + ((16 + 4 * g) * TS + l15) * 4, q * TS * 4, -r21[q]);                   // X21
+        w_store<AUX>(rs, wbase + ((16 + 4 * g) * TS + l15) * 4, q * TS * 4, -r21[q]);              // X21
     }
     // X11 and X22 from their lanes; lanes 16..31 write the zero quarter above X22
     if (!up || h == 0) {
         const int voff = wbase + (up ? 16 + l15 : (16 * h) * TS + 16 * h + l15) * 4;
-        if (kb != 0 || lane != 0) w_store(rs, voff, 0, up ? 0.f : x[0]);
+        if (kb != 0 || lane != 0 || store00) w_store<AUX>(rs, voff, 0, up ? 0.f : x[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) w_store(rs, voff, r * TS * 4, up ? 0.f : x[r]);
+        for (int r = 1; r < 16; ++r) w_store<AUX>(rs, voff, r * TS * 4, up ? 0.f : x[r]);
     }
 }
 
@@ -511,10 +518,15 @@ __device__ __forceinline__ void w_out(__amdgpu_buffer_rsrc_t rs, int i, int j, f
 // W[i,j] = -X_i sum_{m=j}^{i-1} L[i,m] W[m,j] (W[j,j] = X_j).  Every block of W goes to memory from the registers of
 // the wave that made it; W10, W20, W21 are also parked in the image blocks (0,1) (0,2) (1,2) ABOVE the diagonal, which
 // nothing else uses, as operands for the rows below.  The L blocks stay intact and go out after W_k has been published.
-template <bool STAMP = false>
+// SLABS (small_step_kernel): the 32-wide column slabs of the block are handed on as they are finished -- the wave that
+// inverts sub-block kb-1 also copies the blocks below it, L[kb.., kb-1], out of the image and publishes slab[kb-1] =
+// ready_val behind its own release, so that the tiles below this block are solved by substitution (substitute_tile)
+// while the later pivots are still running, and nothing on the way down waits for the inverse.
+template <bool STAMP = false, bool SLABS = false>
 __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
                                           int Np, int k, int b, float* smem, long long* stamps = nullptr,
-                                          bool loaded = false) {
+                                          bool loaded = false, int* ready = nullptr, int ready_val = 0,
+                                          int* slab = nullptr, int* pre = nullptr) {
     float* sT = smem;                                    // row-major image (row stride DT): A -> L / X / W
     VOLT_STAMP(0);
     const int n = Np / TS;
@@ -590,8 +602,29 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
             }
             if (kb == 3) park_l(3, a);                                      // no other wave reads (3,3) in this phase
         } else if (kb >= 1 && wave == xw) {
-            x_block(sT, kb - 1, wrs);
+            x_block<SLABS>(sT, kb - 1, wrs);
+            if (SLABS) {
+                // the blocks below sub-block c out of the image, written through (sc1) like X_c above; the flag follows
+                // this wave's own drain -- no L2-wide write-back: the readers use sc1 loads (substitute_tile)
+                const int c = kb - 1, row = lane >> 1, c0 = 16 * (lane & 1);
+                const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)D, 0, 0x7fffffff, 0x00020000);
+                for (int i = c + 1; i <= 3; ++i) {
+                    const float* src = blk(i, c) + row * DT + c0;
+                    const int voff = (int)((((int64_t)(32 * i + row)) * Np + 32 * c + c0) * 4);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v = {src[4 * q4], src[4 * q4 + 1], src[4 * q4 + 2], src[4 * q4 + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, voff, 16 * q4, AUX_SC1);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(slab + c, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else if (kb == 0) {                                               // wave 3: the zero blocks of W above the diagonal
+            if (SLABS && pre && lane == 0) {            // and the hand-on of the tile the caller finished before this block:
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // every wave drained its stores ahead of the
+                __hip_atomic_store(pre, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // barrier above
+            }
             const u32x4 z = {0u, 0u, 0u, 0u};
             const int voff = ((lane >> 3) * TS + 4 * (lane & 7)) * 4;
 #pragma unroll
@@ -656,6 +689,8 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const int bits = __float_as_int(sT[0]);
         __hip_atomic_store(reinterpret_cast<int*>(W), bits ? bits : 0x7fc00000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // small_step_kernel: the step-numbered flag it waits on instead (W's first word is never cleared there)
+        if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     VOLT_STAMP(13);
     // off-diagonal L blocks out (the diagonal sub-blocks went out of wave 0's registers), zeros above: behind the
@@ -831,6 +866,7 @@ __device__ __forceinline__ TriJob panel_job(float* __restrict__ A, const float* 
     jb.t.n1 = k * (TS / BK);
     jb.t.W = Winv + ((int64_t)b * n + k) * TS * TS;
     jb.t.flag = reinterpret_cast<const int*>(jb.t.W);
+    jb.t.want = 0;
     // T0[p][c] = -A[i,k][c][p]: lane owns row c = 32 wave + l31 of the tile; registers 4g..4g+3 of T[tm] are the four
     // consecutive columns p = 32 tm + 8 g + 4 (lane >> 5) + (0..3): one 16-byte load each.  Column block k <= n-2 lies
     // wholly inside the matrix; only the rows of the last block row can be padding.
@@ -859,6 +895,7 @@ __device__ __forceinline__ TriJob trtri_job(const float* __restrict__ A, const f
     jb.t.n1 = (i - j) * (TS / BK);
     jb.t.W = Winv + ((int64_t)b * n + i) * TS * TS;
     jb.t.flag = nullptr;
+    jb.t.want = 0;
     jb.c0 = nullptr;
     jb.row_ok = jb.vec_ok = true;
     jb.out = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
@@ -1226,6 +1263,596 @@ __global__ __launch_bounds__(256, 2) void tune_update_sq_kernel(float* __restric
 }
 __global__ void tune_empty_kernel(float* A) { if (A == nullptr) A[0] = 0.f; }
 
+// ----------------------------------------------------------------------------- short series: the whole step in ONE launch
+// The reference's own sizes (ntrain = 400, experiments/stocks/ForecastGenerator.py:53-91) are n = 4 block columns: the
+// launch-per-column sequence above is 11 launches (pad, prepare, clear, 5 factor / trtri launches, 3 tails), and every
+// block column pays the chain  W_k -> panel tile (k+1,k) written out -> read back into the update of (k+1,k+1) -> pivots.
+// Here every piece of a series is ONE workgroup of one launch, and a piece starts when the flags of what it reads say so:
+//   D(0)     the first diagonal block, straight from K.
+//   S(k)     k >= 1, the SPINE: everything block column k-1 still owes diagonal block k, without leaving the CU.
+//            Ahead of W_{k-1}: the look-ahead part of A[k,k] (blocks m < k-1, parked in A) and the first phase of panel
+//            tile (k,k-1).  When W_{k-1} appears: the W product -> L[k,k-1] (out to memory for the others, and into LDS),
+//            A[k,k] -= L[k,k-1] L[k,k-1]^T from LDS into the pivot image, factor + invert -> W_k.
+//   P(i,k)   i >= k+2: the other panel tiles (two-phase, as in factor_step_kernel).
+//   T(i,j)   tiles of Y = L^-T with the z / Frobenius partials; T(i,i) copies W_i^T.
+//   grid order (piece-major, series-minor):  for k = 0..n-1:  D(0) | S(k);  P(k+2..n-1, k);  T(k-1, 0..k-1)
+//                                            then T(n-1, 0..n-1) series-major.
+//   S(k)    waits L[k,k-2], L[k-1,k-2] (ahead), W_{k-1};                  publishes L[k,k-1], then W_k
+//   P(i,k)  waits L[i,k-1], L[k,k-1] (phase 1), W_k (phase 2);            publishes L[i,k]
+//   T(i,j)  waits L[i,i-1], Y[i-1,j] (phase 1), W_i (phase 2);            publishes Y[i,j]
+// Every piece depends only on pieces EARLIER in the grid, workgroups are dispatched in grid order, so whatever a
+// resident workgroup waits for is resident or finished (the protocol of trsv.hip and of the W_k hand-off above).  The
+// one exception is the tail: the n pieces of the last row of a series wait for each other -- they sit next to each other
+// in the grid (series-major), fewer than an XCD has slots.
+// With B a multiple of 8 a series' pieces all land on one XCD (w % 8 = b % 8).
+// The flags are never cleared: a flag word holds the NUMBER of the step that set it.  hdr[3] counts the steps done on
+// this workspace; a workgroup reads it on entry (E), waits for E + 1, publishes E + 1, and the last workgroup to leave
+// the launch (hdr[4] counts them) stores E + 1 back -- so a replayed hipGraph needs no host-side argument to change,
+// and no clearing launch precedes the step.  The state is written once by volt_mll_workspace_init_f32; the kernel
+// checks its header and reports scratch that is not (or no longer) initialised as info = INT_MIN + 1.
+// Tail (mll.hip's three tail kernels, same arithmetic in the same order): every T piece takes a ticket when its
+// reductions are out; the n pieces of the last row wait for the full count, each sums the z-partials and takes every
+// n-th group of four rows of alpha = Y z; the last of THEM to finish (a second ticket) writes the scalars.
+constexpr int SMALL_MAGIC = 0x564f4c53;
+constexpr int SMALL_HDR = 64;                  // ints ahead of the per-series blocks
+struct SmallState {
+    int* hdr;                                  // [0] magic [1] B [2] n [3] steps done [4] workgroups that have left the launch
+    int* ser;                                  // per series, `stride` ints apart (a 128-byte line of its own or more):
+    int stride;                                //   [0] T pieces that have delivered alpha's partial sums (running total)
+                                               //   [4 ..) sf[n][4]: column slab of diagonal block k handed on (16-byte rows)
+                                               //          rowc[n]: T pieces of row i whose z-partials are out (running total)
+                                               //          wf[n]: W_k published   lf[n][n]: L[i,j] stored   yf[n][n]: Y tile stored
+                                               //          uf[n]: look-ahead part of A[k,k] parked
+    long long* stamps;                         // tuning only (volt_tune_small_stamps): 16 per workgroup, else nullptr
+};
+__host__ __device__ inline int small_stride(int n) { return (4 + 7 * n + 2 * n * n + 31) & ~31; }
+#define SMALL_STAMP(i) do { if (st.stamps && threadIdx.x == 0) st.stamps[(int64_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+struct SmallTail {
+    const float* resid;                        // [B,N]
+    float* rpad;                               // [B,Np]  zero-padded copy, written by D(0)
+    float* z;                                  // [B,Np]
+    float* apad;                               // [B,Np]
+    float* apart;                              // [B,n,Np]  alpha's partial sums: [i][128 j + c] from tile (i,j) of the inverse
+    const float* sigma2;
+    float jitter;
+    float* out;                                // [B,8]
+    float* alpha;                              // [B,N]
+    int N;
+};
+
+// thread 0 polls with a growing pause (f1 may be nullptr), one agent-scope acquire, a barrier for the rest
+__device__ __forceinline__ bool wait_flag_backoff(const int* flag, int want) {
+    if (flag_is_set(flag, want)) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (!flag_is_set(flag, want)) {
+        if (spins < 16) __builtin_amdgcn_s_sleep(2);
+        else if (spins < 64) __builtin_amdgcn_s_sleep(8);
+        else __builtin_amdgcn_s_sleep(24);
+        if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void small_wait(const int* f0, const int* f1, int want, int* info_b) {
+    if (threadIdx.x == 0) {
+        bool ok = wait_flag_backoff(f0, want);
+        if (f1) ok = wait_flag_backoff(f1, want) && ok;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) atomicCAS(info_b, 0, (int)0x80000000);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void small_publish(int* flag, int val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// T0 of a two-phase tile (factor_step_kernel's prologue)
+__device__ __forceinline__ void job_t0(const TriJob& jb, f32x16 (&T)[4]) {
+    if (jb.c0 && jb.row_ok && jb.vec_ok) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(jb.c0 + 32 * tm + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[tm][4 * g + e] = -v[e];
+            }
+    } else if (jb.c0 && jb.row_ok) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) T[tm][q] = -jb.c0[32 * tm + 8 * (q >> 2) + (q & 3)];
+    } else {
+        zero_acc(T);
+    }
+}
+
+// A tile below diagonal block k, solved by SUBSTITUTION against the column slabs that block's workgroup hands on while
+// it is still pivoting (diag_body<.., SLABS>) -- nothing here waits for the inverse W_k.  On entry T = -U^T, U the tile
+// with every block column m < k already subtracted (tri_tile_run's accumulator layout: T[j] register q <-> column
+// p = 32 j + accrow(q), lane % 32 <-> row c of this wave's 32 rows).  Per slab j, as soon as its flag is up:
+//     U_j -= L'_m L_kk[j,m]^T     for the slabs m < j already here (their L_kk blocks came with THEIR flags: this
+//                                 happens BEFORE flag j is up): A = rows of L_kk[j,m], B = L'_m
+//     L'_j = U_j X_j^T            behind flag j: 16 MFMAs, A = T[j] straight from the registers, B = rows of X_j
+//                                 (W_k's block (j,j))
+// so that behind every flag, the last one included, only one 32^3 product is left.  Operands that every lane reads a row of (X_j, L_kk)
+// come straight from memory as b128 loads; L'_j goes through this wave's own 32 rows of the LDS tile sL (row stride WLD)
+// -- accumulator layout in, operand layout out -- which is also where the spine picks the finished tile up.  No barrier:
+// a wave only ever reads the rows it wrote.  The tile goes out to memory slab by slab.
+// MODE 0: a panel tile.  MODE 1: the spine's tile (k,k-1) -- `acc` holds -C, C the look-ahead part of A[k,k], in the
+// 2x2-wave layout of gemm_nt_128<0>; behind every slab (one barrier: all four waves' rows of it are in the tile) it takes
+// the rank-32 update L'_j L'_j^T in that pipeline's K order, so that after the last slab only a quarter of the product is
+// left, and the result lands in the pivot image (lower triangle, zeros above) that diag_body works on.  MODE 2: a tile of
+// Y = L^-T (the same right-hand product against W_i): the slabs' products are kept in O for the reductions.
+template <int MODE>
+__device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __restrict__ Lkk, int Np,
+                                                const float* __restrict__ Wk, const int* slab, int want,
+                                                float* __restrict__ out, float* sL, f32x16 (&X)[4],
+                                                long long* stamps = nullptr) {
+#define SUB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    float* mine = sL + (wave * 32) * WLD;
+    float* outw = out + (int64_t)(wave * 32) * Np;
+    bool ok = true;
+    // X_j and the L_kk blocks were written through (sc1) ahead of their flag and are read with sc1 loads behind it: the
+    // hand-off costs neither side an L2-wide write-back / invalidate (with 64 series in flight those were what the
+    // pivot chains were waiting for)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, TS * TS * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)Lkk, 0, 0x7fffffff, 0x00020000);
+    // rank-32 update of the spine's accumulators with slab jj of the (whole) L tile
+    auto rank32 = [&](int jj) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ko = 32 * jj + 8 * g + 4 * lh;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sL + (wr * 64 + l31) * WLD + ko);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sL + (wc * 64 + l31) * WLD + ko);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(sL + (wc * 64 + 32 + l31) * WLD + ko);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sL + (wr * 64 + 32 + l31) * WLD + ko);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                X[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m], X[0], 0, 0, 0);
+                X[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b1[m], X[1], 0, 0, 0);
+                X[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b0[m], X[2], 0, 0, 0);
+                X[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m], X[3], 0, 0, 0);
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // ---- between the flags: what the slabs already here owe slab j (their L_kk blocks came with THEIR flags), and
+        // for the spine the rank-32 update of the slab before, whose MFMAs cover the latency of those loads
+        if (j > 0) {
+            f32x4 la[3][4];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (m < j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        la[m][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            lrs, (int)((((int64_t)(32 * j + l31)) * Np + 32 * m + 4 * lh) * 4), 32 * g, AUX_SC1));
+                }
+            if (MODE == 1) {
+                __syncthreads();                                   // all four waves' rows of slab j-1 are in the tile
+                rank32(j - 1);
+            }
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (m < j) {
+                    f32x4 lb[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) lb[g] = *reinterpret_cast<const f32x4*>(mine + l31 * WLD + 32 * m + 8 * g + 4 * lh);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            T[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(la[m][g][e], lb[g][e], T[j], 0, 0, 0);
+                }
+        }
+        // ---- behind flag j: one product
+        if (lane == 0) ok = wait_flag(slab + j, want, 2) && ok;
+        asm volatile("" ::: "memory");                             // the loads below stay below the poll
+        SUB_STAMP(6 + j);
+        f32x4 xb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            xb[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                wrs, ((32 * j + l31) * TS + 32 * j + 4 * lh) * 4, 32 * g, AUX_SC1));
+        f32x16 O = zero16();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) O = __builtin_amdgcn_mfma_f32_32x32x2f32(T[j][4 * g + e], xb[g][e], O, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = accrow(q, lane);
+            mine[c * WLD + 32 * j + l31] = -O[q];
+            VOLT_OUT_STORE(outw + (int64_t)c * Np + 32 * j + l31, -O[q]);
+        }
+        if (MODE == 2) X[j] = O;
+        wave_lds_fence();
+    }
+    SUB_STAMP(10);
+    if (MODE == 1) {
+        __syncthreads();
+        SUB_STAMP(11);
+        rank32(3);
+        __syncthreads();                                           // the image overlays the L tile
+        SUB_STAMP(12);
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                    const int c = wc * 64 + tn * 32 + l31;
+                    sL[r * DT + c] = (c <= r) ? -X[tm * 2 + tn][q] : 0.f;
+                }
+        SUB_STAMP(13);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's part of the tile is out (long since)
+        SUB_STAMP(14);
+    }
+    return ok;               // meaningful in lane 0 of each wave
+}
+
+// Phase 1 of a two-phase tile in two parts: the K blocks but the last as soon as THEIR inputs are there (flags e0, e1),
+// the last block -- whose operand is the tile the previous spine has only just handed on -- behind flags l0, l1.  That
+// leaves one 128^3 product (6.8 us on a CU) between the hand-on and the first slab of the next diagonal block (~8 us).
+__device__ __forceinline__ void phase1_two_parts(TriTile t, f32x16 (&T)[4], float* smem, const int* e0, const int* e1,
+                                                 const int* l0, const int* l1, int want, int* info_b) {
+    const int blocks = t.n1 / 4;
+    if (blocks <= 0) return;
+    if (blocks > 1) {
+        small_wait(e0, e1, want, info_b);
+        t.n1 = 4 * (blocks - 1);
+        tri_phase1_only(t, T, smem);
+    }
+    small_wait(l0, l1, want, info_b);
+    t.X += (int64_t)(blocks - 1) * TS;
+    t.Z += (int64_t)(blocks - 1) * TS;
+    t.n1 = 4;
+    tri_phase1_only(t, T, smem);
+}
+
+// -C into the spine's accumulators: C = the look-ahead part of A[k,k] (parked in A by U(k); for k = 1 the caller's K)
+__device__ __forceinline__ void spine_load_c(const float* __restrict__ A, int Np, int k, int b, const KSource& src,
+                                             f32x16 (&acc)[4]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+    const int wr = wave >> 1, wc = wave & 1;
+    const float* Ab = A + (int64_t)b * Np * Np;
+    const bool usek = k == 1;
+    const float add = usek ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
+    const float* Kb = usek ? src.K + (int64_t)b * src.bsk : nullptr;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                const int c = wc * 64 + tn * 32 + l31;
+                acc[tm * 2 + tn][q] = -input_elem(src, Kb, add, Ab, Np, usek, k * TS + r, k * TS + c);
+            }
+}
+
+// ---- tail.  z_i (block i of z = L^-1 r) is the sum of the z-partials of the tiles of row i of the inverse, i.e. of
+// pieces that sit next to each other in the grid and finish together: each of them waits for the row's count, adds the
+// partials up (128 values, every piece for itself) and multiplies ITS tile -- still in registers -- into alpha's partial
+// sum apart[i][block j] = Y[j,i] z_i.  No pass over Y: y_times_z_kernel's 640 KB stream becomes 16 wave reductions.
+__device__ __forceinline__ void row_z(const TriReduce& red, const SmallTail& tl, int Np, int i, int j, int b, float* sz) {
+    const int n = Np / TS, tid = threadIdx.x;
+    if (tid < TS) {
+        float a = 0.f;
+        for (int jb = 0; jb <= i; ++jb) a += red.zpart[((int64_t)b * n + jb) * Np + i * TS + tid];
+        sz[tid] = a;
+        if (j == 0) tl.z[(int64_t)b * Np + i * TS + tid] = a;
+    }
+    __syncthreads();
+}
+// off-diagonal tile (i,j): Y[c][r] = -O[rb][q], c = 32 wave + accrow(q), r = 32 rb + lane % 32
+__device__ __forceinline__ void alpha_part(const f32x16 (&O)[4], const SmallTail& tl, int Np, int i, int j, int b,
+                                           const float* sz) {
+    const int n = Np / TS, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
+    float zr[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) zr[rb] = sz[rb * 32 + l31];
+    float* dst = tl.apart + ((int64_t)b * n + i) * Np + j * TS + wave * 32;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float v = -((O[0][q] * zr[0] + O[1][q] * zr[1]) + (O[2][q] * zr[2] + O[3][q] * zr[3]));
+        v = dpp_add<0xB1>(v);
+        v = dpp_add<0x4E>(v);
+        v = dpp_add<0x141>(v);
+        v = dpp_add<0x140>(v);                                     // every lane of a 16-lane row holds the row's sum
+        const int vi = __float_as_int(v);
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(vi, 0)) + __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(vi, 32)) + __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+        if (lane == 0) {                                           // lanes 0..31 hold row accrow(q, 0), lanes 32..63 that + 4
+            dst[(q & 3) + 8 * (q >> 2)] = lo;
+            dst[(q & 3) + 8 * (q >> 2) + 4] = hi;
+        }
+    }
+}
+
+// Diagonal tile (i,i) of the inverse for the one-launch step: Y[i,i] = W_i^T out, its z-partial and Frobenius partial,
+// then (behind the row's count) its share of alpha.  Two threads per row / column instead of trtri_diag_body's one, and
+// the residual staged in LDS: this tile is the last piece of its row to start (it needs the WHOLE of W_i).
+__device__ __forceinline__ void small_diag_tile(const float* __restrict__ Winv, float* __restrict__ Y, int Np, int i, int b,
+                                                const TriReduce& red, const SmallTail& tl, int* rowc, int* yflag, int want,
+                                                int* info_b, float* smem) {
+    const int n = Np / TS, tid = threadIdx.x;
+    float* Yb = Y + (int64_t)b * Np * Np;
+    const float* W = Winv + ((int64_t)b * n + i) * TS * TS;
+    float* srv = smem + TS * WLD;                                   // residual block i, then z_i
+    float* sfr = srv + TS;                                          // 256 Frobenius partials
+    for (int e = tid; e < TS * TS / 4; e += NT) {
+        const int r = e >> 5, c = (e & 31) * 4;
+        *reinterpret_cast<f32x4*>(smem + r * WLD + c) = *reinterpret_cast<const f32x4*>(W + r * TS + c);
+    }
+    if (tid < TS) srv[tid] = red.rpad[(int64_t)b * Np + i * TS + tid];
+    __syncthreads();
+    {
+        const int r = tid >> 1, h = tid & 1;                        // column r of Y = row r of W: entries c <= r, c = h, h + 2, ..
+        float fz = 0.f, ff = 0.f, fz1 = 0.f, ff1 = 0.f;
+        const int lim = red.N - i * TS;                             // columns c < lim are inside the matrix
+        int c = h;
+        for (; c + 2 <= r; c += 4) {                                // two independent chains per thread
+            const float y0 = smem[r * WLD + c], y1 = smem[r * WLD + c + 2];
+            fz += y0 * srv[c];
+            fz1 += y1 * srv[c + 2];
+            if (c < lim) ff += y0 * y0;
+            if (c + 2 < lim) ff1 += y1 * y1;
+        }
+        if (c <= r) {
+            const float y = smem[r * WLD + c];
+            fz += y * srv[c];
+            if (c < lim) ff += y * y;
+        }
+        fz += fz1;
+        ff += ff1;
+        fz += __shfl_xor(fz, 1);
+        if (h == 0) red.zpart[((int64_t)b * n + i) * Np + i * TS + r] = fz;
+        sfr[tid] = ff;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float tot = wave_sum_f((sfr[tid] + sfr[tid + 64]) + (sfr[tid + 128] + sfr[tid + 192]));
+        if (tid == 0) red.frob[(int64_t)b * (n * (n + 1) / 2) + i * (i + 1) / 2 + i] = tot;
+    }
+    // ---- the partials are out: the row's count.  Then the tile itself (64 KB of stores that nothing in this row waits
+    // for), z_i, this tile's share of alpha:  apart[i][block i][c] = sum_{r >= c} W[r][c] z_i[r]
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(rowc, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    float* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
+    for (int e = tid; e < TS * TS; e += NT) {
+        const int c = e >> 7, r = e & 127;                          // Y row c, column r
+        Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
+    }
+    small_wait(rowc, nullptr, (int)((unsigned)want * (unsigned)(i + 1)), info_b);
+    row_z(red, tl, Np, i, i, b, srv);
+    {
+        const int c = tid >> 1, h = tid & 1;
+        float ap = 0.f, ap1 = 0.f;
+        int r = c + h;
+        for (; r + 2 < TS; r += 4) {
+            ap += smem[r * WLD + c] * srv[r];
+            ap1 += smem[(r + 2) * WLD + c] * srv[r + 2];
+        }
+        if (r < TS) ap += smem[r * WLD + c] * srv[r];
+        ap += ap1;
+        ap += __shfl_xor(ap, 1);
+        if (h == 0) tl.apart[((int64_t)b * n + i) * Np + i * TS + c] = ap;
+    }
+    small_publish(yflag, want);
+}
+
+// The last T piece of the series to deliver: alpha = sum of the partial sums, the scalars (= mll_scalars_kernel)
+__device__ __forceinline__ void small_tail_scalars(const float* __restrict__ A, int Np, int b, const TriReduce& red,
+                                                   const SmallTail& tl, float* smem) {
+    const int n = Np / TS, tid = threadIdx.x;
+    double* sred = reinterpret_cast<double*>(smem);                 // [4][256]: the four sums go down one tree together
+    const float* Ab = A + (int64_t)b * Np * Np;
+    const int N = tl.N;
+    double q = 0, ld = 0, aa = 0, tr = 0;
+    for (int c = tid; c < Np; c += NT) {
+        float al = 0.f;
+        for (int i = c / TS; i < n; ++i) al += tl.apart[((int64_t)b * n + i) * Np + c];
+        tl.apad[(int64_t)b * Np + c] = al;
+        if (c < N) {
+            const double zi = tl.z[(int64_t)b * Np + c];
+            q += zi * zi;
+            ld += log((double)Ab[(int64_t)c * Np + c]);
+            aa += (double)al * al;
+            tl.alpha[(int64_t)b * N + c] = al;
+        }
+    }
+    const int nt = n * (n + 1) / 2;
+    for (int i = tid; i < nt; i += NT) tr += red.frob[(int64_t)b * nt + i];
+    sred[tid] = q;
+    sred[256 + tid] = ld;
+    sred[512 + tid] = aa;
+    sred[768 + tid] = tr;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sred[256 * v + tid] += sred[256 * v + tid + s2];
+        }
+        __syncthreads();
+    }
+    q = sred[0];
+    ld = 2.0 * sred[256];
+    aa = sred[512];
+    tr = sred[768];
+    if (tid == 0) {
+        const double LOG_2PI = 1.8378770664093453;
+        float* o = tl.out + (int64_t)b * 8;
+        o[0] = (float)(-0.5 * (q + ld + N * LOG_2PI) / N);
+        o[1] = (float)(0.5 * (aa - tr) / N);
+        o[2] = (float)q;
+        o[3] = (float)ld;
+        o[4] = (float)tr;
+        o[5] = (float)aa;
+        o[6] = (tl.sigma2 ? tl.sigma2[b] : 0.f) + tl.jitter;
+        o[7] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                           float* __restrict__ Y, int* __restrict__ info, int Np, int B,
+                                                           KSource src, TriReduce red, SmallState st, SmallTail tl) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    __shared__ int s_last;
+    const int n = Np / TS, tid = threadIdx.x;
+    if (st.hdr[0] != SMALL_MAGIC || st.hdr[1] != B || st.hdr[2] != n) {          // not (or no longer) what init wrote
+        if (tid == 0 && (int)blockIdx.x < B) info[blockIdx.x] = (int)0x80000001;
+        return;
+    }
+    const int want = __hip_atomic_load(st.hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    // ---- which piece.  Group k: D(0) | S(k), the panel pieces P(k+2.., k), U(k+1) -- piece-major, series-minor -- and then
+    // the k tiles of row k-1 of the inverse, series-major (the pieces of a row next to each other: they wait for each other).
+    int w = blockIdx.x, b = 0, k = 0, i = 0, j = 0, kind = -1;          // kind 0: D(0) / S(k)  1: P(i,k)  2: T(i,j)  3: U(k)
+    for (int kk = 0; kk <= n && kind < 0; ++kk) {
+        const int np = kk < n && n - kk - 2 > 0 ? n - kk - 2 : 0;
+        const int nu = (kk >= 1 && kk + 1 <= n - 1) ? 1 : 0;
+        const int nh = kk < n ? 1 + np + nu : 0;                       // pieces ahead of the T pieces
+        if (w < nh * B) {
+            const int p = w / B;
+            b = w % B;
+            k = kk;
+            if (p == 0) kind = 0;
+            else if (p <= np) { kind = 1; i = kk + 1 + p; }
+            else { kind = 3; k = kk + 1; }
+        } else if (w < (nh + kk) * B) {
+            w -= nh * B;
+            b = w / kk;
+            kind = 2;
+            i = kk - 1;
+            j = w % kk;
+        } else {
+            w -= (nh + kk) * B;
+        }
+    }
+    int* ser = st.ser + (int64_t)b * st.stride;
+    int* sf = ser + 4;
+    int* rowc = sf + 4 * n;
+    int* wf = rowc + n;
+    int* lf = wf + n;
+    int* yf = lf + n * n;
+    int* uf = yf + n * n;
+    int* info_b = info + b;
+    float* Ab = A + (int64_t)b * Np * Np;
+    SMALL_STAMP(0);
+
+    if (kind == 0 && k == 0) {
+        if (tid == 0) *info_b = 0;
+        for (int c = tid; c < Np; c += NT) tl.rpad[(int64_t)b * Np + c] = c < tl.N ? tl.resid[(int64_t)b * tl.N + c] : 0.f;
+        update_body<true>(A, Np, 0, 0, 0, 0, true, b, src, smem, true);
+        SMALL_STAMP(3);
+        diag_body<false, true>(A, Winv, info, Np, 0, b, smem, nullptr, true, wf, want, sf);
+        SMALL_STAMP(4);
+    } else if (kind == 3) {
+        // ---- U(k): what block columns m < k-1 owe the diagonal tile (k,k), parked in A for the spine
+        small_wait(lf + k * n + (k - 2), nullptr, want, info_b);
+        SMALL_STAMP(1);
+        update_body<true>(A, Np, k, k, 0, k - 1, true, b, src, smem);
+        SMALL_STAMP(3);
+        small_publish(uf + k, want);
+        SMALL_STAMP(4);
+    } else if (kind <= 1) {
+        // ---- ahead of diagonal block kd (spine: k - 1, panel piece: k): everything the earlier block columns owe this tile
+        const int kd = kind == 0 ? k - 1 : k;                      // the diagonal block this tile sits under
+        const int ti = kind == 0 ? k : i;                          // its block row
+        SMALL_STAMP(1);
+        TriJob jb = panel_job<true>(A, Winv, Np, ti, kd, b, src);
+        f32x16 T[4];
+        job_t0(jb, T);
+        phase1_two_parts(jb.t, T, smem, lf + ti * n + (kd - 2), lf + kd * n + (kd - 2), lf + ti * n + (kd - 1),
+                         lf + kd * n + (kd - 1), want, info_b);
+        SMALL_STAMP(2);
+        // ---- the chain: slab by slab behind the pivots of block kd
+        f32x16 X[4];
+        const float* Lkk = Ab + (int64_t)kd * TS * Np + (int64_t)kd * TS;
+        const float* Wk = Winv + ((int64_t)b * n + kd) * TS * TS;
+        bool ok;
+        if (kind == 0) {
+            if (k >= 2) small_wait(uf + k, nullptr, want, info_b);
+            spine_load_c(A, Np, k, b, src, X);
+            ok = substitute_tile<1>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
+                                    st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
+        } else {
+            ok = substitute_tile<0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X);
+        }
+        if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
+        SMALL_STAMP(3);
+        if (kind == 0) {                                           // L[k,k-1] is handed on by a spare wave of diag_body
+            SMALL_STAMP(4);
+            diag_body<false, true>(A, Winv, info, Np, k, b, smem, nullptr, true, wf + k, want, sf + 4 * k, lf + k * n + kd);
+        } else {
+            small_publish(lf + ti * n + kd, want);
+        }
+    } else {
+        if (i == j) {
+            small_wait(wf + i, nullptr, want, info_b);
+            SMALL_STAMP(1);
+            small_diag_tile(Winv, Y, Np, i, b, red, tl, rowc + i, yf + i * n + i, want, info_b, smem);
+        } else {
+            SMALL_STAMP(1);
+            TriJob jb = trtri_job(A, Winv, Y, Np, i, j, b);
+            f32x16 T[4], O[4];
+            zero_acc(T);
+            phase1_two_parts(jb.t, T, smem, lf + i * n + (i - 2), yf + (i - 2) * n + j, lf + i * n + (i - 1),
+                             yf + (i - 1) * n + j, want, info_b);
+            SMALL_STAMP(2);
+            const bool ok = substitute_tile<2>(T, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np,
+                                               Winv + ((int64_t)b * n + i) * TS * TS, sf + 4 * i, want, jb.out, smem, O);
+            if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
+            __syncthreads();                                       // the reductions' scratch overlays the waves' L rows
+            trtri_reduce(O, Np, i, j, b, red, smem);
+            // the tile and its partials are out; the row's count, z_i, this tile's share of alpha
+            small_publish(yf + i * n + j, want);
+            if (tid == 0) __hip_atomic_fetch_add(rowc + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            small_wait(rowc + i, nullptr, (int)((unsigned)want * (unsigned)(i + 1)), info_b);
+            row_z(red, tl, Np, i, j, b, smem);
+            alpha_part(O, tl, Np, i, j, b, smem);
+        }
+        SMALL_STAMP(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this piece's share of alpha is out:
+        __syncthreads();                                           // the last piece of the series to say so closes it
+        SMALL_STAMP(4);
+        if (tid == 0) {
+            const int nT = n * (n + 1) / 2;
+            const int t = __hip_atomic_fetch_add(ser, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (unsigned)(t + 1) == (unsigned)want * (unsigned)nT;
+        }
+        __syncthreads();
+        if (s_last) small_tail_scalars(A, Np, b, red, tl, smem);
+    }
+    SMALL_STAMP(5);
+    // ---- the last workgroup out closes the step
+    if (tid == 0) {
+        const int f = __hip_atomic_fetch_add(st.hdr + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == (int)gridDim.x - 1) {
+            __hip_atomic_store(st.hdr + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.hdr + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+__global__ void small_init_kernel(int* __restrict__ base, int count, int B, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    base[i] = i == 0 ? SMALL_MAGIC : i == 1 ? B : i == 2 ? n : 0;
+}
+
 }  // namespace volt
 
 using namespace volt;
@@ -1238,6 +1865,9 @@ struct Tunables {
     int sched = 1, sched_minb = 3, sched_maxb = 31, sched_maxb_potrf = 64;
     int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
     float sched_frac = 0.6f;
+    int small_nmax = 4, small_maxwg = 16384;   // the one-launch step: block columns it takes, and workgroups at most
+    int small_maxb = 32, small_maxb2 = 96;     // ... series at most (three or four block columns / one or two)
+    int small_pad_maxb = 32;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
 };
 static const Tunables& tunables() {
     static const Tunables tn = [] {
@@ -1257,6 +1887,11 @@ static const Tunables& tunables() {
         geti("VOLT_SCHED_S", t.sched_s);
         geti("VOLT_SCHED_GROUPS", t.sched_groups);
         geti("VOLT_SCHED_KMIN", t.sched_kmin);
+        geti("VOLT_SMALL_NMAX", t.small_nmax);
+        geti("VOLT_SMALL_MAXWG", t.small_maxwg);
+        geti("VOLT_SMALL_PAD_MAXB", t.small_pad_maxb);
+        geti("VOLT_SMALL_MAXB", t.small_maxb);
+        geti("VOLT_SMALL_MAXB2", t.small_maxb2);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         return t;
     }();
@@ -1743,6 +2378,61 @@ int volt_internal_sched_install(void* tab, size_t tab_bytes, int B, int n, int h
     return sched_install(tab, tab_bytes, B, n, has_y != 0, cap, (hipStream_t)stream);
 }
 
+// ---- the one-launch step for short series (small_step_kernel): its state lives in the caller's workspace, written once
+// by volt_mll_workspace_init_f32; like the schedule tables, a step uses it only for a region this library initialised.
+static bool small_applies(int B, int n) {
+    const Tunables& tn = tunables();
+    // measured (scripts/bench_small_step.py): from ~48 series of three or four block columns on (~128 of one or two) the
+    // pieces wait for workgroup slots rather than for each other and the launch-per-column path is the faster one
+    return n >= 1 && n <= tn.small_nmax && n <= 8 && B <= (n <= 2 ? tn.small_maxb2 : tn.small_maxb) && (int64_t)B * (n * n + n) <= tn.small_maxwg;
+}
+static int small_pieces(int n) { return n * (n + 1) / 2 + (n - 1) * (n - 2) / 2 + n + (n > 2 ? n - 2 : 0); }   // workgroups per series
+size_t volt_internal_small_bytes(int B, int n) {
+    if (!small_applies(B, n)) return 0;
+    return (((size_t)SMALL_HDR + (size_t)B * small_stride(n)) * sizeof(int) + 255) & ~(size_t)255;
+}
+static std::map<std::pair<int, const void*>, std::pair<int, int>> g_small_installed;
+static long long* g_small_stamps = nullptr;    // volt_tune_small_stamps
+int volt_internal_small_install(void* state, size_t bytes, int B, int n, void* stream) {
+    if (!state || !small_applies(B, n) || bytes < volt_internal_small_bytes(B, n)) return 0;
+    const int count = SMALL_HDR + B * small_stride(n);
+    hipLaunchKernelGGL(small_init_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int*)state, count, B, n);
+    VOLT_LAUNCH_CHECK();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_installed_mu);
+    g_small_installed[{dev, state}] = {B, n};
+    return 0;
+}
+// 1: the step has been enqueued (one launch);  0: not applicable here (the caller runs the launch-per-column path)
+int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                             float jitter, float* A, float* Winv, float* Y, int* info, float* rpad, float* zpart,
+                             float* frob, float* z, float* apad, float* apart, float* out, float* alpha, void* state,
+                             int B, int N, void* stream) {
+    const int Np = volt_padded_n(N), n = Np / TS;
+    if (!state || !Y || !apart || !small_applies(B, n)) return 0;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(g_installed_mu);
+        auto it = g_small_installed.find({dev, state});
+        if (it == g_small_installed.end() || it->second != std::make_pair(B, n)) return 0;
+    }
+    int* base = (int*)state;
+    const SmallState st{base, base + SMALL_HDR, small_stride(n), g_small_stamps};
+    const KSource src{K, ldk, bsk, sigma2, jitter, N};
+    const TriReduce red{rpad, zpart, frob, N};
+    const SmallTail tl{resid, rpad, z, apad, apart, sigma2, jitter, out, alpha, N};
+    // A pivot chain that shares its CU with another piece's MFMA / LDS traffic runs two to three times slower (64 x 399:
+    // 71 us per diagonal block against 22): while every series can still have ~8 pieces resident, a workgroup gets a CU
+    // to itself (16 KB of dynamic LDS on top of the 72 KB: one workgroup per 160 KB CU)
+    const unsigned pad = B <= tunables().small_pad_maxb ? 16 * 1024 : 0;
+    hipLaunchKernelGGL(small_step_kernel, dim3(B * small_pieces(n)), dim3(256), pad, (hipStream_t)stream, A, Winv, Y, info, Np,
+                       B, src, red, st, tl);
+    VOLT_LAUNCH_CHECK();
+    return 1;
+}
+
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
@@ -1834,6 +2524,11 @@ int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac
     if (items) memcpy(items, it.data(), it.size() * sizeof(SchedItem));
     if (loads) memcpy(loads, ld.data(), ld.size() * sizeof(float));
     return (int)it.size();
+}
+
+int volt_tune_small_stamps(long long* stamps) {
+    g_small_stamps = stamps;
+    return 0;
 }
 
 int volt_tune_diag_f32(float* A, float* Winv, int* info, int B, int Np, int k, long long* stamps, void* stream) {

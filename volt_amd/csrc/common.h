@@ -269,6 +269,7 @@ struct TriTile {
     int n1;                            // K / 32 (multiple of 4, may be 0)
     const float* W;                    // [128][128] row-major, lower triangular
     const int* flag;                   // nullptr, or W's ready flag
+    int want;                          // 0: ready = the flag word is non-zero;  else: ready = the word equals `want`
 };
 
 // One per-lane byte offset per operand (row t >> 3, 16-byte column t & 7); the row group p (32 rows further down) and
@@ -391,21 +392,28 @@ __device__ __forceinline__ void tri_chunk_p2(const float* cur, float* nxt, f32x1
 // Hand-off waits are bounded by WALL CLOCK (s_memrealtime: a constant 100 MHz counter), not by an iteration count: a
 // preempted or profiled run spins more often, not longer.  3 s -- only a bug or a wedged device gets there.
 constexpr unsigned long long WAIT_LIMIT_TICKS = 300000000ull;
-__device__ __forceinline__ bool wait_nonzero(const int* flag, int sleep) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return true;
+// `want` = 0: wait for a non-zero word;  else wait for the word to EQUAL `want` (flags that carry the number of the step
+// they belong to and are never cleared: small_step_kernel in chol.hip).
+__device__ __forceinline__ bool flag_is_set(const int* flag, int want) {
+    const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return want ? v == want : v != 0;
+}
+__device__ __forceinline__ bool wait_flag(const int* flag, int want, int sleep) {
+    if (flag_is_set(flag, want)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    while (!flag_is_set(flag, want)) {
         if (sleep == 2) __builtin_amdgcn_s_sleep(2);
         else __builtin_amdgcn_s_sleep(4);
         if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
     }
     return true;
 }
-__device__ __forceinline__ bool flag_wait_one_lane(const int* flag) {
+__device__ __forceinline__ bool wait_nonzero(const int* flag, int sleep) { return wait_flag(flag, 0, sleep); }
+__device__ __forceinline__ bool flag_wait_one_lane(const int* flag, int want = 0) {
     bool ok = true;
     if (threadIdx.x == 0) {
-        ok = wait_nonzero(flag, 4);
+        ok = wait_flag(flag, want, 4);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     return ok;       // meaningful in thread 0 only
@@ -438,7 +446,7 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     zero_acc(O);
     bool ok = true;
     if (t.flag && t.n1 == 0) {                       // no phase 1 to hide behind: W is the first thing needed
-        ok = flag_wait_one_lane(t.flag);
+        ok = flag_wait_one_lane(t.flag, t.want);
         __syncthreads();
     }
     StageRegs s0, s1;
@@ -462,7 +470,7 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
             tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
         }
         for (; c < t.n1; c += 2) {                   // last 4 chunks of phase 1: the W chunks come into view
-            if (t.flag && c == t.n1 - 4) ok = flag_wait_one_lane(t.flag);   // barriers below order the acquire
+            if (t.flag && c == t.n1 - 4) ok = flag_wait_one_lane(t.flag, t.want);   // barriers below order the acquire
             tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
             tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
         }
@@ -474,6 +482,49 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     tri_chunk_p2<3>(b1, b0, T, O, s1, ts);
     __syncthreads();                                 // smem is free for reuse on return
     return ok;
+}
+
+// The first phase alone (T += X Z^T over n1 chunks, n1 a positive multiple of 4), nothing of W touched: for a tile whose
+// W is not there yet and whose owner has better things to do than wait inside the pipeline (small_step_kernel's spine);
+// tri_tile_run with n1 = 0 then finishes it.  Same chunk code, same order of MFMAs as the fused pipeline.
+__device__ __forceinline__ void tri_phase1_only(const TriTile& t, f32x16 (&T)[4], float* smem) {
+    const int tid = threadIdx.x;
+    const int srow = tid >> 3, scq = (tid & 7) * 4;
+    TriSrc ts;
+    ts.ra = __builtin_amdgcn_make_buffer_rsrc((void*)t.X, 0, 0x7fffffff, 0x00020000);
+    ts.rb = __builtin_amdgcn_make_buffer_rsrc((void*)t.Z, 0, 0x7fffffff, 0x00020000);
+    ts.rw = ts.ra;                                   // never used: no chunk index reaches n1
+    ts.va = (int)(((int64_t)srow * t.ldx + scq) * 4);
+    ts.vb = (int)(((int64_t)srow * t.ldz + scq) * 4);
+    ts.vw = 0;
+    ts.pa = (int)(32 * t.ldx * 4);
+    ts.pb = (int)(32 * t.ldz * 4);
+    ts.n1 = t.n1;
+    ts.nall = t.n1;
+    StageRegs s0, s1;
+    float* b0 = smem;
+    float* b1 = smem + STAGE_FLOATS;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_load_piece(s0, ts, 0, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_store_piece(s0, b0, ts, 0, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_load_piece(s0, ts, 1, p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) tri_load_piece(s1, ts, 2, p);
+    __syncthreads();
+    Frag<1> F0, F1;
+    frag_load<1>(F0, b0, 0);
+    int c = 0;
+    for (; c + 4 < t.n1; c += 2) {
+        tri_chunk_p1<true>(b0, b1, c, F0, F1, T, s0, ts);
+        tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
+    }
+    for (; c < t.n1; c += 2) {
+        tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
+        tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
+    }
+    __syncthreads();                                 // smem is free for reuse on return
 }
 
 // sum over the 64 lanes (DPP inside 16-lane rows, then four readlanes), result in every lane

@@ -114,11 +114,13 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
 }
 
 struct MllWs {
-    float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob, *sk_slab;
+    float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob, *sk_slab, *apart;
     int sk_rows;
     int* sk_count;
     void* tab;               // the balanced schedule's item tables (chol.hip), tab_bytes long
     size_t tab_bytes;
+    void* small;             // state of the one-launch step for short series (chol.hip), small_bytes long
+    size_t small_bytes;
     size_t bytes;
 };
 
@@ -127,6 +129,12 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 }  // namespace volt
 size_t volt_internal_sched_bytes(int B, int n);   // chol.hip
 int volt_internal_sched_install(void* tab, size_t tab_bytes, int B, int n, int has_y, int cap, void* stream);
+size_t volt_internal_small_bytes(int B, int n);
+int volt_internal_small_install(void* state, size_t bytes, int B, int n, void* stream);
+int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                             float jitter, float* A, float* Winv, float* Y, int* info, float* rpad, float* zpart,
+                             float* frob, float* z, float* apad, float* apart, float* out, float* alpha, void* state,
+                             int B, int N, void* stream);
 namespace volt {
 
 static MllWs carve(void* base, int B, int N, int want_grad) {
@@ -164,6 +172,9 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
     }
     w.tab_bytes = w.sk_rows ? volt_internal_sched_bytes(B, (int)n) : 0;
     w.tab = w.tab_bytes ? take(w.tab_bytes / sizeof(float)) : nullptr;
+    w.small_bytes = want_grad ? volt_internal_small_bytes(B, (int)n) : 0;
+    w.small = w.small_bytes ? take(w.small_bytes / sizeof(float)) : nullptr;
+    w.apart = w.small_bytes ? take((size_t)B * n * Np) : nullptr;              // alpha's partial sums, per row of the inverse
     w.bytes = off;
     return w;
 }
@@ -235,8 +246,13 @@ int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, vo
     if (B < 1 || B > 65535) return -2;
     if (N < 1) return -3;
     MllWs w = carve(workspace, B, N, want_grad);
+    const int n = volt_padded_n(N) / TS;
+    if (w.small) {
+        const int rc = volt_internal_small_install(w.small, w.small_bytes, B, n, stream);
+        if (rc) return rc;
+    }
     if (!w.tab) return 0;
-    return volt_internal_sched_install(w.tab, w.tab_bytes, B, volt_padded_n(N) / TS, want_grad, w.sk_rows, stream);
+    return volt_internal_sched_install(w.tab, w.tab_bytes, B, n, want_grad, w.sk_rows, stream);
 }
 
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2, float jitter,
@@ -256,6 +272,12 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     const int Np = volt_padded_n(N);
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
+    if (want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
+        rc = volt_internal_small_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
+                                      w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
+        if (rc == 1) return 0;
+        if (rc) return rc > 0 ? rc : -1;
+    }
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
     TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
