@@ -184,9 +184,16 @@ int volt_adam_step_f32(const void* slots, int nslots, long long total, const flo
  * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written.
  * workspace: volt_mll_workspace_bytes(B,N,want_grad) bytes, 256-byte aligned. */
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
-/* Once per workspace (and again should the caller have overwritten it): copies the launch-schedule table for this
- * shape into the workspace, asynchronously on `stream`.  Optional, like volt_potrf_workspace_init_f32; it matters
- * for 3 .. 31 series (the workspace of volt_gpcv_step_f32 begins with an MLL workspace: same call, want_grad = 1). */
+/* Once per workspace (and again should the caller have overwritten it), asynchronously on `stream`: copies the
+ * launch-schedule table for this shape into the workspace (3 .. 31 series), and for short series (want_grad = 1, N <= 1024:
+ * up to 32 series of N <= 640, 16 of N = 1024, 64 of N <= 256) writes the state of the ONE-LAUNCH step: a header, a step counter and the
+ * flags its workgroups hand tiles on with -- volt_mll_step_f32 then enqueues one kernel for the whole step instead of
+ * eleven (the counter lives on the device, so the launch replays from a hipGraph as it is).  Optional, like
+ * volt_potrf_workspace_init_f32: a workspace that was never initialised gets the launch-per-column path.  The library
+ * recognises the regions it initialised BY ADDRESS and every launch that follows a table or the state checks the
+ * header there first: a region that was initialised, freed and handed out again at the same address without a new init
+ * is reported like one that was overwritten (info = INT_MIN + 1), never followed -- initialise every workspace or none.
+ * (The workspace of volt_gpcv_step_f32 begins with an MLL workspace: same call, want_grad = 1.) */
 int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, void* stream);
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid,
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,

@@ -1,5 +1,6 @@
-"""ms per gradient step (volt_mll_step_f32, K resident) for short series -- the one-launch step (N <= 512) against the
-launch-per-column path (VOLT_SMALL_NMAX=0 in the environment switches the former off).  Usage: bench_small_step.py [tag]"""
+"""ms per gradient step (volt_mll_step_f32, K resident) for short series -- the one-launch step (N <= 1024, few series)
+against the launch-per-column path (VOLT_SMALL_NMAX=0 in the environment switches the former off; shapes the library
+gates out of the one-launch path run the launch-per-column path in both).  Usage: bench_small_step.py [tag]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,8 +8,9 @@ from volt_amd import ops
 from volt_amd.synthetic import sde_batch
 
 tag = sys.argv[1] if len(sys.argv) > 1 else ("per-column" if os.environ.get("VOLT_SMALL_NMAX") == "0" else "one-launch")
-shapes = [(1, 100), (1, 256), (1, 399), (1, 512), (2, 399), (4, 399), (8, 399), (16, 399), (24, 399), (32, 399), (48, 399),
-          (64, 100), (64, 256), (64, 399), (64, 512), (128, 399), (256, 399), (512, 399)]
+shapes = [(1, 100), (1, 256), (1, 399), (1, 512), (1, 640), (1, 1023), (2, 399), (4, 399), (8, 399), (8, 640), (8, 1023),
+          (16, 399), (16, 640), (16, 1023), (24, 399), (24, 640), (32, 399), (32, 640), (48, 399), (64, 100), (64, 256),
+          (64, 399), (96, 256), (128, 256), (128, 399), (512, 399)]
 if os.environ.get("SHAPES"):
     shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 print(f"# {tag}: ms per step (median of 5 x 200 steps)")

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Round-3 evidence in one go (GPU box, through gpurun): bench line, rocprofv3 kernel-trace summaries of the same command
 # in both schedules, the rollout and fp64 kernels' stats, PMC traffic passes, and the tables DESIGN.md quotes.
-# usage: scripts/collect_r03.sh [part ...]   parts: bench trace roll f64 pmc tables   (default: all)
+# usage: scripts/collect_r03.sh [part ...]   parts: bench trace roll f64 pmc tables small   (default: all)
 R=$PWD
 OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 export TMPDIR=/tmp
-PARTS=${@:-bench trace roll f64 pmc tables}
+PARTS=${@:-bench trace roll f64 pmc tables small}
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-aux-legs --no-rollouts"
 for P in $PARTS; do case $P in
 bench)
@@ -40,6 +40,16 @@ pmc)
 tables)
   (echo "# scripts/small_batch.sh: ms/step of the MLL+grad step, N=4096"; bash scripts/small_batch.sh 1 2 3 4 6 8 12 16 24 32) | tee $OUT/small_batch_table.txt
   (echo "# scripts/configs_table.sh: the MLL+grad step at BASELINE's other configurations"; bash scripts/configs_table.sh) | tee $OUT/configs_table.txt;;
+small)
+  # the one-launch step for short series against the launch-per-column path (VOLT_SMALL_NMAX=0), the per-piece stamps of
+  # one step at the reference's own size, and rocprofv3's view of the launch
+  (python scripts/bench_small_step.py; VOLT_SMALL_NMAX=0 python scripts/bench_small_step.py) 2>&1 | grep -v amdgpu.ids | tee $OUT/small_step_table.txt
+  (python scripts/small_stamps.py 1 399; python scripts/small_stamps.py 8 399) 2>&1 | grep -v amdgpu.ids > $OUT/small_step_stamps.txt
+  cd /tmp
+  SHAPES=1x399,8x399,32x399 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small -o small -- python $R/scripts/bench_small_step.py > $OUT/small_trace.log 2>&1
+  cd $R
+  cp $(find $OUT/small -name "*kernel_stats.csv" | head -1) $OUT/small_step_kernel_stats.csv
+  head -4 $OUT/small_step_kernel_stats.csv;;
 esac; done
-rm -rf $OUT/t1 $OUT/t2 $OUT/roll $OUT/f64
+rm -rf $OUT/t1 $OUT/t2 $OUT/roll $OUT/f64 $OUT/small
 ls -la $OUT

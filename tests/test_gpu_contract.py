@@ -496,8 +496,10 @@ def test_workspace_tables_are_optional_and_checked(ops):
     assert int(ws.info.abs().sum()) == 0
     _check_vs_oracle(K[:1].cpu().numpy(), y, mean, 1e-5, out1.cpu().numpy(), ws.alpha.cpu().numpy(), [0])
     L = _lib.lib()
-    raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 256, dtype=torch.uint8, device="cuda")   # never initialised
-    ptr = (raw.data_ptr() + 255) // 256 * 256
+    # never initialised -- and at an address no initialised workspace ever had (the library recognises the regions it
+    # initialised by their address; torch hands freed blocks out again, 512-byte aligned)
+    raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 1024, dtype=torch.uint8, device="cuda")
+    ptr = (raw.data_ptr() + 511) // 512 * 512 + 256
     out2, alpha2 = torch.empty(B, 8, device="cuda"), torch.empty(B, n, device="cuda")
     info2 = torch.empty(B, dtype=torch.int32, device="cuda")
     _lib.check(L.volt_mll_step_f32(K.data_ptr(), n, n * n, r.data_ptr(), s2.data_ptr(), 0.0, out2.data_ptr(), alpha2.data_ptr(),
@@ -512,7 +514,8 @@ def test_workspace_tables_are_optional_and_checked(ops):
     assert int(ws.info.abs().sum()) == 0 and torch.equal(out3, out1)
 
 
-@pytest.mark.parametrize("B,n", [(1, 399), (3, 100), (8, 399), (64, 399), (5, 257), (16, 512), (130, 300)])
+@pytest.mark.parametrize("B,n", [(1, 399), (3, 100), (8, 399), (64, 399), (5, 257), (16, 512), (130, 300), (1, 1023), (8, 640),
+                                 (3, 900), (12, 1024)])
 def test_short_series_run_as_one_launch(ops, B, n):
     """Up to four block columns (N <= 512, the reference's ntrain = 400: experiments/stocks/ForecastGenerator.py:53-91)
     the whole gradient step is ONE launch (small_step_kernel: step-numbered flags between the pieces, the tiles below a
@@ -531,8 +534,10 @@ def test_short_series_run_as_one_launch(ops, B, n):
     rows = sorted({0, B // 2, B - 1})
     _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out1.cpu().numpy(), alpha1.cpu().numpy(), rows)
     L = _lib.lib()
-    raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 256, dtype=torch.uint8, device="cuda")   # never initialised
-    ptr = (raw.data_ptr() + 255) // 256 * 256
+    # never initialised -- and at an address no initialised workspace ever had (the library recognises the regions it
+    # initialised by their address; torch hands freed blocks out again, 512-byte aligned)
+    raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 1024, dtype=torch.uint8, device="cuda")
+    ptr = (raw.data_ptr() + 511) // 512 * 512 + 256
     out2, alpha2 = torch.empty(B, 8, device="cuda"), torch.empty(B, n, device="cuda")
     info2 = torch.empty(B, dtype=torch.int32, device="cuda")
     _lib.check(L.volt_mll_step_f32(K.data_ptr(), n, n * n, r.data_ptr(), s2.data_ptr(), 0.0, out2.data_ptr(), alpha2.data_ptr(),

@@ -1865,8 +1865,8 @@ struct Tunables {
     int sched = 1, sched_minb = 3, sched_maxb = 31, sched_maxb_potrf = 64;
     int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
     float sched_frac = 0.6f;
-    int small_nmax = 4, small_maxwg = 16384;   // the one-launch step: block columns it takes, and workgroups at most
-    int small_maxb = 32, small_maxb2 = 96;     // ... series at most (three or four block columns / one or two)
+    int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
+    int small_maxb = 32, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 32;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
 };
 static const Tunables& tunables() {
@@ -2380,13 +2380,16 @@ int volt_internal_sched_install(void* tab, size_t tab_bytes, int B, int n, int h
 
 // ---- the one-launch step for short series (small_step_kernel): its state lives in the caller's workspace, written once
 // by volt_mll_workspace_init_f32; like the schedule tables, a step uses it only for a region this library initialised.
+static int small_pieces(int n) { return n * (n + 1) / 2 + (n - 1) * (n - 2) / 2 + n + (n > 2 ? n - 2 : 0); }   // workgroups per series
 static bool small_applies(int B, int n) {
     const Tunables& tn = tunables();
-    // measured (scripts/bench_small_step.py): from ~48 series of three or four block columns on (~128 of one or two) the
-    // pieces wait for workgroup slots rather than for each other and the launch-per-column path is the faster one
-    return n >= 1 && n <= tn.small_nmax && n <= 8 && B <= (n <= 2 ? tn.small_maxb2 : tn.small_maxb) && (int64_t)B * (n * n + n) <= tn.small_maxwg;
+    // measured (scripts/bench_small_step.py, profiles/r03/small_step_table.txt): the one launch wins while a series'
+    // pieces find workgroup slots when their flags come up -- up to 32 series of 3 .. 5 block columns (16 of 8), 64 of one
+    // or two; beyond that the pieces wait for slots rather than for each other and the launch-per-column path is faster
+    if (n < 1 || n > tn.small_nmax || n > 8) return false;
+    if (n <= 2) return B <= tn.small_maxb2;
+    return B <= tn.small_maxb && (int64_t)B * small_pieces(n) <= tn.small_maxwg;
 }
-static int small_pieces(int n) { return n * (n + 1) / 2 + (n - 1) * (n - 2) / 2 + n + (n > 2 ? n - 2 : 0); }   // workgroups per series
 size_t volt_internal_small_bytes(int B, int n) {
     if (!small_applies(B, n)) return 0;
     return (((size_t)SMALL_HDR + (size_t)B * small_stride(n)) * sizeof(int) + 255) & ~(size_t)255;
