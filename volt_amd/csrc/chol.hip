@@ -1585,10 +1585,9 @@ __device__ __forceinline__ void alpha_part(const f32x16 (&O)[4], const SmallTail
 // then (behind the row's count) its share of alpha.  Two threads per row / column instead of trtri_diag_body's one, and
 // the residual staged in LDS: this tile is the last piece of its row to start (it needs the WHOLE of W_i).
 __device__ __forceinline__ void small_diag_tile(const float* __restrict__ Winv, float* __restrict__ Y, int Np, int i, int b,
-                                                const TriReduce& red, const SmallTail& tl, int* rowc, int* yflag, int want,
+                                                const TriReduce& red, const SmallTail& tl, int* rowc, int want,
                                                 int* info_b, float* smem) {
     const int n = Np / TS, tid = threadIdx.x;
-    float* Yb = Y + (int64_t)b * Np * Np;
     const float* W = Winv + ((int64_t)b * n + i) * TS * TS;
     float* srv = smem + TS * WLD;                                   // residual block i, then z_i
     float* sfr = srv + TS;                                          // 256 Frobenius partials
@@ -1626,16 +1625,11 @@ __device__ __forceinline__ void small_diag_tile(const float* __restrict__ Winv, 
         const float tot = wave_sum_f((sfr[tid] + sfr[tid + 64]) + (sfr[tid + 128] + sfr[tid + 192]));
         if (tid == 0) red.frob[(int64_t)b * (n * (n + 1) / 2) + i * (i + 1) / 2 + i] = tot;
     }
-    // ---- the partials are out: the row's count.  Then the tile itself (64 KB of stores that nothing in this row waits
-    // for), z_i, this tile's share of alpha:  apart[i][block i][c] = sum_{r >= c} W[r][c] z_i[r]
+    // ---- the partials are out: the row's count, z_i, this tile's share of alpha:  apart[i][block i][c] = sum_{r >= c}
+    // W[r][c] z_i[r].  The tile itself (64 KB of stores that nothing in this row waits for) follows in small_diag_tile_out.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(rowc, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    float* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
-    for (int e = tid; e < TS * TS; e += NT) {
-        const int c = e >> 7, r = e & 127;                          // Y row c, column r
-        Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
-    }
     small_wait(rowc, nullptr, (int)((unsigned)want * (unsigned)(i + 1)), info_b);
     row_z(red, tl, Np, i, i, b, srv);
     {
@@ -1651,48 +1645,53 @@ __device__ __forceinline__ void small_diag_tile(const float* __restrict__ Winv, 
         ap += __shfl_xor(ap, 1);
         if (h == 0) tl.apart[((int64_t)b * n + i) * Np + i * TS + c] = ap;
     }
+}
+// ... and the tile, out of the W image that small_diag_tile left in LDS: Y[i,i] = W_i^T
+__device__ __forceinline__ void small_diag_tile_out(float* __restrict__ Y, int Np, int i, int b, int* yflag, int want,
+                                                    const float* smem) {
+    float* Yd = Y + (int64_t)b * Np * Np + (int64_t)i * TS * Np + (int64_t)i * TS;
+    for (int e = threadIdx.x; e < TS * TS; e += NT) {
+        const int c = e >> 7, r = e & 127;                          // Y row c, column r
+        Yd[(int64_t)c * Np + r] = (r >= c) ? smem[r * WLD + c] : 0.f;
+    }
     small_publish(yflag, want);
 }
+constexpr int SMALL_SPARE = TS * WLD + TS + NT;                      // floats of the staging area small_diag_tile leaves alone
 
-// The last T piece of the series to deliver: alpha = sum of the partial sums, the scalars (= mll_scalars_kernel)
+// The last T piece of the series to deliver: alpha = sum of the partial sums, the scalars (= mll_scalars_kernel).
+// sred: 16 doubles of LDS that nothing else is using (the diagonal tile's W image is still wanted).
 __device__ __forceinline__ void small_tail_scalars(const float* __restrict__ A, int Np, int b, const TriReduce& red,
-                                                   const SmallTail& tl, float* smem) {
-    const int n = Np / TS, tid = threadIdx.x;
-    double* sred = reinterpret_cast<double*>(smem);                 // [4][256]: the four sums go down one tree together
+                                                   const SmallTail& tl, double* sred) {
+    const int n = Np / TS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* Ab = A + (int64_t)b * Np * Np;
     const int N = tl.N;
-    double q = 0, ld = 0, aa = 0, tr = 0;
+    double v[4] = {0, 0, 0, 0};                                     // z'z, sum log L_ii, alpha'alpha, tr K^-1
     for (int c = tid; c < Np; c += NT) {
         float al = 0.f;
         for (int i = c / TS; i < n; ++i) al += tl.apart[((int64_t)b * n + i) * Np + c];
         tl.apad[(int64_t)b * Np + c] = al;
         if (c < N) {
             const double zi = tl.z[(int64_t)b * Np + c];
-            q += zi * zi;
-            ld += log((double)Ab[(int64_t)c * Np + c]);
-            aa += (double)al * al;
+            v[0] += zi * zi;
+            v[1] += log((double)Ab[(int64_t)c * Np + c]);
+            v[2] += (double)al * al;
             tl.alpha[(int64_t)b * N + c] = al;
         }
     }
     const int nt = n * (n + 1) / 2;
-    for (int i = tid; i < nt; i += NT) tr += red.frob[(int64_t)b * nt + i];
-    sred[tid] = q;
-    sred[256 + tid] = ld;
-    sred[512 + tid] = aa;
-    sred[768 + tid] = tr;
-    __syncthreads();
-    for (int s2 = 128; s2 > 0; s2 >>= 1) {
-        if (tid < s2) {
+    for (int i = tid; i < nt; i += NT) v[3] += red.frob[(int64_t)b * nt + i];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) sred[256 * v + tid] += sred[256 * v + tid + s2];
-        }
-        __syncthreads();
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+        if (lane == 0) sred[4 * wave + k] = v[k];
     }
-    q = sred[0];
-    ld = 2.0 * sred[256];
-    aa = sred[512];
-    tr = sred[768];
+    __syncthreads();
     if (tid == 0) {
+        const double q = (sred[0] + sred[4]) + (sred[8] + sred[12]);
+        const double ld = 2.0 * ((sred[1] + sred[5]) + (sred[9] + sred[13]));
+        const double aa = (sred[2] + sred[6]) + (sred[10] + sred[14]);
+        const double tr = (sred[3] + sred[7]) + (sred[11] + sred[15]);
         const double LOG_2PI = 1.8378770664093453;
         float* o = tl.out + (int64_t)b * 8;
         o[0] = (float)(-0.5 * (q + ld + N * LOG_2PI) / N);
@@ -1755,7 +1754,29 @@ __global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ 
     if (kind == 0 && k == 0) {
         if (tid == 0) *info_b = 0;
         for (int c = tid; c < Np; c += NT) tl.rpad[(int64_t)b * Np + c] = c < tl.N ? tl.resid[(int64_t)b * tl.N + c] : 0.f;
-        update_body<true>(A, Np, 0, 0, 0, 0, true, b, src, smem, true);
+        {   // the first diagonal tile straight from the caller's K into the pivot image: lower triangle only, every load
+            // of a thread in flight at once (update_body's accumulator detour costs 5.3 us here, this 3)
+            const float add = (src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter;
+            const float* Kb = src.K + (int64_t)b * src.bsk;
+            float v[TS * TS / NT];
+#pragma unroll
+            for (int it = 0; it < TS * TS / 4 / NT; ++it) {
+                const int e = tid + it * NT, r = e >> 5, c = (e & 31) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    v[4 * it + q] = (c + q <= r && r < src.N) ? Kb[(int64_t)r * src.ldk + c + q] : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < TS * TS / 4 / NT; ++it) {
+                const int e = tid + it * NT, r = e >> 5, c = (e & 31) * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float x = v[4 * it + q];
+                    if (c + q == r) x = r < src.N ? x + add : 1.f;
+                    smem[r * DT + c + q] = x;
+                }
+            }
+        }
         SMALL_STAMP(3);
         diag_body<false, true>(A, Winv, info, Np, 0, b, smem, nullptr, true, wf, want, sf);
         SMALL_STAMP(4);
@@ -1803,7 +1824,7 @@ __global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ 
         if (i == j) {
             small_wait(wf + i, nullptr, want, info_b);
             SMALL_STAMP(1);
-            small_diag_tile(Winv, Y, Np, i, b, red, tl, rowc + i, yf + i * n + i, want, info_b, smem);
+            small_diag_tile(Winv, Y, Np, i, b, red, tl, rowc + i, want, info_b, smem);
         } else {
             SMALL_STAMP(1);
             TriJob jb = trtri_job(A, Winv, Y, Np, i, j, b);
@@ -1834,7 +1855,9 @@ __global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ 
             s_last = (unsigned)(t + 1) == (unsigned)want * (unsigned)nT;
         }
         __syncthreads();
-        if (s_last) small_tail_scalars(A, Np, b, red, tl, smem);
+        static_assert((SMALL_SPARE % 2) == 0 && SMALL_SPARE + 32 <= 2 * STAGE_FLOATS, "16 doubles behind the diagonal tile's LDS");
+        if (s_last) small_tail_scalars(A, Np, b, red, tl, reinterpret_cast<double*>(smem + SMALL_SPARE));
+        if (i == j) small_diag_tile_out(Y, Np, i, b, yf + i * n + i, want, smem);
     }
     SMALL_STAMP(5);
     // ---- the last workgroup out closes the step
