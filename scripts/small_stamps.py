@@ -44,6 +44,8 @@ def name(w):
             return b, f"U({k + 1})"
         if w < (nh + k) * B:
             w -= nh * B
+            if B * nb <= 224:
+                return w % B, f"T({k - 1},{w // B})"
             return w // k, f"T({k - 1},{w % k})"
         w -= (nh + k) * B
     raise ValueError

@@ -1275,8 +1275,8 @@ __global__ void tune_empty_kernel(float* A) { if (A == nullptr) A[0] = 0.f; }
 //            A[k,k] -= L[k,k-1] L[k,k-1]^T from LDS into the pivot image, factor + invert -> W_k.
 //   P(i,k)   i >= k+2: the other panel tiles (two-phase, as in factor_step_kernel).
 //   T(i,j)   tiles of Y = L^-T with the z / Frobenius partials; T(i,i) copies W_i^T.
-//   grid order (piece-major, series-minor):  for k = 0..n-1:  D(0) | S(k);  P(k+2..n-1, k);  T(k-1, 0..k-1)
-//                                            then T(n-1, 0..n-1) series-major.
+//   grid order (piece-major, series-minor):  for k = 0..n-1:  D(0) | S(k);  P(k+2..n-1, k);  U(k+1);  T(k-1, 0..k-1)
+//                                            then T(n-1, 0..n-1).
 //   S(k)    waits L[k,k-2], L[k-1,k-2] (ahead), W_{k-1};                  publishes L[k,k-1], then W_k
 //   P(i,k)  waits L[i,k-1], L[k,k-1] (phase 1), W_k (phase 2);            publishes L[i,k]
 //   T(i,j)  waits L[i,i-1], Y[i-1,j] (phase 1), W_i (phase 2);            publishes Y[i,j]
@@ -1732,10 +1732,15 @@ __global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ 
             else { kind = 3; k = kk + 1; }
         } else if (w < (nh + kk) * B) {
             w -= nh * B;
-            b = w / kk;
             kind = 2;
             i = kk - 1;
-            j = w % kk;
+            if (B * n <= 224) {              // a whole row's pieces of every series fit the resident set: keep series-minor,
+                j = w / B;                   // so that with B a multiple of 8 a series stays on its XCD (8 x 399: 139 -> 132 us)
+                b = w % B;
+            } else {                         // else the pieces of a row next to each other (they wait for each other)
+                b = w / kk;
+                j = w % kk;
+            }
         } else {
             w -= (nh + kk) * B;
         }
