@@ -1894,8 +1894,8 @@ struct Tunables {
     int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
     float sched_frac = 0.6f;
     int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
-    int small_maxb = 32, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
-    int small_pad_maxb = 32;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
+    int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
+    int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
 };
 static const Tunables& tunables() {
     static const Tunables tn = [] {
@@ -2412,7 +2412,7 @@ static int small_pieces(int n) { return n * (n + 1) / 2 + (n - 1) * (n - 2) / 2 
 static bool small_applies(int B, int n) {
     const Tunables& tn = tunables();
     // measured (scripts/bench_small_step.py, profiles/r03/small_step_table.txt): the one launch wins while a series'
-    // pieces find workgroup slots when their flags come up -- up to 32 series of 3 .. 5 block columns (16 of 8), 64 of one
+    // pieces find workgroup slots when their flags come up -- up to 40 series of 3 .. 4 block columns (16 of 8), 64 of one
     // or two; beyond that the pieces wait for slots rather than for each other and the launch-per-column path is faster
     if (n < 1 || n > tn.small_nmax || n > 8) return false;
     if (n <= 2) return B <= tn.small_maxb2;
