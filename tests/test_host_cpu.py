@@ -43,6 +43,11 @@ def test_argument_validation_without_a_device():
     assert L.volt_potrf_workspace_bytes(8, 4096) == 64 * 33 * 65536 + (33 * 33 * 8 * 4 + 255) // 256 * 256 + tables
     assert L.volt_potrf_workspace_bytes(64, 4096) > 128 * 33 * 65536
     assert L.volt_mll_workspace_bytes(64, 4096, 1) > L.volt_mll_workspace_bytes(64, 4096, 0) > 0
+    # the one-launch step for short series keeps its state and alpha's partial sums in the workspace: there for
+    # the shapes it takes (few series of N <= 1024, gradient step), absent where the library keeps the launch-per-column path
+    base = lambda B, N: L.volt_mll_workspace_bytes(B, N, 1) / B
+    assert base(32, 399) > base(64, 399) and base(64, 256) > base(128, 256)
+    assert L.volt_mll_workspace_bytes(8, 399, 1) - L.volt_mll_workspace_bytes(8, 399, 0) > 8 * 512 * 512 * 4   # + Y, partials, state
     assert L.volt_rollout_scratch_bytes(2, 3, 4) == 2 * 3 * 16 * 4
     assert L.volt_mll_workspace_init_f32(None, 8, 4096, 1, None) == -1 and L.volt_potrf_workspace_init_f32(None, 0, 8, 100, None) == -4
     assert L.volt_potrf_workspace_init_f32(None, 0, 100, 4096, None) == 0          # no scratch for that shape: nothing to do
