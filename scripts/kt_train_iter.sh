@@ -31,7 +31,7 @@ for f in glob.glob("gpurun_out/kt_iter/*kernel_trace.csv") + glob.glob("gpurun_o
 rows.sort()
 # last iteration: from the last prepare_kernel on ... back to the one before
 idx = [i for i, r in enumerate(rows) if "fill_kernel" in r[2] or "prepare_kernel" in r[2]]
-marks = [i for i, r in enumerate(rows) if "mll_scalars" in r[2]]
+marks = [i for i, r in enumerate(rows) if "mll_scalars" in r[2] or "small_step_kernel" in r[2]]
 a, b = marks[-2], marks[-1]
 t0 = rows[a + 1][0]
 for s, e, nm in rows[a + 1:b + 1]:

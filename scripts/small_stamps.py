@@ -17,9 +17,17 @@ ws = ops.MllWorkspace(B, n, True, K.device)
 for _ in range(10):
     ops.mll_step(K, r, s2, ws)
 nb = ops.padded_n(n) // 128
-G = B * (nb * (nb + 1) // 2 + (nb - 1) * (nb - 2) // 2 + nb + max(nb - 2, 0))
-st = torch.zeros(G, 16, dtype=torch.int64, device="cuda")
 L = _lib.lib()
+LONG = nb > 8                      # one long series: the piece list comes from the library (csrc/long_sched.h)
+if LONG:
+    first, emin = int(os.environ.get("VOLT_LONG_FIRST", 4)), int(os.environ.get("VOLT_LONG_EMIN", 2))
+    npieces = L.volt_long_describe(nb, first, emin, None, 0, None, None)
+    items = np.zeros((npieces, 4), dtype=np.int32)
+    L.volt_long_describe(nb, first, emin, items.ctypes.data, npieces, None, None)
+    G = npieces
+else:
+    G = B * (nb * (nb + 1) // 2 + (nb - 1) * (nb - 2) // 2 + nb + max(nb - 2, 0))
+st = torch.zeros(G, 16, dtype=torch.int64, device="cuda")
 L.volt_tune_small_stamps(st.data_ptr())
 ops.mll_step(K, r, s2, ws)
 torch.cuda.synchronize()
@@ -28,9 +36,24 @@ s = st.cpu().numpy().astype(np.float64)
 t0 = s[:, 0].min()
 us = (s - t0) / 100.0
 us[s == 0] = np.nan
+KINDS = ["D", "S", "P", "U", "T", "T", "eP", "eT", "eU"]
+
+
+def name_long(w):
+    x, y = int(items[w, 0]), int(items[w, 1])
+    kind, a, bb = x & 255, (x >> 8) & 255, (x >> 16) & 255
+    if kind == 0:
+        return 0, "D(0)"
+    if kind in (1, 3):
+        return 0, f"{KINDS[kind]}({a})" + (f"/{y}" if y else "")
+    if kind >= 6:
+        return 0, f"{KINDS[kind]}({a},{bb})[{y & 255}:{(y >> 8) & 255}]"
+    return 0, f"{KINDS[kind]}({a},{bb})" + (f"/{y}" if y else "")
 
 
 def name(w):
+    if LONG:
+        return name_long(w)
     for k in range(nb + 1):
         npan = max(nb - k - 2, 0) if k < nb else 0
         nu = 1 if (k >= 1 and k + 1 <= nb - 1) else 0
@@ -54,7 +77,7 @@ def name(w):
 print(f"B={B} N={n}: step spans {np.nanmax(us):.1f} us;  columns: enter, wait1, wait2 (spine: ahead part done), work (spine: image ready), published, exit (us from the first entry)")
 for w in range(G):
     b, nm = name(w)
-    if b in (0, B - 1):
+    if b in (0, B - 1) and (not LONG or nm[0] in os.environ.get("SHOW", "DS")):
         print(f"  series {b:3d} {nm:8s} " + " ".join("    -  " if np.isnan(v) else f"{v:7.1f}" for v in us[w, :6]))
         if nm.startswith("S("):
             print("             spine: flags seen " + " ".join(f"{v:6.1f}" for v in us[w, 6:10]) + "  solved %.1f  all there %.1f  rank32 %.1f  image %.1f  out %.1f" % tuple(us[w, 10:15]))

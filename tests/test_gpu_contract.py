@@ -515,7 +515,7 @@ def test_workspace_tables_are_optional_and_checked(ops):
 
 
 @pytest.mark.parametrize("B,n", [(1, 399), (3, 100), (8, 399), (64, 399), (5, 257), (16, 512), (130, 300), (1, 1023), (8, 640),
-                                 (3, 900), (12, 1024)])
+                                 (3, 900), (12, 1024), (1, 1500), (1, 2048), (1, 4096)])
 def test_short_series_run_as_one_launch(ops, B, n):
     """Up to four block columns (N <= 512, the reference's ntrain = 400: experiments/stocks/ForecastGenerator.py:53-91)
     the whole gradient step is ONE launch (small_step_kernel: step-numbered flags between the pieces, the tiles below a

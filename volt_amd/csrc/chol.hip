@@ -18,6 +18,7 @@
 // (factor_step_kernel); P3 is the second.
 #include "common.h"
 #include "sched.h"
+#include "long_sched.h"
 #include "../../include/volt_hip.h"
 #include "../../include/volt_hip_tune.h"
 #include <algorithm>
@@ -1390,11 +1391,12 @@ __device__ __forceinline__ void job_t0(const TriJob& jb, f32x16 (&T)[4]) {
 // the rank-32 update L'_j L'_j^T in that pipeline's K order, so that after the last slab only a quarter of the product is
 // left, and the result lands in the pivot image (lower triangle, zeros above) that diag_body works on.  MODE 2: a tile of
 // Y = L^-T (the same right-hand product against W_i): the slabs' products are kept in O for the reductions.
-template <int MODE>
+struct NoOp { __device__ __forceinline__ void operator()() const {} };
+template <int MODE, class F = NoOp>
 __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __restrict__ Lkk, int Np,
                                                 const float* __restrict__ Wk, const int* slab, int want,
                                                 float* __restrict__ out, float* sL, f32x16 (&X)[4],
-                                                long long* stamps = nullptr) {
+                                                long long* stamps = nullptr, F before_first_rank = F()) {
 #define SUB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
@@ -1429,6 +1431,7 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
         // ---- between the flags: what the slabs already here owe slab j (their L_kk blocks came with THEIR flags), and
         // for the spine the rank-32 update of the slab before, whose MFMAs cover the latency of those loads
         if (j > 0) {
+            if (MODE == 1 && j == 1) before_first_rank();          // (long series: the spine's accumulators are loaded as late as this)
             f32x4 la[3][4];
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -1523,11 +1526,11 @@ __device__ __forceinline__ void phase1_two_parts(TriTile t, f32x16 (&T)[4], floa
 
 // -C into the spine's accumulators: C = the look-ahead part of A[k,k] (parked in A by U(k); for k = 1 the caller's K)
 __device__ __forceinline__ void spine_load_c(const float* __restrict__ A, int Np, int k, int b, const KSource& src,
-                                             f32x16 (&acc)[4]) {
+                                             f32x16 (&acc)[4], bool from_k = false) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31;
     const int wr = wave >> 1, wc = wave & 1;
     const float* Ab = A + (int64_t)b * Np * Np;
-    const bool usek = k == 1;
+    const bool usek = k == 1 || from_k;
     const float add = usek ? ((src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter) : 0.f;
     const float* Kb = usek ? src.K + (int64_t)b * src.bsk : nullptr;
 #pragma unroll
@@ -1881,6 +1884,247 @@ __global__ void small_init_kernel(int* __restrict__ base, int count, int B, int 
     base[i] = i == 0 ? SMALL_MAGIC : i == 1 ? B : i == 2 ? n : 0;
 }
 
+// ----------------------------------------------------------------------------- ONE long series in one launch
+// (long_sched.h) The pieces of small_step_kernel for 9 .. 32 block columns, the early part of every deep tile's first
+// phase cut into K-slices that are pieces of their own.  Same flags, same step counter, same tail; one workgroup per CU.
+struct LongState {
+    int* hdr;                                  // as SmallState::hdr (B = 1)
+    int* ser;                                  // [0] T pieces delivered  [4..) sf[n][4] rowc[n] wf[n] lf[n][n] yf[n][n] uf[n] ecnt[ncnt]
+    const int4* items;                         // the piece list, one entry per workgroup
+    const int4* uinfo;                         // [n] {_, slabs, first slab, counter} of the look-ahead tile U(k)
+    float* eslab;                              // [nslabs][128*128] partial accumulators of the early-part slices
+    long long* stamps;
+};
+// acc += the nsl consecutive slabs at `slabs` (slab_dump's layout), read with sc1 loads: the slices wrote them through and
+// raised a counter, no fence on either side
+__device__ __forceinline__ void slab_add_sc1(f32x16 (&acc)[4], const float* __restrict__ slabs, int nsl) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slabs, 0, 0x7fffffff, 0x00020000);
+    for (int sidx = 0; sidx < nsl; ++sidx) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    rs, ((t4 * 4 + g) * NT + (int)threadIdx.x) * 16, sidx * TS * TS * 4, AUX_SC1));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[t4][4 * g + e] += v[e];
+            }
+    }
+}
+// a slice's partial sums out: write-through, every wave drained, then the tile's counter
+__device__ __forceinline__ void slice_out(const f32x16 (&acc)[4], float* __restrict__ slab, int* counter) {
+    slab_dump(acc, slab);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256, 2) void long_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                          float* __restrict__ Y, int* __restrict__ info, int Np,
+                                                          KSource src, TriReduce red, LongState st, SmallTail tl) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    __shared__ int s_last;
+    const int n = Np / TS, tid = threadIdx.x;
+    if (st.hdr[0] != SMALL_MAGIC || st.hdr[1] != 1 || st.hdr[2] != n) {          // not (or no longer) what init wrote
+        if (tid == 0 && blockIdx.x == 0) info[0] = (int)0x80000001;
+        return;
+    }
+    const int want = __hip_atomic_load(st.hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const int4 item = st.items[blockIdx.x];
+    const int pk = item.x & 255, pa = (item.x >> 8) & 255, pb = (item.x >> 16) & 255;
+    const bool isE = pk >= LG_E_PANEL;
+    const int nslices = isE ? 0 : item.y;                           // base pieces: slices their early part came in
+    const float* eslabs = st.eslab + (int64_t)item.z * TS * TS;
+    int* ser = st.ser;
+    int* sf = ser + 4;
+    int* rowc = sf + 4 * n;
+    int* wf = rowc + n;
+    int* lf = wf + n;
+    int* yf = lf + n * n;
+    int* uf = yf + n * n;
+    int* ecnt = uf + n;
+    int* info_b = info;
+    float* Ab = A;
+    SMALL_STAMP(0);
+    auto wait_slices = [&]() {
+        if (tid == 0 && !wait_flag_backoff(ecnt + item.w, (int)((unsigned)want * (unsigned)nslices))) atomicCAS(info_b, 0, (int)0x80000000);
+        __syncthreads();
+    };
+
+    if (pk == LG_D0) {
+        if (tid == 0) *info_b = 0;
+        for (int c = tid; c < Np; c += NT) tl.rpad[c] = c < tl.N ? tl.resid[c] : 0.f;
+        update_body<true>(A, Np, 0, 0, 0, 0, true, 0, src, smem, true);
+        diag_body<false, true>(A, Winv, info, Np, 0, 0, smem, nullptr, true, wf, want, sf);
+    } else if (pk == LG_U || pk == LG_E_U) {
+        // ---- the look-ahead part of diagonal tile (k,k): U(k) adds its early slices (if any) to its own block(s) and parks
+        // C = input - sum in A for the spine; a slice E_U just dumps its partial sum
+        const int kk = pa;
+        f32x16 acc[4];
+        zero_acc(acc);
+        if (pk == LG_E_U) {                                        // (U itself multiplies nothing: all its blocks come as slabs, the
+            const int u0 = item.y & 255, u1 = (item.y >> 8) & 255; //  last one from P(k,k-2) the moment that tile is there)
+            small_wait(lf + kk * n + (u1 - 1), nullptr, want, info_b);
+            const float* rows = Ab + (int64_t)kk * TS * Np + (int64_t)u0 * TS;
+            gemm_nt_128<0>(rows, Np, rows, Np, (u1 - u0) * (TS / BK), acc, smem);
+        }
+        if (pk == LG_E_U) {
+            slice_out(acc, st.eslab + (int64_t)item.z * TS * TS, ecnt + item.w);
+        } else {
+            if (nslices > 0) {
+                wait_slices();
+                slab_add_sc1(acc, eslabs, nslices);
+            }
+            const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+            const float add = (src.sigma2 ? src.sigma2[0] : 0.f) + src.jitter;
+            float* C = Ab + (int64_t)kk * TS * Np + (int64_t)kk * TS;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                        const int c = wc * 64 + tn * 32 + (lane & 31);
+                        C[(int64_t)r * Np + c] = input_elem(src, src.K, add, Ab, Np, true, kk * TS + r, kk * TS + c) - acc[tm * 2 + tn][q];
+                    }
+            small_publish(uf + kk, want);
+        }
+    } else if (pk == LG_TDIAG) {
+        small_wait(wf + pa, nullptr, want, info_b);
+        small_diag_tile(Winv, Y, Np, pa, 0, red, tl, rowc + pa, want, info_b, smem);
+    } else {
+        // ---- a two-phase tile: spine / panel tile under diagonal block kd, a tile of the inverse, or a K-slice of either.
+        // ONE instance of the phase-1 pipeline serves them all: [early blocks], then [the last block] (a slice has only
+        // the former, a tile whose early part came as slices only the latter).
+        const bool isT = pk == LG_T || pk == LG_E_T;
+        const int kd = pk == LG_SPINE ? pa - 1 : pb;               // S / P / E_PANEL: the diagonal block above the tile
+        TriJob jb = isT ? trtri_job(A, Winv, Y, Np, pa, pb, 0) : panel_job<true>(A, Winv, Np, pa, kd, 0, src);
+        const int blocks = jb.t.n1 / 4;                            // K blocks of the whole first phase
+        int e0, e1, l0, l1;                                        // K blocks run here: the early range, the last block
+        if (isE) {
+            e0 = item.y & 255; e1 = (item.y >> 8) & 255;
+            l0 = l1 = 0;
+        } else {
+            e0 = 0; e1 = nslices > 0 ? 0 : blocks - 1;
+            l0 = blocks > 0 ? blocks - 1 : 0; l1 = blocks;
+        }
+        f32x16 T[4];
+        if (isE || isT) zero_acc(T);
+        else job_t0(jb, T);
+        if (!isE && nslices > 0) {                                 // the early part came as slices: add them up
+            wait_slices();
+            slab_add_sc1(T, eslabs, nslices);
+        }
+#pragma unroll 1
+        for (int part = 0; part < 2; ++part) {
+            const int q0 = part == 0 ? e0 : l0, q1 = part == 0 ? e1 : l1;
+            if (q1 <= q0) continue;
+            // what a range ending at block q1 (exclusive) reads: S / P: L[row, q1-1] and L[kd, q1-1];  T(i,j): L[i, j+q1-1], Y[j+q1-1, j]
+            small_wait(isT ? lf + pa * n + (pb + q1 - 1) : lf + pa * n + (q1 - 1),
+                       isT ? yf + (pb + q1 - 1) * n + pb : lf + kd * n + (q1 - 1), want, info_b);
+            TriTile t = jb.t;
+            t.X += (int64_t)q0 * TS;
+            t.Z += (int64_t)q0 * TS;
+            t.n1 = 4 * (q1 - q0);
+            tri_phase1_only(t, T, smem);
+        }
+        SMALL_STAMP(2);
+        if (isE) {
+            slice_out(T, st.eslab + (int64_t)item.z * TS * TS, ecnt + item.w);
+        } else if (!isT) {
+            f32x16 X[4];
+            const float* Lkk = Ab + (int64_t)kd * TS * Np + (int64_t)kd * TS;
+            const float* Wk = Winv + (int64_t)kd * TS * TS;
+            bool ok;
+            if (pk == LG_SPINE) {
+                const int k = pa;
+                // -A[k,k] (its look-ahead part, parked by U(k) -- whose last block is only a block column old) comes into the
+                // accumulators right before the first rank-32 update, not before the first slab
+                // -A[k,k] + what block columns m < k-1 owe it: the early blocks summed and parked by U(k), the last one a slab that
+                // P(k,k-2) wrote the moment its tile existed
+                auto load_c = [&]() {
+                    const int4 ui = st.uinfo[k];                   // {U(k) exists, -, P(k,k-2)'s slab, its counter}
+                    if (ui.x) small_wait(uf + k, nullptr, want, info_b);
+                    spine_load_c(A, Np, k, 0, src, X, !ui.x);      // parked by U(k), or (k <= 2) the input tile itself
+                    if (k >= 2) {
+                        if (tid == 0 && !wait_flag_backoff(ecnt + ui.w, want)) atomicCAS(info_b, 0, (int)0x80000000);
+                        __syncthreads();
+                        slab_add_sc1(X, st.eslab + (int64_t)ui.z * TS * TS, 1);
+                    }
+                };
+                load_c();                                          // (both are there by now: P(k,k-2)'s slab is a block column old)
+                ok = substitute_tile<1>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
+                                        st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
+                if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
+                SMALL_STAMP(4);
+                diag_body<false, true>(A, Winv, info, Np, k, 0, smem, nullptr, true, wf + k, want, sf + 4 * k, lf + k * n + kd);
+            } else {
+                ok = substitute_tile<0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X);
+                if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
+                if (pa == kd + 2) {
+                    __syncthreads();                               // every wave's rows of the tile are in LDS
+                    // L[k,k-2] is the last block diagonal tile k = pa is still owed, and it sits in this workgroup's LDS: its
+                    // product with its own transpose goes out as the last of U(k)'s slabs right now (no round trip, no wait)
+                    const int4 ui = st.uinfo[pa];
+                    const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5, wr = wave >> 1, wc = wave & 1;
+                    zero_acc(X);
+#pragma unroll 2
+                    for (int kk = 0; kk < TS / 8; ++kk) {
+                        const int ko = kk * 8 + 4 * lh;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(smem + (wr * 64 + l31) * WLD + ko);
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(smem + (wc * 64 + l31) * WLD + ko);
+                        const f32x4 b1 = *reinterpret_cast<const f32x4*>(smem + (wc * 64 + 32 + l31) * WLD + ko);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(smem + (wr * 64 + 32 + l31) * WLD + ko);
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) {
+                            X[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m], X[0], 0, 0, 0);
+                            X[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b1[m], X[1], 0, 0, 0);
+                            X[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b0[m], X[2], 0, 0, 0);
+                            X[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m], X[3], 0, 0, 0);
+                        }
+                    }
+                    slice_out(X, st.eslab + (int64_t)ui.z * TS * TS, ecnt + ui.w);
+                }
+                small_publish(lf + pa * n + kd, want);
+            }
+        } else {
+            const int i = pa, j = pb;
+            f32x16 O[4];
+            const bool ok = substitute_tile<2>(T, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np, Winv + (int64_t)i * TS * TS,
+                                               sf + 4 * i, want, jb.out, smem, O);
+            if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
+            __syncthreads();                                       // the reductions' scratch overlays the waves' L rows
+            trtri_reduce(O, Np, i, j, 0, red, smem);
+            small_publish(yf + i * n + j, want);
+            if (tid == 0) __hip_atomic_fetch_add(rowc + i, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            small_wait(rowc + i, nullptr, (int)((unsigned)want * (unsigned)(i + 1)), info_b);
+            row_z(red, tl, Np, i, j, 0, smem);
+            alpha_part(O, tl, Np, i, j, 0, smem);
+        }
+    }
+    if (pk == LG_T || pk == LG_TDIAG) {                            // the tiles of the inverse close the series' tail
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int nT = n * (n + 1) / 2;
+            const int t = __hip_atomic_fetch_add(ser, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (unsigned)(t + 1) == (unsigned)want * (unsigned)nT;
+        }
+        __syncthreads();
+        if (s_last) small_tail_scalars(A, Np, 0, red, tl, reinterpret_cast<double*>(smem + SMALL_SPARE));
+        if (pk == LG_TDIAG) small_diag_tile_out(Y, Np, pa, 0, yf + pa * n + pa, want, smem);
+    }
+    SMALL_STAMP(5);
+    if (tid == 0) {                                                // the last workgroup out closes the step
+        const int f = __hip_atomic_fetch_add(st.hdr + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == (int)gridDim.x - 1) {
+            __hip_atomic_store(st.hdr + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.hdr + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 }  // namespace volt
 
 using namespace volt;
@@ -1894,6 +2138,7 @@ struct Tunables {
     int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
     float sched_frac = 0.6f;
     int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
+    int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
 };
@@ -1920,6 +2165,10 @@ static const Tunables& tunables() {
         geti("VOLT_SMALL_PAD_MAXB", t.small_pad_maxb);
         geti("VOLT_SMALL_MAXB", t.small_maxb);
         geti("VOLT_SMALL_MAXB2", t.small_maxb2);
+        geti("VOLT_LONG", t.long_on);
+        geti("VOLT_LONG_FIRST", t.long_first);
+        geti("VOLT_LONG_EMIN", t.long_emin);
+        geti("VOLT_LONG_PAD", t.long_pad);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         return t;
     }();
@@ -2464,6 +2713,102 @@ int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const flo
     return 1;
 }
 
+// ---- ONE long series in one launch (long_step_kernel, long_sched.h)
+struct LongPlanDev {
+    int4* items = nullptr;                     // pinned host
+    int nitems = 0, nslabs = 0, ncnt = 0;
+};
+static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
+    static std::mutex mu;
+    static std::map<std::array<int, 3>, LongPlanDev*> cache;
+    const Tunables& tn = tunables();
+    const std::array<int, 3> key{n, tn.long_first, tn.long_emin};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin);
+    static_assert(sizeof(LongItem) == sizeof(int4), "items are read as int4");
+    LongPlanDev* pd = new LongPlanDev;
+    pd->nitems = (int)pl.items.size();
+    pd->nslabs = pl.nslabs;
+    pd->ncnt = pl.ncnt;
+    if (hipHostMalloc((void**)&pd->items, (pl.items.size() + n) * sizeof(int4), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        delete pd;
+        pd = nullptr;
+    } else {
+        memcpy(pd->items, pl.items.data(), pl.items.size() * sizeof(int4));
+        memcpy(pd->items + pl.items.size(), pl.uinfo.data(), (size_t)n * sizeof(int4));
+    }
+    cache[key] = pd;
+    return pd;
+}
+static bool long_applies(int B, int n) {
+    const Tunables& tn = tunables();
+    return tn.long_on && B == 1 && n > 8 && n > tn.small_nmax && n <= 32;
+}
+static size_t long_flag_ints(int n, int ncnt) { return (size_t)SMALL_HDR + (size_t)((4 + 7 * n + 2 * n * n + ncnt + 31) & ~31); }
+size_t volt_internal_long_bytes(int B, int n) {
+    if (!long_applies(B, n)) return 0;
+    const Tunables& tn = tunables();
+    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin);
+    return ((long_flag_ints(n, pl.ncnt) * sizeof(int) + 255) & ~(size_t)255) + (((pl.items.size() + n) * sizeof(int4) + 255) & ~(size_t)255);
+}
+size_t volt_internal_long_slab_floats(int B, int n) {
+    if (!long_applies(B, n)) return 0;
+    const Tunables& tn = tunables();
+    return (size_t)long_build(n, tn.long_first, tn.long_emin).nslabs * TS * TS;
+}
+static std::map<std::pair<int, const void*>, int> g_long_installed;
+int volt_internal_long_install(void* state, size_t bytes, int B, int n, void* stream) {
+    if (!state || !long_applies(B, n) || bytes < volt_internal_long_bytes(B, n)) return 0;
+    const LongPlanDev* pd = get_long_plan(n, (hipStream_t)stream);
+    if (!pd) return 0;
+    const int count = (int)long_flag_ints(n, pd->ncnt);
+    hipLaunchKernelGGL(small_init_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int*)state, count, 1, n);
+    VOLT_LAUNCH_CHECK();
+    char* tab = reinterpret_cast<char*>(state) + (((size_t)count * sizeof(int) + 255) & ~(size_t)255);
+    hipError_t e = hipMemcpyAsync(tab, pd->items, (size_t)(pd->nitems + n) * sizeof(int4), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_installed_mu);
+    g_long_installed[{dev, state}] = n;
+    return 0;
+}
+// 1: enqueued (one launch);  0: not applicable (launch-per-column path)
+int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                            float jitter, float* A, float* Winv, float* Y, int* info, float* rpad, float* zpart,
+                            float* frob, float* z, float* apad, float* apart, float* eslab, float* out, float* alpha,
+                            void* state, int B, int N, void* stream) {
+    const int Np = volt_padded_n(N), n = Np / TS;
+    hipStream_t s = (hipStream_t)stream;
+    if (!state || !Y || !apart || !eslab || !long_applies(B, n)) return 0;
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(g_installed_mu);
+        auto it = g_long_installed.find({dev, state});
+        if (it == g_long_installed.end() || it->second != n) return 0;
+    }
+    const LongPlanDev* pd = get_long_plan(n, s);
+    if (!pd) return 0;
+    int* base = (int*)state;
+    const size_t flag_bytes = (long_flag_ints(n, pd->ncnt) * sizeof(int) + 255) & ~(size_t)255;
+    const KSource src{K, ldk, bsk, sigma2, jitter, N};
+    const TriReduce red{rpad, zpart, frob, N};
+    const SmallTail tl{resid, rpad, z, apad, apart, sigma2, jitter, out, alpha, N};
+    const int4* tab = reinterpret_cast<const int4*>(reinterpret_cast<char*>(state) + flag_bytes);
+    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps};
+    // one workgroup per CU (16 KB of LDS padding): a pivot chain that shares its CU runs 1.5 - 3x slower
+    const unsigned pad = tunables().long_pad ? 16 * 1024 : 0;
+    hipLaunchKernelGGL(long_step_kernel, dim3(pd->nitems), dim3(256), pad, s, A, Winv, Y, info, Np, src, red, st, tl);
+    VOLT_LAUNCH_CHECK();
+    return 1;
+}
+
 // used by mll.hip
 int volt_internal_factor(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
                          float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
@@ -2555,6 +2900,18 @@ int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac
     if (items) memcpy(items, it.data(), it.size() * sizeof(SchedItem));
     if (loads) memcpy(loads, ld.data(), ld.size() * sizeof(float));
     return (int)it.size();
+}
+
+int volt_long_describe(int n, int first, int emin, int* items, int max_items, int* nslabs, int* ncnt) {
+    if (n < 1 || n > 32) return -1;
+    if (first < 1) return -2;
+    if (emin < 0) return -3;
+    const LongPlan pl = long_build(n, first, emin);
+    if (nslabs) *nslabs = pl.nslabs;
+    if (ncnt) *ncnt = pl.ncnt;
+    if (items)
+        for (int i = 0; i < (int)pl.items.size() && i < max_items; ++i) memcpy(items + 4 * i, &pl.items[i], sizeof(LongItem));
+    return (int)pl.items.size();
 }
 
 int volt_tune_small_stamps(long long* stamps) {

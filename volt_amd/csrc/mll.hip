@@ -121,6 +121,9 @@ struct MllWs {
     size_t tab_bytes;
     void* small;             // state of the one-launch step for short series (chol.hip), small_bytes long
     size_t small_bytes;
+    void* lng;               // state of the one-launch step for one long series (chol.hip), lng_bytes long
+    size_t lng_bytes;
+    float* eslab;            // ... and the slabs of its early-part slices
     size_t bytes;
 };
 
@@ -135,6 +138,13 @@ int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const flo
                              float jitter, float* A, float* Winv, float* Y, int* info, float* rpad, float* zpart,
                              float* frob, float* z, float* apad, float* apart, float* out, float* alpha, void* state,
                              int B, int N, void* stream);
+size_t volt_internal_long_bytes(int B, int n);
+size_t volt_internal_long_slab_floats(int B, int n);
+int volt_internal_long_install(void* state, size_t bytes, int B, int n, void* stream);
+int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
+                            float jitter, float* A, float* Winv, float* Y, int* info, float* rpad, float* zpart,
+                            float* frob, float* z, float* apad, float* apart, float* eslab, float* out, float* alpha,
+                            void* state, int B, int N, void* stream);
 namespace volt {
 
 static MllWs carve(void* base, int B, int N, int want_grad) {
@@ -174,7 +184,10 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
     w.tab = w.tab_bytes ? take(w.tab_bytes / sizeof(float)) : nullptr;
     w.small_bytes = want_grad ? volt_internal_small_bytes(B, (int)n) : 0;
     w.small = w.small_bytes ? take(w.small_bytes / sizeof(float)) : nullptr;
-    w.apart = w.small_bytes ? take((size_t)B * n * Np) : nullptr;              // alpha's partial sums, per row of the inverse
+    w.lng_bytes = want_grad ? volt_internal_long_bytes(B, (int)n) : 0;
+    w.lng = w.lng_bytes ? take(w.lng_bytes / sizeof(float)) : nullptr;
+    w.eslab = w.lng_bytes ? take(volt_internal_long_slab_floats(B, (int)n)) : nullptr;
+    w.apart = (w.small_bytes || w.lng_bytes) ? take((size_t)B * n * Np) : nullptr;   // alpha's partial sums, per row of the inverse
     w.bytes = off;
     return w;
 }
@@ -251,6 +264,10 @@ int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, vo
         const int rc = volt_internal_small_install(w.small, w.small_bytes, B, n, stream);
         if (rc) return rc;
     }
+    if (w.lng) {
+        const int rc = volt_internal_long_install(w.lng, w.lng_bytes, B, n, stream);
+        if (rc) return rc;
+    }
     if (!w.tab) return 0;
     return volt_internal_sched_install(w.tab, w.tab_bytes, B, n, want_grad, w.sk_rows, stream);
 }
@@ -275,6 +292,12 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     if (want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
         rc = volt_internal_small_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                       w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
+        if (rc == 1) return 0;
+        if (rc) return rc > 0 ? rc : -1;
+    }
+    if (want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
+        rc = volt_internal_long_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
+                                     w.z, w.apad, w.apart, w.eslab, out, alpha, w.lng, B, N, stream);
         if (rc == 1) return 0;
         if (rc) return rc > 0 ? rc : -1;
     }
