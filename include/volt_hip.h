@@ -187,7 +187,8 @@ size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
 /* Once per workspace (and again should the caller have overwritten it), asynchronously on `stream`: copies the
  * launch-schedule table for this shape into the workspace (3 .. 31 series), and for short series (want_grad = 1, N <= 1024:
  * up to 40 series of N <= 512, 16 of N = 1024, 64 of N <= 256) writes the state of the ONE-LAUNCH step: a header, a step counter and the
- * flags its workgroups hand tiles on with -- volt_mll_step_f32 then enqueues one kernel for the whole step instead of
+ * flags its workgroups hand tiles on with (for ONE series of 1025 .. 4096 points also the list of its pieces, and the
+ * workspace holds the slabs of their K-slices) -- volt_mll_step_f32 then enqueues one kernel for the whole step instead of
  * eleven (the counter lives on the device, so the launch replays from a hipGraph as it is).  Optional, like
  * volt_potrf_workspace_init_f32: a workspace that was never initialised gets the launch-per-column path.  The library
  * recognises the regions it initialised BY ADDRESS and every launch that follows a table or the state checks the
