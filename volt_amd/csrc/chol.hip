@@ -1971,12 +1971,29 @@ __global__ __launch_bounds__(256, 2) void long_step_kernel(float* __restrict__ A
         if (pk == LG_E_U) {
             slice_out(acc, st.eslab + (int64_t)item.z * TS * TS, ecnt + item.w);
         } else {
+            // U(k): the early slabs first (they have been there for block columns), the input tile into registers, and then
+            // the one slab that is only just being written: P(k,k-2)'s L[k,k-2] L[k,k-2]^T -- so that what the spine finds
+            // parked in A is final and its own load is one round trip
             if (nslices > 0) {
                 wait_slices();
                 slab_add_sc1(acc, eslabs, nslices);
             }
             const int lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
             const float add = (src.sigma2 ? src.sigma2[0] : 0.f) + src.jitter;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                        const int c = wc * 64 + tn * 32 + (lane & 31);
+                        acc[tm * 2 + tn][q] -= input_elem(src, src.K, add, Ab, Np, true, kk * TS + r, kk * TS + c);
+                    }
+            const int4 ui = st.uinfo[kk];
+            if (tid == 0 && !wait_flag_backoff(ecnt + ui.w, want)) atomicCAS(info_b, 0, (int)0x80000000);
+            __syncthreads();
+            slab_add_sc1(acc, st.eslab + (int64_t)ui.z * TS * TS, 1);
             float* C = Ab + (int64_t)kk * TS * Np + (int64_t)kk * TS;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
@@ -1986,7 +2003,7 @@ __global__ __launch_bounds__(256, 2) void long_step_kernel(float* __restrict__ A
                     for (int q = 0; q < 16; ++q) {
                         const int r = wr * 64 + tm * 32 + accrow(q, lane);
                         const int c = wc * 64 + tn * 32 + (lane & 31);
-                        C[(int64_t)r * Np + c] = input_elem(src, src.K, add, Ab, Np, true, kk * TS + r, kk * TS + c) - acc[tm * 2 + tn][q];
+                        C[(int64_t)r * Np + c] = -acc[tm * 2 + tn][q];
                     }
             small_publish(uf + kk, want);
         }
@@ -2046,14 +2063,14 @@ __global__ __launch_bounds__(256, 2) void long_step_kernel(float* __restrict__ A
                 auto load_c = [&]() {
                     const int4 ui = st.uinfo[k];                   // {U(k) exists, -, P(k,k-2)'s slab, its counter}
                     if (ui.x) small_wait(uf + k, nullptr, want, info_b);
-                    spine_load_c(A, Np, k, 0, src, X, !ui.x);      // parked by U(k), or (k <= 2) the input tile itself
-                    if (k >= 2) {
+                    spine_load_c(A, Np, k, 0, src, X, !ui.x);      // final, parked by U(k) -- or (k <= 2) the input tile itself ...
+                    if (k == 2) {                                  // ... plus, for k = 2, the one slab there is
                         if (tid == 0 && !wait_flag_backoff(ecnt + ui.w, want)) atomicCAS(info_b, 0, (int)0x80000000);
                         __syncthreads();
                         slab_add_sc1(X, st.eslab + (int64_t)ui.z * TS * TS, 1);
                     }
                 };
-                load_c();                                          // (both are there by now: P(k,k-2)'s slab is a block column old)
+                load_c();
                 ok = substitute_tile<1>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
                                         st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
                 if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
