@@ -385,6 +385,21 @@ def test_batched_driver_matches_per_series_functions(va, mean):
         assert p0.shape[0] == B and float(p0.detach().std()) > 0
 
 
+def test_graph_captured_loop_on_a_long_series(va):
+    """One series of 1 200 points runs its gradient step as ONE launch (long_step_kernel: host-made piece list, slabs,
+    a step counter on the device) -- captured once and replayed, it must train like the eager loop."""
+    from volt_amd.train_utils import TrainVoltMagpieModel
+    n = 1200
+    F, vol = sde_series(n, 11)
+    tx = torch.arange(n, device="cuda") / 252.
+    prices, v = dev(F), dev(vol)
+    out = {}
+    for graph in (False, True):
+        m, lh = TrainVoltMagpieModel(tx, prices[1:], None, None, v, train_iters=25, k=50, graph=graph)
+        out[graph] = float(lh.raw_noise.detach())
+    assert abs(out[False] - out[True]) < 2e-3 * max(1.0, abs(out[False])), out
+
+
 def test_graph_captured_training_loops_match_eager(va):
     """train_utils graph=True: the warm-up iterations run eagerly, then ONE captured iteration (every HIP launch of the
     step + the capturable Adam update) is replayed.  Same number of optimiser steps, same arithmetic: the trained
