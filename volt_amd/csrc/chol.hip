@@ -2155,7 +2155,7 @@ struct Tunables {
     int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
     float sched_frac = 0.6f;
     int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
-    int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
+    int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1, long_nmin = 7;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
 };
@@ -2186,6 +2186,7 @@ static const Tunables& tunables() {
         geti("VOLT_LONG_FIRST", t.long_first);
         geti("VOLT_LONG_EMIN", t.long_emin);
         geti("VOLT_LONG_PAD", t.long_pad);
+        geti("VOLT_LONG_NMIN", t.long_nmin);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         return t;
     }();
@@ -2764,7 +2765,7 @@ static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
 }
 static bool long_applies(int B, int n) {
     const Tunables& tn = tunables();
-    return tn.long_on && B == 1 && n > 8 && n > tn.small_nmax && n <= 32;
+    return tn.long_on && B == 1 && n > tn.long_nmin && n <= 32;     // (one series of 8 block columns: 0.289 ms here, 0.307 as a short series)
 }
 static size_t long_flag_ints(int n, int ncnt) { return (size_t)SMALL_HDR + (size_t)((4 + 7 * n + 2 * n * n + ncnt + 31) & ~31); }
 size_t volt_internal_long_bytes(int B, int n) {

@@ -289,15 +289,15 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     const int Np = volt_padded_n(N);
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
-    if (want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
-        rc = volt_internal_small_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
-                                      w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
-        if (rc == 1) return 0;
-        if (rc) return rc > 0 ? rc : -1;
-    }
     if (want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
         rc = volt_internal_long_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                      w.z, w.apad, w.apart, w.eslab, out, alpha, w.lng, B, N, stream);
+        if (rc == 1) return 0;
+        if (rc) return rc > 0 ? rc : -1;
+    }
+    if (want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
+        rc = volt_internal_small_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
+                                      w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
         if (rc == 1) return 0;
         if (rc) return rc > 0 ? rc : -1;
     }
