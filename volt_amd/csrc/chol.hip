@@ -2768,16 +2768,35 @@ static bool long_applies(int B, int n) {
     return tn.long_on && B == 1 && n > tn.long_nmin && n <= 32;     // (one series of 8 block columns: 0.289 ms here, 0.307 as a short series)
 }
 static size_t long_flag_ints(int n, int ncnt) { return (size_t)SMALL_HDR + (size_t)((4 + 7 * n + 2 * n * n + ncnt + 31) & ~31); }
+// sizes of the plan for n block columns (the workspace layout asks for them on every step: computed once)
+static void long_sizes(int n, size_t& items, int& nslabs, int& ncnt) {
+    static std::mutex mu;
+    static std::map<std::array<int, 3>, std::array<size_t, 3>> cache;
+    const Tunables& tn = tunables();
+    const std::array<int, 3> key{n, tn.long_first, tn.long_emin};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        const LongPlan pl = long_build(n, tn.long_first, tn.long_emin);
+        it = cache.emplace(key, std::array<size_t, 3>{pl.items.size(), (size_t)pl.nslabs, (size_t)pl.ncnt}).first;
+    }
+    items = it->second[0];
+    nslabs = (int)it->second[1];
+    ncnt = (int)it->second[2];
+}
 size_t volt_internal_long_bytes(int B, int n) {
     if (!long_applies(B, n)) return 0;
-    const Tunables& tn = tunables();
-    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin);
-    return ((long_flag_ints(n, pl.ncnt) * sizeof(int) + 255) & ~(size_t)255) + (((pl.items.size() + n) * sizeof(int4) + 255) & ~(size_t)255);
+    size_t items;
+    int nslabs, ncnt;
+    long_sizes(n, items, nslabs, ncnt);
+    return ((long_flag_ints(n, ncnt) * sizeof(int) + 255) & ~(size_t)255) + (((items + n) * sizeof(int4) + 255) & ~(size_t)255);
 }
 size_t volt_internal_long_slab_floats(int B, int n) {
     if (!long_applies(B, n)) return 0;
-    const Tunables& tn = tunables();
-    return (size_t)long_build(n, tn.long_first, tn.long_emin).nslabs * TS * TS;
+    size_t items;
+    int nslabs, ncnt;
+    long_sizes(n, items, nslabs, ncnt);
+    return (size_t)nslabs * TS * TS;
 }
 static std::map<std::pair<int, const void*>, int> g_long_installed;
 int volt_internal_long_install(void* state, size_t bytes, int B, int n, void* stream) {
