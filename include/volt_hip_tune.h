@@ -10,7 +10,8 @@
  *   VOLT_SCHED_MINB / _MAXB / _MAXB_POTRF   batch range of the balanced schedule (3 / 31 / 64)
  *   VOLT_SCHED_G / _S / _FRAC / _GROUPS / _KMIN   its slots (256), slices per tile (4), cut threshold (0.6), groups (2),
  *                          first scheduled block column (by batch size)
- *   VOLT_F64_LOOKAHEAD     fp64 factorisation: the chain / bulk multi-stream schedule on/off (1)   (read in csrc/chol64.hip)
+ *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
+ *                          1 = one column, 2 = two columns (2 from 6 matrices on, else 1)           (read in csrc/chol64.hip)
  *   VOLT_F64_SPLIT_TARGET  fp64: workgroups per K-sliced launch (512)
  * None of them is read by the product's Python; a deployment sets none.
  */

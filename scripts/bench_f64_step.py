@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from volt_amd import ops
 from volt_amd.synthetic import sde_batch
 
-def timeit(fn, reps=3):
+def timeit(fn, reps=int(os.environ.get('REPS', 3))):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -15,6 +15,8 @@ def timeit(fn, reps=3):
 
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 shapes = [(8, 4096), (1, 4096), (2, 4096), (32, 2048), (64, 399)]
+if os.environ.get("SHAPES"):
+    shapes = [tuple(int(v) for v in t.split("x")) for t in os.environ["SHAPES"].split(",")]
 rows = []
 for B, n in shapes:
     x, F, vol = sde_batch(B, n)

@@ -2511,8 +2511,8 @@ static StreamPool* stream_pool() {
 // chol64.hip runs its look-ahead on the same pool: one auxiliary stream, the fork event and five of the join events,
 // under the pool's mutex while it enqueues -- like run_factor_groups below.
 struct VoltAux {
-    hipStream_t aux, aux2;
-    hipEvent_t fork, ev[5];
+    hipStream_t aux, aux2, aux3;
+    hipEvent_t fork, ev[7];
     std::mutex* mu;
 };
 bool volt_internal_aux(VoltAux* out) {
@@ -2520,7 +2520,8 @@ bool volt_internal_aux(VoltAux* out) {
     if (!p) return false;
     // (lowest-priority streams for the bulk work were tried: the chain then waits for events from a stream the hardware
     // serves last -- one 4096^2 matrix 4.2 -> 8.1 ms)
-    *out = VoltAux{p->aux[0], p->aux[1], p->fork, {p->join[0], p->join[1], p->join[2], p->join[3], p->join[4]}, &p->mu};
+    *out = VoltAux{p->aux[0], p->aux[1], p->aux[2], p->fork,
+                   {p->join[0], p->join[1], p->join[2], p->join[3], p->join[4], p->join[5], p->join[6]}, &p->mu};
     return true;
 }
 

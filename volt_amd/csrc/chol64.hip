@@ -161,31 +161,36 @@ __global__ __launch_bounds__(256) void prepare64_kernel(const double* __restrict
 // not fixed, so with S > 1 the last bits of the factor can differ from run to run (the fp32 path's slab scheme is
 // bitwise repeatable; in fp64 the spread is ~1e-16 relative and the tests hold 1e-9 .. 1e-11).
 __global__ __launch_bounds__(256) void update64_kernel(double* __restrict__ A, int Np, int k, int row0, int ntiles, int kb0,
-                                                       int kb1, int B) {
+                                                       int kb1, int B, int S, int atomic) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    int t, b;
-    decode_tile_batch(ntiles, B, t, b);
-    const int S = gridDim.z, sl = blockIdx.z, len = kb1 - kb0;
-    const int c0 = kb0 + sl * len / S, c1 = kb0 + (sl + 1) * len / S;
-    if (c1 <= c0) return;
-    double* Ab = A + (int64_t)b * Np * Np;
-    const double* Arows = Ab + (int64_t)(row0 + t) * TS * Np + (int64_t)c0 * TS;
-    const double* Brows = Ab + (int64_t)k * TS * Np + (int64_t)c0 * TS;
-    double* C = Ab + (int64_t)(row0 + t) * TS * Np + (int64_t)k * TS;
-    f64x4 acc[16];
-    zero_acc64(acc);
-    gemm64_nt_128(Arows, Np, Brows, Np, (c1 - c0) * (TS / BK64), acc, smem);
+    const int nx = ntiles * B, len = kb1 - kb0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // grid = nx * S workgroups (or fewer, striding over the (tile, slice) pairs: persistent bulk grids of <= 248 workgroups,
+    // one per CU, that leave CUs free for the chain's kernels were measured -- 8 x 4096 potrf 6.58 ms either way -- and are not used)
+    for (int v = blockIdx.x; v < nx * S; v += gridDim.x) {
+        int t, b;
+        decode_tile_batch(v % nx, ntiles, B, t, b);
+        const int sl = v / nx;
+        const int c0 = kb0 + sl * len / S, c1 = kb0 + (sl + 1) * len / S;
+        if (c1 <= c0) continue;
+        double* Ab = A + (int64_t)b * Np * Np;
+        const double* Arows = Ab + (int64_t)(row0 + t) * TS * Np + (int64_t)c0 * TS;
+        const double* Brows = Ab + (int64_t)k * TS * Np + (int64_t)c0 * TS;
+        double* C = Ab + (int64_t)(row0 + t) * TS * Np + (int64_t)k * TS;
+        f64x4 acc[16];
+        zero_acc64(acc);
+        gemm64_nt_128(Arows, Np, Brows, Np, (c1 - c0) * (TS / BK64), acc, smem);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                VOLT_ACC64_RC(mt, nt, q)
-                if (S == 1) C[(int64_t)r * Np + c] -= acc[mt * 4 + nt][q];
-                else unsafeAtomicAdd(&C[(int64_t)r * Np + c], -acc[mt * 4 + nt][q]);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    VOLT_ACC64_RC(mt, nt, q)
+                    if (!atomic) C[(int64_t)r * Np + c] -= acc[mt * 4 + nt][q];
+                    else unsafeAtomicAdd(&C[(int64_t)r * Np + c], -acc[mt * 4 + nt][q]);
+                }
+    }
 }
 
 // ----------------------------------------------------------------------------- P3
@@ -682,8 +687,8 @@ using namespace volt;
 
 // chol.hip: the library's stream pool (one auxiliary stream, fork event, two more events, the enqueue mutex)
 struct VoltAux {
-    hipStream_t aux, aux2;
-    hipEvent_t fork, ev[5];
+    hipStream_t aux, aux2, aux3;
+    hipEvent_t fork, ev[7];
     std::mutex* mu;
 };
 bool volt_internal_aux(VoltAux* out);
@@ -792,7 +797,11 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
     // (the bulk of the flops, K-sliced with fp64 atomics so that a launch has ~512 workgroups whatever the batch).
     // Events: a = column done (C -> A), c = panel tiles ready for their solve (A -> C), b[2] = column k+1's old blocks
     // applied (A -> next C; two of them because A(k) is enqueued before C(k) has waited for A(k-1)'s).
-    static const int look = getenv("VOLT_F64_LOOKAHEAD") ? atoi(getenv("VOLT_F64_LOOKAHEAD")) : 1;
+    // look-ahead depth: 0 = one stream, 1 = one column, 2 = two columns.  Measured (N = 4096, potrf / MLL step, ms, depth 1 ->
+    // depth 2): B = 8 6.55 -> 5.87 / 10.6 -> 10.2, B = 16 11.6 -> 9.7 / 19.2 -> 17.6, 32 x 2048 3.81 -> 3.28 / 6.82 -> 6.54; B <= 4
+    // potrf +-2 % and the step 1 - 5 % SLOWER (the third stream competes with the rows of the inverse): depth 2 from B = 6
+    static const int look_env = getenv("VOLT_F64_LOOKAHEAD") ? atoi(getenv("VOLT_F64_LOOKAHEAD")) : -1;
+    const int look = look_env >= 0 ? look_env : (B >= 6 ? 2 : 1);
     static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
     auto slices = [&](int tiles, int kblocks) {
         int S = tiles > 0 ? target / tiles : 1;
@@ -807,7 +816,7 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
         for (int k = 0; k < n; ++k) {
             if (k > 0) {
                 const int S = slices((n - k) * B, k);
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k) * B, 1, S), dim3(256), 0, s, A, Np, k, k, n - k, 0, k, B);
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k) * B * S), dim3(256), 0, s, A, Np, k, k, n - k, 0, k, B, S, S > 1);
             }
             hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
             if (k + 1 < n) hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
@@ -828,17 +837,60 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
         VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ax.fork, 0));
         trtri64_begin(Y, B, Np, ax.aux2);
     }
+    if (look >= 2) {
+        // TWO-column look-ahead: the wide part of a column's update gets two chain steps to finish in instead of one.
+        // Column j receives   Z(j-2): blocks m <= j-3   (third stream, enqueued when column j-3 is done)
+        //                     Y(j-1): block  m  = j-2   (auxiliary stream, when column j-2 is done)
+        //                     X(j):   block  m  = j-1 into the tiles below the diagonal (auxiliary stream), and the
+        //                             same block into the diagonal tile on the chain itself.
+        // X, Y and Z of different steps may touch one tile at the same time: all three subtract with fp64 atomics.
+        hipEvent_t ev_y = ax.ev[2], ev_z[2] = {ax.ev[3], ax.ev[5]};
+        VOLT_TRY64(hipStreamWaitEvent(ax.aux3, ax.fork, 0));
+        for (int k = 0; k < n; ++k) {
+            // the chain's waits first (they refer to what earlier iterations recorded)
+            if (k >= 2) VOLT_TRY64(hipStreamWaitEvent(s, ev_y, 0));                 // Y(k-1): block k-2 is in column k
+            if (k >= 3) VOLT_TRY64(hipStreamWaitEvent(s, ev_z[k & 1], 0));          // Z(k-2): blocks <= k-3 are in column k
+            if (k >= 1 && k + 1 < n) {
+                VOLT_TRY64(hipStreamWaitEvent(ax.aux, ev_a, 0));                    // column k-1 complete
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), 0, ax.aux, A, Np, k, k + 1, n - k - 1,
+                                   k - 1, k, B, 1, 1);                               // X(k)
+                VOLT_TRY64(hipEventRecord(ev_c, ax.aux));
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), 0, ax.aux, A, Np, k + 1, k + 1,
+                                   n - k - 1, k - 1, k, B, 1, 1);                    // Y(k): block k-1 into column k+1
+                VOLT_TRY64(hipEventRecord(ev_y, ax.aux));
+            }
+            if (k >= 1 && k + 2 < n) {
+                VOLT_TRY64(hipStreamWaitEvent(ax.aux3, ev_a, 0));
+                const int S = slices((n - k - 2) * B, k);
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 2) * B * S), dim3(256), 0, ax.aux3, A, Np,
+                                   k + 2, k + 2, n - k - 2, 0, k, B, S, 1);          // Z(k): blocks <= k-1 into column k+2
+                VOLT_TRY64(hipEventRecord(ev_z[k & 1], ax.aux3));
+            }
+            if (Y && k >= 1) {
+                VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
+                trtri64_row(A, Winv, Y, B, Np, k - 1, ax.aux2);
+            }
+            if (k >= 1)
+                hipLaunchKernelGGL(update64_kernel, dim3(B), dim3(256), 0, s, A, Np, k, k, 1, k - 1, k, B, 1, 1);   // block k-1 into (k,k)
+            hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
+            if (k + 1 < n) {
+                if (k >= 1) VOLT_TRY64(hipStreamWaitEvent(s, ev_c, 0));
+                hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+                VOLT_TRY64(hipEventRecord(ev_a, s));
+            }
+        }
+    } else
     for (int k = 0; k < n; ++k) {
         // ---- A(k) on the auxiliary stream (needs column k-1 complete: event a)
         if (k >= 1) {
             VOLT_TRY64(hipStreamWaitEvent(ax.aux, ev_a, 0));
             if (k + 1 < n) {
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B, 1, 1), dim3(256), 0, ax.aux, A, Np, k, k + 1, n - k - 1,
-                                   k - 1, k, B);                             // block k-1 into the tiles (i,k), i > k
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), 0, ax.aux, A, Np, k, k + 1,
+                                   n - k - 1, k - 1, k, B, 1, 0);             // block k-1 into the tiles (i,k), i > k
                 VOLT_TRY64(hipEventRecord(ev_c, ax.aux));
                 const int S = slices((n - k - 1) * B, k);
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B, 1, S), dim3(256), 0, ax.aux, A, Np, k + 1, k + 1,
-                                   n - k - 1, 0, k, B);                      // blocks m < k into every tile of column k+1
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B * S), dim3(256), 0, ax.aux, A, Np, k + 1,
+                                   k + 1, n - k - 1, 0, k, B, S, S > 1);     // blocks m < k into every tile of column k+1
                 VOLT_TRY64(hipEventRecord(ev_b[k & 1], ax.aux));
             }
         }
@@ -850,7 +902,7 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
         // ---- C(k) on the caller's stream
         if (k >= 1) {
             if (k >= 2) VOLT_TRY64(hipStreamWaitEvent(s, ev_b[(k - 1) & 1], 0));   // column k's old blocks are in
-            hipLaunchKernelGGL(update64_kernel, dim3(B, 1, 1), dim3(256), 0, s, A, Np, k, k, 1, k - 1, k, B);   // block k-1 into (k,k)
+            hipLaunchKernelGGL(update64_kernel, dim3(B), dim3(256), 0, s, A, Np, k, k, 1, k - 1, k, B, 1, 0);   // block k-1 into (k,k)
         }
         hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
         if (k + 1 < n) {
