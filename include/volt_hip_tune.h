@@ -12,6 +12,8 @@
  *                          first scheduled block column (by batch size)
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
  *                          1 = one column, 2 = two columns (2 from 6 matrices on, else 1)           (read in csrc/chol64.hip)
+ *   VOLT_F64_TRTRI_LOOKAHEAD  fp64 inverse: one-row look-ahead on its own stream, 0 / 1 (on up to 4 matrices)
+ *   VOLT_F64_SPREAD        fp64: launches of up to this many workgroups run one workgroup per CU (512)
  *   VOLT_F64_SPLIT_TARGET  fp64: workgroups per K-sliced launch (512)
  * None of them is read by the product's Python; a deployment sets none.
  */

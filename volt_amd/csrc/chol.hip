@@ -2483,7 +2483,7 @@ static int begin_factor(float* Winv, int* info, int B, int n, hipStream_t s, int
 constexpr int MAX_GROUPS = 8;
 struct StreamPool {
     hipStream_t aux[MAX_GROUPS - 1];
-    hipEvent_t fork, join[MAX_GROUPS - 1];
+    hipEvent_t fork, join[MAX_GROUPS - 1], extra[5];     // extra: chol64.hip's look-ahead schedules
     std::mutex mu;
     int want_groups = 2;                 // tunables().groups
     bool ok = false;
@@ -2500,6 +2500,7 @@ static StreamPool* stream_pool() {
             ok = ok && hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
         }
+        for (int i = 0; i < 5; ++i) ok = ok && hipEventCreateWithFlags(&p.extra[i], hipEventDisableTiming) == hipSuccess;
         p.want_groups = tunables().groups;
         if (p.want_groups < 1) p.want_groups = 1;
         if (p.want_groups > MAX_GROUPS) p.want_groups = MAX_GROUPS;
@@ -2511,8 +2512,8 @@ static StreamPool* stream_pool() {
 // chol64.hip runs its look-ahead on the same pool: one auxiliary stream, the fork event and five of the join events,
 // under the pool's mutex while it enqueues -- like run_factor_groups below.
 struct VoltAux {
-    hipStream_t aux, aux2, aux3;
-    hipEvent_t fork, ev[7];
+    hipStream_t aux, aux2, aux3, aux4;
+    hipEvent_t fork, ev[12];
     std::mutex* mu;
 };
 bool volt_internal_aux(VoltAux* out) {
@@ -2520,8 +2521,9 @@ bool volt_internal_aux(VoltAux* out) {
     if (!p) return false;
     // (lowest-priority streams for the bulk work were tried: the chain then waits for events from a stream the hardware
     // serves last -- one 4096^2 matrix 4.2 -> 8.1 ms)
-    *out = VoltAux{p->aux[0], p->aux[1], p->aux[2], p->fork,
-                   {p->join[0], p->join[1], p->join[2], p->join[3], p->join[4], p->join[5], p->join[6]}, &p->mu};
+    *out = VoltAux{p->aux[0], p->aux[1], p->aux[2], p->aux[3], p->fork,
+                   {p->join[0], p->join[1], p->join[2], p->join[3], p->join[4], p->join[5], p->join[6], p->extra[0],
+                    p->extra[1], p->extra[2], p->extra[3], p->extra[4]}, &p->mu};
     return true;
 }
 

@@ -94,25 +94,27 @@ __device__ __forceinline__ void chunk64_run(const float* cur, float* nxt, bool m
 __device__ __forceinline__ void gemm64_nt_128(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
                                               int64_t ldb, int nchunks, f64x4 (&acc)[16], float* smem) {
     if (nchunks <= 0) return;
-    StageRegs s0, s1;
+    // ONE staging register set, loads one chunk ahead: with two sets (two chunks ahead, as the fp32 loop has it) a wave
+    // needs 242 + 128 registers and a SIMD holds one wave -- nothing covers its barrier and LDS waits, and the 128x128 fp64
+    // core stops at 57 TF/s (74 % of the 77 TF/s the MFMA pipe issues, scripts/ubench/mfma64.hip).  One set fits two.
+    StageRegs s0;
     const StageAddr sa = stage_addr(reinterpret_cast<const float*>(A), 2 * lda, reinterpret_cast<const float*>(B), 2 * ldb);
     stage_load_buf(s0, sa, 0);
     stage_store(s0, smem);
     if (nchunks > 1) stage_load_buf(s0, sa, BK);
-    if (nchunks > 2) stage_load_buf(s1, sa, 2 * BK);
     __syncthreads();
     Frag64 F0, F1;
     frag64_load(F0, smem, 0);
     float* b0 = smem;
     float* b1 = smem + STAGE_FLOATS;
     int c = 0;
-    for (; c + 4 < nchunks; c += 2) {
-        chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
-        chunk64_run<true>(b1, b0, true, F0, F1, acc, s1, true, true, sa, (c + 4) * BK);
+    for (; c + 3 < nchunks; c += 2) {
+        chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 2) * BK);
+        chunk64_run<true>(b1, b0, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
     }
     for (; c + 1 < nchunks; c += 2) {
-        chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 3 < nchunks, sa, (c + 3) * BK);
-        chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
+        chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 2 < nchunks, sa, (c + 2) * BK);
+        chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s0, c + 2 < nchunks, c + 3 < nchunks, sa, (c + 3) * BK);
     }
     if (c < nchunks) chunk64_run<false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
     __syncthreads();
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void prepare64_kernel(const double* __restrict
 // 8 (n - k) tiles of K = 128 k each (8 x 4096, k = 28: 32 tiles on 256 CUs).  The order in which the slices land is
 // not fixed, so with S > 1 the last bits of the factor can differ from run to run (the fp32 path's slab scheme is
 // bitwise repeatable; in fp64 the spread is ~1e-16 relative and the tests hold 1e-9 .. 1e-11).
-__global__ __launch_bounds__(256) void update64_kernel(double* __restrict__ A, int Np, int k, int row0, int ntiles, int kb0,
+__global__ __launch_bounds__(256, 2) void update64_kernel(double* __restrict__ A, int Np, int k, int row0, int ntiles, int kb0,
                                                        int kb1, int B, int S, int atomic) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     const int nx = ntiles * B, len = kb1 - kb0;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void update64_kernel(double* __restrict__ A, i
 
 // ----------------------------------------------------------------------------- P3
 // grid.x = (n-k-1) * B.  L[i,k] = A[i,k] W_k^T in place (all of the tile is read before the epilogue stores).
-__global__ __launch_bounds__(256) void trsm64_kernel(double* __restrict__ A, const double* __restrict__ Winv, int Np,
+__global__ __launch_bounds__(256, 2) void trsm64_kernel(double* __restrict__ A, const double* __restrict__ Winv, int Np,
                                                      int k, int B) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     const int n = Np / TS;
@@ -590,19 +592,24 @@ __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, dou
 //   phase 2  Y[j-rows c][i-cols r] = -sum_p S(i,j)[c][p] W_i[r][p];  and Y[i,i] = W_i^T
 // Both are "NT" products of K-contiguous rows on the 128x128 fp64 core.  (The fp32 path keeps S in the accumulators
 // and fuses the phases, chol.hip; here the tile makes one round trip through HBM -- N^2/2 doubles per matrix.)
-__global__ __launch_bounds__(256) void trtri64_p1_kernel(const double* __restrict__ A, double* __restrict__ Y, int Np, int i,
-                                                         int B) {
+// K range of tile j: blocks [max(j, klo), khi) -- the whole sum is (0, i); the look-ahead schedule cuts it into the early
+// part (0, i-1), which needs rows <= i-2 of the inverse only, and the last block (i-1, i).  `atomic`: add to the slot
+// (zeroed once) instead of storing -- K slices, and the two parts of the look-ahead schedule.
+__global__ __launch_bounds__(256, 2) void trtri64_p1_kernel(const double* __restrict__ A, double* __restrict__ Y, int Np, int i,
+                                                         int ntiles, int B, int klo, int khi, int atomic) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     int j, b;
-    decode_tile_batch(i, B, j, b);
-    // K slices (gridDim.z > 1: the slot was zeroed, the slices add their partial products with fp64 atomics -- few
-    // matrices would otherwise leave a launch as long as its longest tile on one CU, as in update64_kernel)
-    const int kb = i - j;
+    decode_tile_batch(ntiles, B, j, b);
+    // K slices (gridDim.z > 1: the slices add their partial products with fp64 atomics -- few matrices would otherwise
+    // leave a launch as long as its longest tile on one CU, as in update64_kernel)
+    const int k0 = j > klo ? j : klo;
+    const int kb = khi - k0;
+    if (kb <= 0) return;
     int nsl = gridDim.z < (kb + 1) / 2 ? gridDim.z : (kb + 1) / 2;
     if (nsl < 1) nsl = 1;
     const int sl = blockIdx.z;
     if (sl >= nsl) return;
-    const int c0 = j + sl * kb / nsl, c1 = j + (sl + 1) * kb / nsl;
+    const int c0 = k0 + sl * kb / nsl, c1 = k0 + (sl + 1) * kb / nsl;
     const double* Ab = A + (int64_t)b * Np * Np;
     double* Yb = Y + (int64_t)b * Np * Np;
     f64x4 acc[16];
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(256) void trtri64_p1_kernel(const double* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 VOLT_ACC64_RC(mt, nt, q)
-                if (gridDim.z == 1) S[(int64_t)r * Np + c] = acc[mt * 4 + nt][q];
+                if (!atomic) S[(int64_t)r * Np + c] = acc[mt * 4 + nt][q];
                 else unsafeAtomicAdd(&S[(int64_t)r * Np + c], acc[mt * 4 + nt][q]);
             }
 }
@@ -639,7 +646,7 @@ __global__ __launch_bounds__(256) void trtri64_zero_kernel(double* __restrict__ 
 }
 
 // grid: (i + 1) * B; tile j == i transposes W_i into Y[i,i]
-__global__ __launch_bounds__(256) void trtri64_p2_kernel(const double* __restrict__ Winv, double* __restrict__ Y, int Np,
+__global__ __launch_bounds__(256, 2) void trtri64_p2_kernel(const double* __restrict__ Winv, double* __restrict__ Y, int Np,
                                                          int i, int B) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     const int n = Np / TS;
@@ -687,8 +694,8 @@ using namespace volt;
 
 // chol.hip: the library's stream pool (one auxiliary stream, fork event, two more events, the enqueue mutex)
 struct VoltAux {
-    hipStream_t aux, aux2, aux3;
-    hipEvent_t fork, ev[7];
+    hipStream_t aux, aux2, aux3, aux4;
+    hipEvent_t fork, ev[12];
     std::mutex* mu;
 };
 bool volt_internal_aux(VoltAux* out);
@@ -699,6 +706,16 @@ bool volt_internal_aux(VoltAux* out);
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
+// The GEMM kernels fit two workgroups per CU (72 KB of LDS, 246 registers; one staging register set, gemm64_nt_128) and
+// run at 72 TF/s that way when a launch has many rounds of workgroups (64 x 4096, update launch k = 16 alone on the chip;
+// 64 - 66 TF/s with one workgroup per CU; 56 - 58 with the two staging sets that allowed only one).  A launch of up to 512
+// workgroups is SPREAD OUT instead -- 16 KB of LDS padding, one workgroup per CU, two rounds -- : the dispatcher otherwise
+// pairs them up, two share one MFMA pipe and the launch lasts as long as the slower pair (8 x 4096 potrf / inverse / MLL
+// step, ms: no spreading 6.38 / 6.05 / 11.7, up to 256 5.93 / 6.05 / 11.5, **up to 512 5.64 / 4.77 / 9.57**; flat beyond).
+static unsigned spread64(int workgroups) {
+    static const int lim = getenv("VOLT_F64_SPREAD") ? atoi(getenv("VOLT_F64_SPREAD")) : 512;
+    return workgroups <= lim ? 16 * 1024 : 0;
+}
 static int trtri64_slices(int i, int B) {                       // row i: i B tiles of 1 .. i K blocks
     static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
     int S = target / (i * B);
@@ -706,15 +723,39 @@ static int trtri64_slices(int i, int B) {                       // row i: i B ti
     if (S > 16) S = 16;
     return S < 1 ? 1 : S;
 }
-static void trtri64_begin(double* Y, int B, int Np, hipStream_t s) {
+// One-row look-ahead of the inverse (trtri64_early / trtri64_finish on two streams).  Measured at N = 4096, ms without -> with:
+// volt_trtri_f64 alone B = 1 2.10 -> 1.88, 2: 2.88 -> 2.60, 4: 4.05 -> 3.87, 8: 5.18 -> 5.14, 16: 9.0 -> 9.1; inside the MLL step
+// B <= 4 -1 %, B = 8 10.3 -> 12.0, 16: 17.6 -> 20.3 (from 8 matrices on the inverse is bound by the 128x128 fp64 core's
+// throughput, not by its chain, and one more stream only gets in the factorisation's way): up to 4 matrices.
+static bool trtri64_lookahead(int B) {
+    static const int env = getenv("VOLT_F64_TRTRI_LOOKAHEAD") ? atoi(getenv("VOLT_F64_TRTRI_LOOKAHEAD")) : -1;
+    return env >= 0 ? env != 0 : B <= 4;
+}
+static void trtri64_begin(double* Y, int B, int Np, hipStream_t s, bool lookahead = false) {
     const int n = Np / TS;
-    bool any = false;
+    bool any = lookahead;
     for (int i = 1; i < n; ++i) any = any || trtri64_slices(i, B) > 1;
     if (any) hipLaunchKernelGGL(trtri64_zero_kernel, dim3(n * (n - 1) / 2, B), dim3(256), 0, s, Y, Np);
 }
 static void trtri64_row(const double* A, const double* Winv, double* Y, int B, int Np, int i, hipStream_t s) {
-    if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B, 1, trtri64_slices(i, B)), dim3(256), 0, s, A, Y, Np, i, B);
-    hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), 0, s, Winv, Y, Np, i, B);
+    if (i > 0) {
+        const int S = trtri64_slices(i, B);
+        hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B, 1, S), dim3(256), spread64((i * B) * (S)), s, A, Y, Np, i, i, B, 0, i, S > 1);
+    }
+    hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), spread64((i + 1) * B), s, Winv, Y, Np, i, B);
+}
+// The look-ahead form of a row (slots zeroed by trtri64_begin(.., true)): the early part of phase 1 -- every K block but
+// the last, which needs rows <= i-2 of the inverse only -- goes out a row ahead on its own stream ...
+static void trtri64_early(const double* A, double* Y, int B, int Np, int i, hipStream_t s) {
+    if (i < 2) return;
+    const int S = trtri64_slices(i - 1, B);
+    hipLaunchKernelGGL(trtri64_p1_kernel, dim3((i - 1) * B, 1, S), dim3(256), spread64((i - 1) * B * S), s, A, Y, Np, i, i - 1, B, 0,
+                       i - 1, 1);
+}
+// ... and the chain of the inverse is two one-block launches per row: the last block of phase 1, then phase 2
+static void trtri64_finish(const double* A, const double* Winv, double* Y, int B, int Np, int i, hipStream_t s) {
+    if (i > 0) hipLaunchKernelGGL(trtri64_p1_kernel, dim3(i * B, 1, 1), dim3(256), spread64((i * B) * (1)), s, A, Y, Np, i, i, B, i - 1, i, 1);
+    hipLaunchKernelGGL(trtri64_p2_kernel, dim3((i + 1) * B), dim3(256), spread64((i + 1) * B), s, Winv, Y, Np, i, B);
 }
 
 // Factorisation (+ optional triangular inverse Y = L^-T, row k-1 riding on a THIRD stream beside block column k: at
@@ -763,8 +804,33 @@ int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int n = Np / TS;
-    trtri64_begin(Y, B, Np, s);
-    for (int i = 0; i < n; ++i) trtri64_row(A, Winv, Y, B, Np, i, s);
+    const bool look = trtri64_lookahead(B);
+    VoltAux ax;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool two = look && n >= 3 && volt_internal_aux(&ax) && hipStreamIsCapturing(s, &cap) == hipSuccess &&
+                     cap == hipStreamCaptureStatusNone;
+    if (!two) {
+        trtri64_begin(Y, B, Np, s);
+        for (int i = 0; i < n; ++i) trtri64_row(A, Winv, Y, B, Np, i, s);
+        VOLT_LAUNCH_CHECK();
+        return 0;
+    }
+    // Row i's early part (stream aux) runs beside row i-1's last block and phase 2 (the caller's stream)
+    std::lock_guard<std::mutex> lock(*ax.mu);
+    hipEvent_t ev_p2[2] = {ax.ev[7], ax.ev[8]}, ev_p1a = ax.ev[9];
+    trtri64_begin(Y, B, Np, s, true);
+    VOLT_TRY64(hipEventRecord(ax.fork, s));
+    VOLT_TRY64(hipStreamWaitEvent(ax.aux, ax.fork, 0));
+    for (int i = 0; i < n; ++i) {
+        if (i >= 2) {
+            VOLT_TRY64(hipStreamWaitEvent(ax.aux, ev_p2[i & 1], 0));        // row i-2 of the inverse is out
+            trtri64_early(A, Y, B, Np, i, ax.aux);
+            VOLT_TRY64(hipEventRecord(ev_p1a, ax.aux));
+            VOLT_TRY64(hipStreamWaitEvent(s, ev_p1a, 0));
+        }
+        trtri64_finish(A, Winv, Y, B, Np, i, s);
+        if (i + 2 < n) VOLT_TRY64(hipEventRecord(ev_p2[i & 1], s));
+    }
     VOLT_LAUNCH_CHECK();
     return 0;
 }
@@ -816,10 +882,10 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
         for (int k = 0; k < n; ++k) {
             if (k > 0) {
                 const int S = slices((n - k) * B, k);
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k) * B * S), dim3(256), 0, s, A, Np, k, k, n - k, 0, k, B, S, S > 1);
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k) * B * S), dim3(256), spread64((n - k) * B * S), s, A, Np, k, k, n - k, 0, k, B, S, S > 1);
             }
             hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
-            if (k + 1 < n) hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+            if (k + 1 < n) hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), spread64((n - k - 1) * B), s, A, Winv, Np, k, B);
         }
         if (Y) {
             trtri64_begin(Y, B, Np, s);
@@ -833,10 +899,31 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
     hipEvent_t ev_b[2] = {ax.ev[2], ax.ev[3]};
     VOLT_TRY64(hipEventRecord(ax.fork, s));
     VOLT_TRY64(hipStreamWaitEvent(ax.aux, ax.fork, 0));
+    // Rows of the inverse beside the factorisation, themselves with a one-row look-ahead: call k (column k-1 is complete)
+    // puts the last block + phase 2 of row k-1 on aux2 and the early part of row k -- it needs rows <= k-2 only -- on aux4
+    hipEvent_t ev_p2[2] = {ax.ev[7], ax.ev[8]}, ev_p1a = ax.ev[9];
+    const bool tri_look = trtri64_lookahead(B);
     if (Y) {
         VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ax.fork, 0));
-        trtri64_begin(Y, B, Np, ax.aux2);
+        VOLT_TRY64(hipStreamWaitEvent(ax.aux4, ax.fork, 0));
+        trtri64_begin(Y, B, Np, ax.aux2, tri_look);
     }
+    auto tri_step = [&](int k) -> int {
+        VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
+        if (!tri_look) {
+            trtri64_row(A, Winv, Y, B, Np, k - 1, ax.aux2);
+            return 0;
+        }
+        if (k - 1 >= 2) VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_p1a, 0));
+        trtri64_finish(A, Winv, Y, B, Np, k - 1, ax.aux2);
+        VOLT_TRY64(hipEventRecord(ev_p2[(k - 1) & 1], ax.aux2));
+        if (k >= 2 && k < n) {
+            VOLT_TRY64(hipStreamWaitEvent(ax.aux4, ev_p2[k & 1], 0));              // row k-2 is out
+            trtri64_early(A, Y, B, Np, k, ax.aux4);
+            VOLT_TRY64(hipEventRecord(ev_p1a, ax.aux4));
+        }
+        return 0;
+    };
     if (look >= 2) {
         // TWO-column look-ahead: the wide part of a column's update gets two chain steps to finish in instead of one.
         // Column j receives   Z(j-2): blocks m <= j-3   (third stream, enqueued when column j-3 is done)
@@ -852,30 +939,27 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
             if (k >= 3) VOLT_TRY64(hipStreamWaitEvent(s, ev_z[k & 1], 0));          // Z(k-2): blocks <= k-3 are in column k
             if (k >= 1 && k + 1 < n) {
                 VOLT_TRY64(hipStreamWaitEvent(ax.aux, ev_a, 0));                    // column k-1 complete
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), 0, ax.aux, A, Np, k, k + 1, n - k - 1,
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), spread64((n - k - 1) * B), ax.aux, A, Np, k, k + 1, n - k - 1,
                                    k - 1, k, B, 1, 1);                               // X(k)
                 VOLT_TRY64(hipEventRecord(ev_c, ax.aux));
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), 0, ax.aux, A, Np, k + 1, k + 1,
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), spread64((n - k - 1) * B), ax.aux, A, Np, k + 1, k + 1,
                                    n - k - 1, k - 1, k, B, 1, 1);                    // Y(k): block k-1 into column k+1
                 VOLT_TRY64(hipEventRecord(ev_y, ax.aux));
             }
             if (k >= 1 && k + 2 < n) {
                 VOLT_TRY64(hipStreamWaitEvent(ax.aux3, ev_a, 0));
                 const int S = slices((n - k - 2) * B, k);
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 2) * B * S), dim3(256), 0, ax.aux3, A, Np,
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 2) * B * S), dim3(256), spread64((n - k - 2) * B * S), ax.aux3, A, Np,
                                    k + 2, k + 2, n - k - 2, 0, k, B, S, 1);          // Z(k): blocks <= k-1 into column k+2
                 VOLT_TRY64(hipEventRecord(ev_z[k & 1], ax.aux3));
             }
-            if (Y && k >= 1) {
-                VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
-                trtri64_row(A, Winv, Y, B, Np, k - 1, ax.aux2);
-            }
+            if (Y && k >= 1) { const int rc_ = tri_step(k); if (rc_) return rc_; }
             if (k >= 1)
-                hipLaunchKernelGGL(update64_kernel, dim3(B), dim3(256), 0, s, A, Np, k, k, 1, k - 1, k, B, 1, 1);   // block k-1 into (k,k)
+                hipLaunchKernelGGL(update64_kernel, dim3(B), dim3(256), spread64(B), s, A, Np, k, k, 1, k - 1, k, B, 1, 1);   // block k-1 into (k,k)
             hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
             if (k + 1 < n) {
                 if (k >= 1) VOLT_TRY64(hipStreamWaitEvent(s, ev_c, 0));
-                hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+                hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), spread64((n - k - 1) * B), s, A, Winv, Np, k, B);
                 VOLT_TRY64(hipEventRecord(ev_a, s));
             }
         }
@@ -885,37 +969,33 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
         if (k >= 1) {
             VOLT_TRY64(hipStreamWaitEvent(ax.aux, ev_a, 0));
             if (k + 1 < n) {
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), 0, ax.aux, A, Np, k, k + 1,
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B), dim3(256), spread64((n - k - 1) * B), ax.aux, A, Np, k, k + 1,
                                    n - k - 1, k - 1, k, B, 1, 0);             // block k-1 into the tiles (i,k), i > k
                 VOLT_TRY64(hipEventRecord(ev_c, ax.aux));
                 const int S = slices((n - k - 1) * B, k);
-                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B * S), dim3(256), 0, ax.aux, A, Np, k + 1,
+                hipLaunchKernelGGL(update64_kernel, dim3((n - k - 1) * B * S), dim3(256), spread64((n - k - 1) * B * S), ax.aux, A, Np, k + 1,
                                    k + 1, n - k - 1, 0, k, B, S, S > 1);     // blocks m < k into every tile of column k+1
                 VOLT_TRY64(hipEventRecord(ev_b[k & 1], ax.aux));
             }
         }
         // ---- row k-1 of the triangular inverse on the third stream (needs column k-1 and W_{k-1}: event a)
-        if (Y && k >= 1) {
-            VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
-            trtri64_row(A, Winv, Y, B, Np, k - 1, ax.aux2);
-        }
+        if (Y && k >= 1) { const int rc_ = tri_step(k); if (rc_) return rc_; }
         // ---- C(k) on the caller's stream
         if (k >= 1) {
             if (k >= 2) VOLT_TRY64(hipStreamWaitEvent(s, ev_b[(k - 1) & 1], 0));   // column k's old blocks are in
-            hipLaunchKernelGGL(update64_kernel, dim3(B), dim3(256), 0, s, A, Np, k, k, 1, k - 1, k, B, 1, 0);   // block k-1 into (k,k)
+            hipLaunchKernelGGL(update64_kernel, dim3(B), dim3(256), spread64(B), s, A, Np, k, k, 1, k - 1, k, B, 1, 0);   // block k-1 into (k,k)
         }
         hipLaunchKernelGGL(diag64_kernel<false>, dim3(B), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, info, Np, k, nullptr);
         if (k + 1 < n) {
             if (k >= 1) VOLT_TRY64(hipStreamWaitEvent(s, ev_c, 0));            // the panel tiles have their last block
-            hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), 0, s, A, Winv, Np, k, B);
+            hipLaunchKernelGGL(trsm64_kernel, dim3((n - k - 1) * B), dim3(256), spread64((n - k - 1) * B), s, A, Winv, Np, k, B);
             VOLT_TRY64(hipEventRecord(ev_a, s));                               // column k complete
         }
     }
     // every launch of the auxiliary stream has been waited for by the caller's stream (c before trsm(n-2), b before C(n-1))
     if (Y) {                                                                  // the last row of the inverse, then join
         VOLT_TRY64(hipEventRecord(ev_a, s));
-        VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ev_a, 0));
-        trtri64_row(A, Winv, Y, B, Np, n - 1, ax.aux2);
+        { const int rc_ = tri_step(n); if (rc_) return rc_; }
         VOLT_TRY64(hipEventRecord(ev_d, ax.aux2));
         VOLT_TRY64(hipStreamWaitEvent(s, ev_d, 0));
     }
