@@ -2155,6 +2155,7 @@ struct Tunables {
     int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
     float sched_frac = 0.6f;
     int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
+    int plain_spread = 320, split_spread = 700;   // plain / all-split launches of up to this many workgroups run one workgroup per CU
     int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1, long_nmin = 7;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
@@ -2187,6 +2188,8 @@ static const Tunables& tunables() {
         geti("VOLT_LONG_EMIN", t.long_emin);
         geti("VOLT_LONG_PAD", t.long_pad);
         geti("VOLT_LONG_NMIN", t.long_nmin);
+        geti("VOLT_PLAIN_SPREAD", t.plain_spread);
+        geti("VOLT_SPLIT_SPREAD", t.split_spread);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         return t;
     }();
@@ -2431,27 +2434,35 @@ static void enqueue_step(const Group& g, int Np, int k, LaunchTimer* tm) {
         sk.L = L;
         const int gs = B + S * (npre + (n - k - 1) * B + (itri >= 0 ? (itri + 1) * B : 0));
         if (tm) tm->begin(0, g.s);
+        // (as the plain launches below: up to 700 slices one workgroup per CU -- two series of N = 4096 2.30 -> 2.12 ms/step)
+        const int split_spread = tunables().split_spread;
+        const unsigned spad = gs <= split_spread ? 16 * 1024 : 0;
         if (g.o.src.K)
-            hipLaunchKernelGGL(factor_step_split_kernel<true>, dim3(gs), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
+            hipLaunchKernelGGL(factor_step_split_kernel<true>, dim3(gs), dim3(256), spad, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
                                k, itri, B, g.o.src, g.o.Y ? g.o.red : nored, sk);
         else
-            hipLaunchKernelGGL(factor_step_split_kernel<false>, dim3(gs), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
+            hipLaunchKernelGGL(factor_step_split_kernel<false>, dim3(gs), dim3(256), spad, g.s, g.A, g.Winv, g.o.Y, g.info, Np,
                                k, itri, B, g.o.src, g.o.Y ? g.o.red : nored, sk);
         if (tm) tm->end(g.s);
         if (k + 1 == n && g.o.Y) {                           // the trailing trtri row: k = n (no factorisation part)
             if (tm) tm->begin(1, g.s);
-            hipLaunchKernelGGL(factor_step_split_kernel<false>, dim3(S * n * B), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y,
+            hipLaunchKernelGGL(factor_step_split_kernel<false>, dim3(S * n * B), dim3(256), S * n * B <= split_spread ? 16 * 1024 : 0, g.s, g.A, g.Winv, g.o.Y,
                                g.info, Np, n, n - 1, B, g.o.src, g.o.red, sk);
             if (tm) tm->end(g.s);
         }
         return;
     }
     if (tm) tm->begin(0, g.s);
+    // A launch of about one tile per CU is spread out (16 KB of LDS padding: one workgroup per CU): left alone the dispatcher
+    // pairs tiles up on some CUs, where two share one MFMA pipe, and the launch lasts as long as the slower pairs.  ms/step at
+    // N = 4096 without -> with: B = 9 5.51 -> 5.09, 10 4.90 -> 4.51, 12 5.45 -> 5.14, 14 6.09 -> 5.87, 16 6.59 -> 6.51, 20 (330
+    // tiles per launch) 8.01 -> 8.04, 24 (396) 9.19 -> 9.39, 32 (528) 11.6 -> 12.3; B <= 8 unchanged: up to 320 tiles
+    const unsigned pad = grid <= tunables().plain_spread ? 16 * 1024 : 0;
     if (g.o.src.K)
-        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(grid), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
+        hipLaunchKernelGGL(factor_step_kernel<true>, dim3(grid), dim3(256), pad, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
                            itri, B, g.o.src, g.o.Y ? g.o.red : nored);
     else
-        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(grid), dim3(256), 0, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
+        hipLaunchKernelGGL(factor_step_kernel<false>, dim3(grid), dim3(256), pad, g.s, g.A, g.Winv, g.o.Y, g.info, Np, k,
                            itri, B, g.o.src, g.o.Y ? g.o.red : nored);
     if (tm) tm->end(g.s);
     if (k + 1 == n && g.o.Y) {
