@@ -306,11 +306,9 @@ def main():
         if pws is not None:
             _lib.check(L_.volt_potrf_workspace_init_f32(pws_ptr, pws_bytes, B, Np, _lib.stream_ptr()), "potrf workspace init")
 
-        def potrf_once():
-            _lib.check(L_.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n,
-                                           _lib.stream_ptr()), "prepare")
-            _lib.check(L_.volt_potrf_ws_f32(A.data_ptr(), Winv.data_ptr(), inf.data_ptr(), B, Np, pws_ptr, pws_bytes,
-                                            _lib.stream_ptr()), "potrf")
+        def potrf_once():                                   # what ops.potrf calls: the factor of K + s2 I straight from K
+            _lib.check(L_.volt_potrf_k_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), Winv.data_ptr(),
+                                           inf.data_ptr(), B, n, pws_ptr, pws_bytes, _lib.stream_ptr()), "potrf")
 
         def fwd_once():
             _lib.check(L_.volt_mll_step_f32(K.data_ptr(), n, n * n, y.data_ptr(), s2.data_ptr(), 0.0, ws.out.data_ptr(),

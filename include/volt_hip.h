@@ -100,6 +100,12 @@ size_t volt_potrf_workspace_bytes(int B, int Np);
  * table-free schedules (3 .. 64 matrices: 2-25 % slower in the late block columns). */
 int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void* stream);
 int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream);
+/* volt_prepare_f32 + volt_potrf_ws_f32 in one: the factor of K + (sigma2 + jitter) I (K [B,N,N], row stride ldk, batch
+ * stride bsk, lower triangle read; sigma2 [B] or NULL) lands in A [B,Np,Np], Np = volt_padded_n(N), without a copy-in
+ * pass -- the tiles are read from K by the workgroups that update them (what torch.linalg.cholesky(K + s2 I) is to the
+ * reference: gpytorch's MLL, psd_safe_cholesky at rollout_utils.py:35).  ws as for volt_potrf_ws_f32 (may be NULL). */
+int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, float* Winv,
+                     int* info, int B, int N, void* ws, size_t ws_bytes, void* stream);
 
 /* fp64 twins on v_mfma_f64_16x16x4_f64 (the reference keeps the caller's dtype, VolKernel.py:28-33; the
  * noise-free train block of rollout_utils.py:35 has condition number 1e6 (N = 400) .. 1e8 (N = 4096), beyond

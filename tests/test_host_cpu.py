@@ -37,6 +37,8 @@ def test_argument_validation_without_a_device():
     assert L.volt_cumtrapz_f32(1, 8, 1, 0, 1, 1, 1, 1, None) == -7            # N < 2: x[1]-x[0] undefined
     assert L.volt_potrf_f32(1, 1, 1, 1, 100, None) == -5                      # Np not a multiple of 128
     assert L.volt_potrf_ws_f32(1, 1, 1, 1, 100, None, 0, None) == -5
+    assert L.volt_potrf_k_f32(None, 8, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, None) == -1
+    assert L.volt_potrf_k_f32(1, 4, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, None) == -2     # row stride shorter than N
     assert L.volt_potrf_workspace_bytes(65, 4096) == 0 and L.volt_potrf_workspace_bytes(1, 100) == 0
     assert L.volt_potrf_workspace_bytes(1, 128) == 0 and L.volt_potrf_workspace_bytes(4, 256) == 0   # nothing long enough to cut
     tables = ((33 * 8 * (1 + 4 * 33) + 16) * 16 + 255) // 256 * 256  # the balanced schedule's tables (+ a 16-slot header) live in caller scratch too

@@ -28,6 +28,7 @@ _SIGS = {
     "volt_potrf_workspace_bytes": (C.c_size_t, [_i32, _i32]),
     "volt_potrf_workspace_init_f32": (C.c_int, [_ptr, C.c_size_t, _i32, _i32, _ptr]),
     "volt_potrf_ws_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
+    "volt_potrf_k_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, C.c_float, _ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
     "volt_prepare_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, _f64, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),

@@ -3043,6 +3043,40 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
     return volt_potrf_ws_f32(A, Winv, info, B, Np, nullptr, 0, stream);
 }
 
+// Factor of K + (sigma2 + jitter) I straight from K: only block column 0 is copied, every other tile is read from K by
+// the workgroup that updates it (as the MLL step does) -- volt_prepare_f32's pass over the lower triangle (2.2 GB in,
+// 2.2 GB out and 0.82 ms for 64 x 4096^2: 7 % of the factorisation) disappears.
+int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, float* Winv,
+                     int* info, int B, int N, void* ws, size_t ws_bytes, void* stream) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!A) return -6;
+    if (!Winv) return -7;
+    if (!info) return -8;
+    if (B < 0 || B > 65535) return -9;
+    if (N < 1) return -10;
+    if (B == 0) return 0;
+    const int Np = volt_padded_n(N), n = Np / TS;
+    SplitK sk{nullptr, nullptr, 1, 1, 0, nullptr, 0};
+    const size_t need = volt_potrf_workspace_bytes(B, Np);
+    if (ws) {
+        if (((uintptr_t)ws & 255) != 0) return -11;
+        if (ws_bytes < need) return -12;
+        if (need) {
+            sk.slab = reinterpret_cast<float*>(ws);
+            sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
+            sk.cap = potrf_ws_rows(B);
+            sk.tab_bytes = volt_internal_sched_bytes(B, Np / TS);
+            sk.tab = sk.tab_bytes ? reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) +
+                                                            potrf_ws_count_bytes(B, Np)) : nullptr;
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prepare_kernel, dim3(n, B), dim3(256), 0, s, K, ldk, bsk, sigma2, jitter, A, N, Np, 1);
+    FactorOpts o{KSource{K, ldk, bsk, sigma2, jitter, N}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}, sk};
+    return run_factor_groups(A, Winv, info, B, Np, s, o);
+}
+
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream) {
     if (!A) return -1;
     if (!Winv) return -2;

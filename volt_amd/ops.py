@@ -136,14 +136,16 @@ def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0
         s2 = sigma2.to(K.dtype).expand(B).contiguous()
     L = _lib.lib()
     st = _lib.stream_ptr()
-    prep = L.volt_prepare_f32 if K.dtype == torch.float32 else L.volt_prepare_f64
-    _lib.check(prep(K.data_ptr(), K.stride(1), K.stride(0), s2.data_ptr() if s2 is not None else None,
-                    float(jitter), A.data_ptr(), B, n, st), "volt_prepare")
+    s2p = s2.data_ptr() if s2 is not None else None
     if K.dtype == torch.float32:
-        # scratch for the small-batch schedules (0 bytes above 64 matrices and below 3 block columns)
+        # straight from K (no copy-in pass); scratch for the small-batch schedules (0 bytes above 64 matrices and below
+        # 3 block columns)
         wp, nbytes = _potrf_workspace(B, Np, K.device)
-        _lib.check(L.volt_potrf_ws_f32(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, wp, nbytes, st), "volt_potrf")
+        _lib.check(L.volt_potrf_k_f32(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(),
+                                      Winv.data_ptr(), info.data_ptr(), B, n, wp, nbytes, st), "volt_potrf_k")
     else:
+        _lib.check(L.volt_prepare_f64(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(), B, n, st),
+                   "volt_prepare")
         _lib.check(L.volt_potrf_f64(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, st), "volt_potrf")
     return CholeskyFactor(A, Winv, info, n)
 
