@@ -331,8 +331,9 @@ def main():
             extra["ms_per_cholesky"] = round(res["chol"] / B, 4)
             extra["cholesky_tflops"] = round(B * Np ** 3 / 3 / (res["chol"] * 1e-3) / 1e12, 2)
             extra["ms_per_mll_forward"] = round(res["fwd"] / B, 4)
-        extra["cholesky_note"] = ("ms_per_cholesky = wall time of one batched factorisation of K + s2 I (copy-in + blocked "
-                                  "Cholesky, N^3/3 flop each) / 64; ms_per_mll_forward adds the forward solve and log-det")
+        extra["cholesky_note"] = ("ms_per_cholesky = wall time of one batched factorisation of K + s2 I (volt_potrf_k_f32: blocked "
+                                  "Cholesky reading K in place, N^3/3 flop each) / 64; ms_per_mll_forward adds the forward solve "
+                                  "and log-det")
         del A, Winv, f, pws
 
     # ---- rollouts leg (rank 0): BASELINE config 5's per-GPU share -- 8 series x 10,000 paths x 256 steps at this N
