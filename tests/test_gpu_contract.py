@@ -457,6 +457,37 @@ def test_mll_step_f64_vs_fp64_oracle(ops, B, n, tol, want_grad):
         assert np.abs(a - o["alpha"]).max() <= tol * 100 * np.abs(o["alpha"]).max()
 
 
+@pytest.mark.parametrize("B,n", [(2, 600), (8, 600), (1, 384)])
+def test_mll_step_f64_captured_in_a_graph(ops, B, n):
+    """The fp64 step forks onto the library's side streams (one- / two-column look-ahead of the factorisation, the rows of
+    the inverse and their own look-ahead): captured into a hipGraph every fork must be joined again, and the replay must
+    give the eager result -- 2 matrices run the one-column schedule with the inverse's look-ahead, 8 the two-column one,
+    3 block columns the shortest chain that still forks."""
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol.astype(np.float64)), dev(x.astype(np.float64)), square=True))
+    r = dev((y - mean).astype(np.float64))
+    s2 = torch.full((B,), 0.05, device="cuda", dtype=torch.float64)
+    ws = ops.MllWorkspace(B, n, True, "cuda", torch.float64)
+    out0, alpha0, info0 = ops.mll_step(K, r, s2, ws)
+    out0, alpha0 = out0.clone(), alpha0.clone()
+    assert int(info0.abs().sum()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.mll_step(K, r, s2, ws)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out, alpha, info = ops.mll_step(K, r, s2, ws)
+    for _ in range(3):
+        out.zero_()
+        alpha.zero_()
+        g.replay()
+    torch.cuda.synchronize()
+    assert int(info.abs().sum()) == 0
+    assert torch.allclose(out, out0, rtol=1e-12, atol=1e-14) and torch.allclose(alpha, alpha0, rtol=1e-9, atol=1e-12)
+
+
 def test_trtri_f64_vs_lapack(ops):
     B, n = 2, 700
     x, F, vol = sde_batch(B, n)

@@ -902,10 +902,11 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
     // Rows of the inverse beside the factorisation, themselves with a one-row look-ahead: call k (column k-1 is complete)
     // puts the last block + phase 2 of row k-1 on aux2 and the early part of row k -- it needs rows <= k-2 only -- on aux4
     hipEvent_t ev_p2[2] = {ax.ev[7], ax.ev[8]}, ev_p1a = ax.ev[9];
-    const bool tri_look = trtri64_lookahead(B);
+    // (not inside a graph capture: the fourth branch it adds crashed hipStreamEndCapture here; captured steps keep the plain rows)
+    const bool tri_look = trtri64_lookahead(B) && cap == hipStreamCaptureStatusNone;
     if (Y) {
         VOLT_TRY64(hipStreamWaitEvent(ax.aux2, ax.fork, 0));
-        VOLT_TRY64(hipStreamWaitEvent(ax.aux4, ax.fork, 0));
+        if (tri_look) VOLT_TRY64(hipStreamWaitEvent(ax.aux4, ax.fork, 0));   // (a forked stream must get work that is joined: captures)
         trtri64_begin(Y, B, Np, ax.aux2, tri_look);
     }
     auto tri_step = [&](int k) -> int {
@@ -932,7 +933,7 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
         //                             same block into the diagonal tile on the chain itself.
         // X, Y and Z of different steps may touch one tile at the same time: all three subtract with fp64 atomics.
         hipEvent_t ev_y = ax.ev[2], ev_z[2] = {ax.ev[3], ax.ev[5]};
-        VOLT_TRY64(hipStreamWaitEvent(ax.aux3, ax.fork, 0));
+        if (n >= 4) VOLT_TRY64(hipStreamWaitEvent(ax.aux3, ax.fork, 0));     // Z(1) exists from four block columns on
         for (int k = 0; k < n; ++k) {
             // the chain's waits first (they refer to what earlier iterations recorded)
             if (k >= 2) VOLT_TRY64(hipStreamWaitEvent(s, ev_y, 0));                 // Y(k-1): block k-2 is in column k
