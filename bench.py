@@ -441,7 +441,8 @@ def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):
     loss.backward(); optimizer.step()``, voltron/train_utils.py:243-254 -- for B series of length n, per iteration as
     the difference of two runs (t2 vs t1 iterations: construction and the one-off fill cancel).  eager = the loop with
     the factorisation's info check deferred (the default of the batched loop); eager_per_step_check = with the host
-    read-back every step, as a literal gpytorch loop does; graph = one captured iteration replayed."""
+    read-back every step, as a literal gpytorch loop does; graph = graph=True (one captured iteration replayed where the
+    step is launch-bound; at this size the loop declines the capture, see `captured`)."""
     from volt_amd.train_utils import TrainVoltMagpieBatch
     tx = torch.tensor(x, device=dev)
     prices = torch.tensor(F[:B, 1:], device=dev)
@@ -462,6 +463,12 @@ def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):
         b = min(run(t2, **kw) for _ in range(2))
         ms = (b - a) / (t2 - t1) * 1e3
         out[mode] = {"ms_per_step": round(ms, 3), "overhead_vs_raw_op": round(ms / raw_ms - 1.0, 4)}
+    from volt_amd.train_utils import _capture_pays
+    out["graph"]["captured"] = bool(_capture_pays(prices))
+    if not out["graph"]["captured"]:
+        out["graph"]["note"] = ("graph=True is honoured where a step is launch-bound (< 700 tiles per launch); a step that "
+                                "fills the chip runs eagerly with the deferred check (captured it took 25.9 ms: one stream "
+                                "group instead of two)")
     return out
 
 

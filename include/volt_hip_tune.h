@@ -10,6 +10,7 @@
  *   VOLT_SCHED_MINB / _MAXB / _MAXB_POTRF   batch range of the balanced schedule (3 / 31 / 64)
  *   VOLT_SCHED_G / _S / _FRAC / _GROUPS / _KMIN   its slots (256), slices per tile (4), cut threshold (0.6), groups (2),
  *                          first scheduled block column (by batch size)
+ *   VOLT_LONG_XCD          one long series: spines on one XCD, their slab hand-offs through its L2 (0; measured -1.7 %)
  *   VOLT_PLAIN_SPREAD / VOLT_SPLIT_SPREAD   plain / all-split launches of up to this many workgroups run one workgroup
  *                          per CU (320 / 700)
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,

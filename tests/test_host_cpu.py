@@ -317,3 +317,11 @@ def test_deferred_checks_keep_one_accumulator_per_shape():
         chk.immediate = True
         assert gp.deferred_checks.deferring() is None and gp.deferred_checks._active is chk
     assert gp.deferred_checks._active is None
+
+
+def test_graph_capture_is_declined_where_a_step_fills_the_chip():
+    """train_utils honours graph=True only for launch-bound steps (the library's one-group gate: < 700 tiles per launch)."""
+    import torch
+    from volt_amd.train_utils import _capture_pays
+    assert _capture_pays(torch.empty(1, 4096)) and _capture_pays(torch.empty(4096)) and _capture_pays(torch.empty(64, 399))
+    assert not _capture_pays(torch.empty(64, 4096)) and not _capture_pays(torch.empty(64, 2048))

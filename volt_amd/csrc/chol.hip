@@ -1392,7 +1392,7 @@ __device__ __forceinline__ void job_t0(const TriJob& jb, f32x16 (&T)[4]) {
 // left, and the result lands in the pivot image (lower triangle, zeros above) that diag_body works on.  MODE 2: a tile of
 // Y = L^-T (the same right-hand product against W_i): the slabs' products are kept in O for the reductions.
 struct NoOp { __device__ __forceinline__ void operator()() const {} };
-template <int MODE, class F = NoOp>
+template <int MODE, class F = NoOp, int AUXL = 16 /* AUX_SC1 */>
 __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __restrict__ Lkk, int Np,
                                                 const float* __restrict__ Wk, const int* slab, int want,
                                                 float* __restrict__ out, float* sL, f32x16 (&X)[4],
@@ -1439,7 +1439,7 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         la[m][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            lrs, (int)((((int64_t)(32 * j + l31)) * Np + 32 * m + 4 * lh) * 4), 32 * g, AUX_SC1));
+                            lrs, (int)((((int64_t)(32 * j + l31)) * Np + 32 * m + 4 * lh) * 4), 32 * g, AUXL));
                 }
             if (MODE == 1) {
                 __syncthreads();                                   // all four waves' rows of slab j-1 are in the tile
@@ -1466,7 +1466,7 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             xb[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                wrs, ((32 * j + l31) * TS + 32 * j + 4 * lh) * 4, 32 * g, AUX_SC1));
+                wrs, ((32 * j + l31) * TS + 32 * j + 4 * lh) * 4, 32 * g, AUXL));
         f32x16 O = zero16();
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -1894,6 +1894,7 @@ struct LongState {
     const int4* uinfo;                         // [n] {_, slabs, first slab, counter} of the look-ahead tile U(k)
     float* eslab;                              // [nslabs][128*128] partial accumulators of the early-part slices
     long long* stamps;
+    int xcd_from;                              // > 0: the spines S(g), g >= xcd_from, all run on XCD 0 (grid index % 8 == 0)
 };
 // acc += the nsl consecutive slabs at `slabs` (slab_dump's layout), read with sc1 loads: the slices wrote them through and
 // raised a counter, no fence on either side
@@ -1919,7 +1920,7 @@ __device__ __forceinline__ void slice_out(const f32x16 (&acc)[4], float* __restr
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256, 2) void long_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
+__global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                           float* __restrict__ Y, int* __restrict__ info, int Np,
                                                           KSource src, TriReduce red, LongState st, SmallTail tl) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
@@ -2071,8 +2072,14 @@ __global__ __launch_bounds__(256, 2) void long_step_kernel(float* __restrict__ A
                     }
                 };
                 load_c();
-                ok = substitute_tile<1>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
-                                        st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
+                // the slabs of diagonal block kd come from S(kd): when both spines run on XCD 0 (long_sched.h) its L2 has them --
+                // written through it a moment ago -- and plain loads spare the trip through the fabric that sc1 loads make
+                if (st.xcd_from > 0 && kd >= st.xcd_from)
+                    ok = substitute_tile<1, NoOp, 0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
+                                                     st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
+                else
+                    ok = substitute_tile<1>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
+                                            st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
                 if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
                 SMALL_STAMP(4);
                 diag_body<false, true>(A, Winv, info, Np, k, 0, smem, nullptr, true, wf + k, want, sf + 4 * k, lf + k * n + kd);
@@ -2156,6 +2163,7 @@ struct Tunables {
     float sched_frac = 0.6f;
     int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
     int plain_spread = 320, split_spread = 700;   // plain / all-split launches of up to this many workgroups run one workgroup per CU
+    int long_xcd = 0;                        // long series: spines on one XCD, their hand-offs through its L2 (long_sched.h)
     int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1, long_nmin = 7;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
@@ -2188,6 +2196,7 @@ static const Tunables& tunables() {
         geti("VOLT_LONG_EMIN", t.long_emin);
         geti("VOLT_LONG_PAD", t.long_pad);
         geti("VOLT_LONG_NMIN", t.long_nmin);
+        geti("VOLT_LONG_XCD", t.long_xcd);
         geti("VOLT_PLAIN_SPREAD", t.plain_spread);
         geti("VOLT_SPLIT_SPREAD", t.split_spread);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
@@ -2748,7 +2757,7 @@ int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const flo
 // ---- ONE long series in one launch (long_step_kernel, long_sched.h)
 struct LongPlanDev {
     int4* items = nullptr;                     // pinned host
-    int nitems = 0, nslabs = 0, ncnt = 0;
+    int nitems = 0, nslabs = 0, ncnt = 0, xcd_from = 0;
 };
 static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
     static std::mutex mu;
@@ -2760,12 +2769,13 @@ static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
     if (it != cache.end()) return it->second;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin);
+    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0);
     static_assert(sizeof(LongItem) == sizeof(int4), "items are read as int4");
     LongPlanDev* pd = new LongPlanDev;
     pd->nitems = (int)pl.items.size();
     pd->nslabs = pl.nslabs;
     pd->ncnt = pl.ncnt;
+    pd->xcd_from = pl.xcd_from;
     if (hipHostMalloc((void**)&pd->items, (pl.items.size() + n) * sizeof(int4), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         delete pd;
@@ -2791,7 +2801,7 @@ static void long_sizes(int n, size_t& items, int& nslabs, int& ncnt) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it == cache.end()) {
-        const LongPlan pl = long_build(n, tn.long_first, tn.long_emin);
+        const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0);
         it = cache.emplace(key, std::array<size_t, 3>{pl.items.size(), (size_t)pl.nslabs, (size_t)pl.ncnt}).first;
     }
     items = it->second[0];
@@ -2852,7 +2862,7 @@ int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const floa
     const TriReduce red{rpad, zpart, frob, N};
     const SmallTail tl{resid, rpad, z, apad, apart, sigma2, jitter, out, alpha, N};
     const int4* tab = reinterpret_cast<const int4*>(reinterpret_cast<char*>(state) + flag_bytes);
-    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps};
+    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps, pd->xcd_from};
     // one workgroup per CU (16 KB of LDS padding): a pivot chain that shares its CU runs 1.5 - 3x slower
     const unsigned pad = tunables().long_pad ? 16 * 1024 : 0;
     hipLaunchKernelGGL(long_step_kernel, dim3(pd->nitems), dim3(256), pad, s, A, Winv, Y, info, Np, src, red, st, tl);

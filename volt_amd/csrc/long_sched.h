@@ -40,9 +40,13 @@ struct LongPlan {
                                    // which P(k,k-2) contributes (its own tile times its transpose) the moment the tile is there
     int nslabs = 0;          // slab slots (128 x 128 floats each)
     int ncnt = 0;            // slice counters
+    int xcd_from = 0;        // > 0: D(0) and every spine S(g), g >= xcd_from, sit at a grid index that is a multiple of 8
 };
 
-inline LongPlan long_build(int n, int first, int emin) {
+// xcd_align: workgroup i runs on XCD i % 8, and a hand-off between workgroups of ONE XCD can be served by that XCD's L2
+// instead of a trip through the fabric.  The chain's hand-offs are spine to spine, so the spines are put at grid indices
+// that are multiples of 8: up to 7 tiles of row g-1 of the inverse (which do not depend on S(g)) go in front of S(g).
+inline LongPlan long_build(int n, int first, int emin, bool xcd_align = false) {
     LongPlan pl;
     struct Slice { LongItem it; int ready; };
     std::vector<Slice> slices;
@@ -102,11 +106,31 @@ inline LongPlan long_build(int n, int first, int emin) {
             pl.uinfo[k] = {k >= 3 ? 1 : 0, 0, pl.nslabs++, pl.ncnt++};      // {U(k) exists, -, P's slab, its counter}
         }
     }
+    int unaligned_last = 0;                                      // the last spine that could not be aligned
     for (int g = 0; g <= n; ++g) {
-        for (const LongItem& it : groups[g]) pl.items.push_back(it);
+        std::vector<LongItem>& G = groups[g];
+        size_t lead = 0;
+        const bool spine = g >= 1 && g < n;
+        if (xcd_align && spine) {
+            const size_t need = (8 - pl.items.size() % 8) % 8;
+            // fillers: T(g-1, j) pieces (kind LG_T), from the front of the row (the longest tiles)
+            std::vector<size_t> fill;
+            for (size_t q = 1; q < G.size() && fill.size() < need; ++q)
+                if ((G[q].kind_ij & 0xff) == LG_T) fill.push_back(q);
+            if (fill.size() == need) {
+                for (size_t q : fill) pl.items.push_back(G[q]);
+                for (size_t q = fill.size(); q-- > 0;) G.erase(G.begin() + (long)fill[q]);
+            } else {
+                unaligned_last = g;
+            }
+        }
+        (void)lead;
+        for (const LongItem& it : G) pl.items.push_back(it);
         for (const Slice& s : slices)
             if ((s.ready < 0 ? 0 : s.ready) == g) pl.items.push_back(s.it);
     }
+    pl.xcd_from = xcd_align ? unaligned_last + 1 : 0;
+    if (pl.xcd_from >= n) pl.xcd_from = 0;
     return pl;
 }
 
