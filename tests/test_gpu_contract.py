@@ -340,6 +340,27 @@ def test_potrf_with_scratch_small_and_late_column_schedules(ops, B, n):
                                 base + 4, need, _lib.stream_ptr()) == -11
 
 
+def test_potrf_from_a_strided_view_with_jitter(ops):
+    """volt_potrf_k_f32 reads K in place: a leading block of a larger matrix (row stride N + 37, as rollout_utils.py:27-35
+    slices its train block out of the joint covariance) plus sigma2 and a jitter gives the factor of the contiguous copy,
+    bitwise -- and the padding rows of the factor are the identity."""
+    B, n = 3, 700
+    x, vol, _, _ = _series_problem(B, n + 37)
+    big = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    view = big[:, :n, :n]
+    assert not view.is_contiguous()
+    s2 = torch.full((B,), SIG2, device="cuda")
+    f_view = ops.potrf(view, s2, jitter=1e-4)
+    f_copy = ops.potrf(view.contiguous(), s2, jitter=1e-4)
+    assert int(f_view.info.abs().sum()) == 0
+    assert torch.equal(f_view.L, f_copy.L)
+    ref = torch.linalg.cholesky(view[1].double() + (SIG2 + 1e-4) * torch.eye(n, device="cuda", dtype=torch.float64))
+    assert float((f_view.L[1].double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    Np = ops.padded_n(n)
+    pad = f_view.A[:, n:, n:]
+    assert torch.equal(torch.tril(pad), torch.eye(Np - n, device="cuda").expand(B, -1, -1))
+
+
 def test_diagonal_block_tuning_hook(ops):
     """volt_tune_diag_f32 runs the diagonal-block kernel alone on block column 0 with phase stamps: the stamps are
     monotone, and its L_00 / W_0 are bitwise the ones the factorisation produces (same device code)."""
