@@ -36,7 +36,7 @@ s = st.cpu().numpy().astype(np.float64)
 t0 = s[:, 0].min()
 us = (s - t0) / 100.0
 us[s == 0] = np.nan
-KINDS = ["D", "S", "P", "U", "T", "T", "eP", "eT", "eU"]
+KINDS = ["D", "S", "P", "U", "T", "T", "eP", "eT", "eU", "R"]
 
 
 def name_long(w):
@@ -44,9 +44,9 @@ def name_long(w):
     kind, a, bb = x & 255, (x >> 8) & 255, (x >> 16) & 255
     if kind == 0:
         return 0, "D(0)"
-    if kind in (1, 3):
+    if kind in (1, 3, 9):
         return 0, f"{KINDS[kind]}({a})" + (f"/{y}" if y else "")
-    if kind >= 6:
+    if 6 <= kind <= 8:
         return 0, f"{KINDS[kind]}({a},{bb})[{y & 255}:{(y >> 8) & 255}]"
     return 0, f"{KINDS[kind]}({a},{bb})" + (f"/{y}" if y else "")
 
@@ -79,5 +79,7 @@ for w in range(G):
     b, nm = name(w)
     if b in (0, B - 1) and (not LONG or nm[0] in os.environ.get("SHOW", "DS")):
         print(f"  series {b:3d} {nm:8s} " + " ".join("    -  " if np.isnan(v) else f"{v:7.1f}" for v in us[w, :6]))
+        if nm.startswith("R("):
+            print("             R: slabs seen " + " ".join(f"{v:6.1f}" for v in us[w, 6:10]))
         if nm.startswith("S("):
             print("             spine: flags seen " + " ".join(f"{v:6.1f}" for v in us[w, 6:10]) + "  solved %.1f  all there %.1f  rank32 %.1f  image %.1f  out %.1f" % tuple(us[w, 10:15]))

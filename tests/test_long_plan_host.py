@@ -7,7 +7,7 @@ import pytest
 
 from volt_amd import _lib
 
-D0, SPINE, PANEL, U, T, TDIAG, E_PANEL, E_T, E_U = range(9)
+D0, SPINE, PANEL, U, T, TDIAG, E_PANEL, E_T, E_U, R = range(10)
 
 
 def plan(n, first=4, emin=2):
@@ -39,7 +39,8 @@ def test_pieces_are_in_dependency_order(n, first):
                 return True
             return False
 
-        key = (kind if kind < E_PANEL else -kind, a, b, y if kind >= E_PANEL else 0)
+        is_slice = E_PANEL <= kind <= E_U
+        key = (kind if not is_slice else -kind, a, b, y if is_slice else 0)
         assert key not in seen, f"piece {q} twice"
         seen.add(key)
         if kind == D0:
@@ -54,7 +55,16 @@ def test_pieces_are_in_dependency_order(n, first):
             if k >= 3:
                 assert k in uf
             lf.add((k, kd))
-            wf.add(k)
+            split = q + 1 < len(items) and (items[q + 1][0] & 255) == R
+            if split:                                 # split spine: R(k), right behind it, owns the diagonal block
+                assert ((items[q + 1][0] >> 8) & 255) == k
+            else:
+                wf.add(k)
+        elif kind == R:
+            assert (a, a - 1) in lf and (q == 0 or (items[q - 1][0] & 255, (items[q - 1][0] >> 8) & 255) == (SPINE, a))
+            if a >= 3:
+                assert a in uf
+            wf.add(a)
         elif kind == PANEL:
             i, k = a, b
             if not early(k - 1) and k > 1:
@@ -100,7 +110,7 @@ def test_slices_grow_away_from_the_tile_and_spread_evenly():
     items, nslabs, ncnt = plan(32, 4)
     per_tile = {}
     for x, y, z, w in items.tolist():
-        if (x & 255) >= E_PANEL:
+        if E_PANEL <= (x & 255) <= E_U:
             per_tile.setdefault(w, []).append(((y >> 8) & 255) - (y & 255))
     for lens in per_tile.values():
         # in list (= readiness) order: a remainder first, then 4 * 2^i blocks falling to the 4 next to the tile

@@ -22,6 +22,7 @@ HEADERS = ["common.h", "sched.h", "long_sched.h", os.path.join("..", "..", "incl
            os.path.join("..", "..", "include", "volt_hip_tune.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function"]
+FLAGS += os.environ.get("VOLT_EXTRA_FLAGS", "").split()      # experiments (A/B builds of a -D switch); part of the source hash
 
 
 def _hipcc() -> str:

@@ -584,10 +584,23 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         }
     };
     int bad = 0;
+    // SLABS: the wave that handed slab c on (X_c and the L blocks below it, written through) raises slab[c] only once its
+    // stores have drained -- but it does not sit out that drain in front of the phase's barrier, where the pivot waves
+    // would wait for it too (2 - 3 us per phase when 250 other workgroups are streaming operands): it carries the slab
+    // number along and publishes at the start of its NEXT phase, in which it never is a pivot wave.
+    int pend = -1;
+    auto publish_pending = [&]() {
+        if (SLABS && pend >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_store(slab + pend, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pend = -1;
+        }
+    };
 #pragma unroll 1
     for (int kb = 0; kb <= 4; ++kb) {
         float a[32];                                     // wave 0: the factored rows of sub-block kb, phase A -> B
         f32x16 P = zero16();                             // kb = 4, waves 2, 3: partial sums of W's last block row, A4 -> T
+        publish_pending();
         // ---- phase A
         const int npw = kb > 3 ? 0 : (kb == 3 ? 1 : 3 - kb);               // pivot waves
         const int xw = kb == 1 ? 2 : (kb == 4 ? 0 : 1);                     // the wave that inverts sub-block kb - 1
@@ -618,8 +631,10 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, voff, 16 * q4, AUX_SC1);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(slab + c, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pend = c;                                                   // (published at the start of this wave's next phase)
+#ifdef VOLT_PUBLISH_NOW
+                publish_pending();
+#endif
             }
         } else if (kb == 0) {                                               // wave 3: the zero blocks of W above the diagonal
             if (SLABS && pre && lane == 0) {            // and the hand-on of the tile the caller finished before this block:
@@ -658,7 +673,8 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         __syncthreads();
         VOLT_STAMP(2 + 2 * kb);
         if (kb == 4) {
-            // ---- phase T: the last block row of W
+            // ---- phase T: the last block row of W (wave 0: the last slab's flag, behind its drain)
+            publish_pending();
             if (wave == 3) {
                 P = mm32_lds_lds(P, blk(3, 2), blk(0, 2));                                            // + L32 W20
                 w_out(wrs, 3, 0, nullptr, mm32_lds_reg(zero16(), blk(3, 3), P));                    // W30 = -X3 P
@@ -1396,12 +1412,16 @@ template <int MODE, class F = NoOp, int AUXL = 16 /* AUX_SC1 */>
 __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __restrict__ Lkk, int Np,
                                                 const float* __restrict__ Wk, const int* slab, int want,
                                                 float* __restrict__ out, float* sL, f32x16 (&X)[4],
-                                                long long* stamps = nullptr, F before_first_rank = F()) {
+                                                long long* stamps = nullptr, F before_first_rank = F(),
+                                                int* handon = nullptr) {
 #define SUB_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
     float* mine = sL + (wave * 32) * WLD;
     float* outw = out + (int64_t)(wave * 32) * Np;
+    // handon (MODE 0, the split spine): the tile goes out written THROUGH, and behind every slab each wave counts itself
+    // into handon[j] once its 32 rows of the slab are out -- the piece that takes the rank-32 updates reads them from there
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)outw, 0, 0x7fffffff, 0x00020000);
     bool ok = true;
     // X_j and the L_kk blocks were written through (sc1) ahead of their flag and are read with sc1 loads behind it: the
     // hand-off costs neither side an L2-wide write-back / invalidate (with 64 series in flight those were what the
@@ -1409,6 +1429,14 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)Wk, 0, TS * TS * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)Lkk, 0, 0x7fffffff, 0x00020000);
     // rank-32 update of the spine's accumulators with slab jj of the (whole) L tile
+    int hand_pend = -1;
+    auto hand_on = [&]() {
+        if (MODE == 0 && handon && hand_pend >= 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(handon + hand_pend, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hand_pend = -1;
+        }
+    };
     auto rank32 = [&](int jj) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1426,21 +1454,13 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
             }
         }
     };
+    f32x4 la[3][4];                                                // L_kk[j, m], m < j, for the slab after the one in hand
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // ---- between the flags: what the slabs already here owe slab j (their L_kk blocks came with THEIR flags), and
         // for the spine the rank-32 update of the slab before, whose MFMAs cover the latency of those loads
         if (j > 0) {
             if (MODE == 1 && j == 1) before_first_rank();          // (long series: the spine's accumulators are loaded as late as this)
-            f32x4 la[3][4];
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-                if (m < j) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        la[m][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            lrs, (int)((((int64_t)(32 * j + l31)) * Np + 32 * m + 4 * lh) * 4), 32 * g, AUXL));
-                }
             if (MODE == 1) {
                 __syncthreads();                                   // all four waves' rows of slab j-1 are in the tile
                 rank32(j - 1);
@@ -1458,6 +1478,7 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
                             T[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(la[m][g][e], lb[g][e], T[j], 0, 0, 0);
                 }
         }
+        hand_on();                                                 // (the previous slab's stores have had that long to drain)
         // ---- behind flag j: one product
         if (lane == 0) ok = wait_flag(slab + j, want, 2) && ok;
         asm volatile("" ::: "memory");                             // the loads below stay below the poll
@@ -1467,6 +1488,18 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
         for (int g = 0; g < 4; ++g)
             xb[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                 wrs, ((32 * j + l31) * TS + 32 * j + 4 * lh) * 4, 32 * g, AUXL));
+        // the rows of L_kk the NEXT slab's between-the-flags work reads came with this flag and the ones before it: asked
+        // for now, their trip is covered by this slab's product and stores
+        if (j < 3) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                if (m <= j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        la[m][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            lrs, (int)((((int64_t)(32 * (j + 1) + l31)) * Np + 32 * m + 4 * lh) * 4), 32 * g, AUXL));
+                }
+        }
         f32x16 O = zero16();
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -1476,11 +1509,16 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
         for (int q = 0; q < 16; ++q) {
             const int c = accrow(q, lane);
             mine[c * WLD + 32 * j + l31] = -O[q];
-            VOLT_OUT_STORE(outw + (int64_t)c * Np + 32 * j + l31, -O[q]);
+            if (MODE == 0 && handon)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-O[q]), ors, (int)(((int64_t)c * Np + 32 * j + l31) * 4), 0, AUX_SC1);
+            else
+                VOLT_OUT_STORE(outw + (int64_t)c * Np + 32 * j + l31, -O[q]);
         }
         if (MODE == 2) X[j] = O;
         wave_lds_fence();
+        if (MODE == 0 && handon) hand_pend = j;                    // counted in behind the NEXT slab's between-the-flags work
     }
+    hand_on();
     SUB_STAMP(10);
     if (MODE == 1) {
         __syncthreads();
@@ -1895,6 +1933,7 @@ struct LongState {
     float* eslab;                              // [nslabs][128*128] partial accumulators of the early-part slices
     long long* stamps;
     int xcd_from;                              // > 0: the spines S(g), g >= xcd_from, all run on XCD 0 (grid index % 8 == 0)
+    int split;                                 // the plan has R(g) pieces: S(g) hands its tile on slab by slab
 };
 // acc += the nsl consecutive slabs at `slabs` (slab_dump's layout), read with sc1 loads: the slices wrote them through and
 // raised a counter, no fence on either side
@@ -1920,6 +1959,27 @@ __device__ __forceinline__ void slice_out(const f32x16 (&acc)[4], float* __restr
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// rank-32 update of the diagonal tile's accumulators with columns [32 jj, 32 jj + 32) of the L tile in LDS (row stride WLD)
+__device__ __forceinline__ void rank32_update(f32x16 (&X)[4], const float* sL, int jj) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int ko = 32 * jj + 8 * g + 4 * lh;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sL + (wr * 64 + l31) * WLD + ko);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sL + (wc * 64 + l31) * WLD + ko);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sL + (wc * 64 + 32 + l31) * WLD + ko);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(sL + (wr * 64 + 32 + l31) * WLD + ko);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            X[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[m], X[0], 0, 0, 0);
+            X[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b1[m], X[1], 0, 0, 0);
+            X[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b0[m], X[2], 0, 0, 0);
+            X[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[m], X[3], 0, 0, 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                           float* __restrict__ Y, int* __restrict__ info, int Np,
                                                           KSource src, TriReduce red, LongState st, SmallTail tl) {
@@ -1933,7 +1993,7 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
     const int want = __hip_atomic_load(st.hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     const int4 item = st.items[blockIdx.x];
     const int pk = item.x & 255, pa = (item.x >> 8) & 255, pb = (item.x >> 16) & 255;
-    const bool isE = pk >= LG_E_PANEL;
+    const bool isE = pk >= LG_E_PANEL && pk <= LG_E_U;
     const int nslices = isE ? 0 : item.y;                           // base pieces: slices their early part came in
     const float* eslabs = st.eslab + (int64_t)item.z * TS * TS;
     int* ser = st.ser;
@@ -1943,7 +2003,8 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
     int* lf = wf + n;
     int* yf = lf + n * n;
     int* uf = yf + n * n;
-    int* ecnt = uf + n;
+    int* hf = uf + n;                                              // [n][4] waves of S(k) whose rows of slab j of L[k,k-1] are out (4 per step)
+    int* ecnt = hf + 4 * n;
     int* info_b = info;
     float* Ab = A;
     SMALL_STAMP(0);
@@ -2008,6 +2069,57 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
                     }
             small_publish(uf + kk, want);
         }
+    } else if (pk == LG_R) {
+        // ---- the second half of a split spine: -A[k,k] (parked by U(k)) into the accumulators, the rank-32 update behind
+        // every slab of L[k,k-1] that S(k) hands on, the pivot image, diagonal block k
+        const int k = pa;
+        f32x16 X[4];
+        {
+            const int4 ui = st.uinfo[k];                           // {U(k) exists, -, P(k,k-2)'s slab, its counter}
+            if (ui.x) small_wait(uf + k, nullptr, want, info_b);
+            spine_load_c(A, Np, k, 0, src, X, !ui.x);
+            if (k == 2) {
+                if (tid == 0 && !wait_flag_backoff(ecnt + ui.w, want)) atomicCAS(info_b, 0, (int)0x80000000);
+                __syncthreads();
+                slab_add_sc1(X, st.eslab + (int64_t)ui.z * TS * TS, 1);
+            }
+        }
+        SMALL_STAMP(1);
+        const float* Lt = Ab + (int64_t)k * TS * Np + (int64_t)(k - 1) * TS;
+        const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)Lt, 0, 0x7fffffff, 0x00020000);
+        float* sL = smem;
+        const int row = tid >> 1, half = tid & 1;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            if (tid == 0 && !wait_flag(hf + 4 * k + j, 4 * want, 2)) atomicCAS(info_b, 0, (int)0x80000000);
+            __syncthreads();
+            if (st.stamps && tid == 0) st.stamps[(int64_t)blockIdx.x * 16 + 6 + j] = __builtin_amdgcn_s_memrealtime();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    lrs, (int)(((int64_t)row * Np + 32 * j + 16 * half + 4 * g) * 4), 0, AUX_SC1));
+                *reinterpret_cast<f32x4*>(sL + row * WLD + 32 * j + 16 * half + 4 * g) = v;
+            }
+            __syncthreads();
+            rank32_update(X, sL, j);
+        }
+        __syncthreads();                                           // the image overlays the L tile
+        {
+            const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int r = wr * 64 + tm * 32 + accrow(q, lane);
+                        const int c = wc * 64 + tn * 32 + l31;
+                        sL[r * DT + c] = (c <= r) ? -X[tm * 2 + tn][q] : 0.f;
+                    }
+        }
+        SMALL_STAMP(3);
+        diag_body<false, true>(A, Winv, info, Np, k, 0, smem, nullptr, true, wf + k, want, sf + 4 * k);
+        SMALL_STAMP(4);
     } else if (pk == LG_TDIAG) {
         small_wait(wf + pa, nullptr, want, info_b);
         small_diag_tile(Winv, Y, Np, pa, 0, red, tl, rowc + pa, want, info_b, smem);
@@ -2055,7 +2167,16 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
             const float* Lkk = Ab + (int64_t)kd * TS * Np + (int64_t)kd * TS;
             const float* Wk = Winv + (int64_t)kd * TS * TS;
             bool ok;
-            if (pk == LG_SPINE) {
+            if (pk == LG_SPINE && st.split) {
+                // split spine: the tile by substitution, handed on slab by slab to R(k); its flag goes up here
+                ok = substitute_tile<0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
+                                        st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr, NoOp(), hf + 4 * pa);
+                if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
+                // every word of the tile went out written through and has been waited for (hand_on): the flag needs no
+                // release fence -- an L2-wide write-back that would sit on the chain
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(lf + pa * n + kd, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (pk == LG_SPINE) {
                 const int k = pa;
                 // -A[k,k] (its look-ahead part, parked by U(k) -- whose last block is only a block column old) comes into the
                 // accumulators right before the first rank-32 update, not before the first slab
@@ -2163,6 +2284,7 @@ struct Tunables {
     float sched_frac = 0.6f;
     int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
     int plain_spread = 320, split_spread = 700;   // plain / all-split launches of up to this many workgroups run one workgroup per CU
+    int long_split = 1;                      // long series: the spine split in two workgroups (substitution | rank-32 updates + diagonal block)
     int long_xcd = 0;                        // long series: spines on one XCD, their hand-offs through its L2 (long_sched.h)
     int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1, long_nmin = 7;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
@@ -2197,6 +2319,7 @@ static const Tunables& tunables() {
         geti("VOLT_LONG_PAD", t.long_pad);
         geti("VOLT_LONG_NMIN", t.long_nmin);
         geti("VOLT_LONG_XCD", t.long_xcd);
+        geti("VOLT_LONG_SPLIT", t.long_split);
         geti("VOLT_PLAIN_SPREAD", t.plain_spread);
         geti("VOLT_SPLIT_SPREAD", t.split_spread);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
@@ -2769,7 +2892,7 @@ static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
     if (it != cache.end()) return it->second;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0);
+    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0, tn.long_split != 0);
     static_assert(sizeof(LongItem) == sizeof(int4), "items are read as int4");
     LongPlanDev* pd = new LongPlanDev;
     pd->nitems = (int)pl.items.size();
@@ -2791,7 +2914,7 @@ static bool long_applies(int B, int n) {
     const Tunables& tn = tunables();
     return tn.long_on && B == 1 && n > tn.long_nmin && n <= 32;     // (one series of 8 block columns: 0.289 ms here, 0.307 as a short series)
 }
-static size_t long_flag_ints(int n, int ncnt) { return (size_t)SMALL_HDR + (size_t)((4 + 7 * n + 2 * n * n + ncnt + 31) & ~31); }
+static size_t long_flag_ints(int n, int ncnt) { return (size_t)SMALL_HDR + (size_t)((4 + 11 * n + 2 * n * n + ncnt + 31) & ~31); }
 // sizes of the plan for n block columns (the workspace layout asks for them on every step: computed once)
 static void long_sizes(int n, size_t& items, int& nslabs, int& ncnt) {
     static std::mutex mu;
@@ -2801,7 +2924,7 @@ static void long_sizes(int n, size_t& items, int& nslabs, int& ncnt) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it == cache.end()) {
-        const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0);
+        const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0, tn.long_split != 0);
         it = cache.emplace(key, std::array<size_t, 3>{pl.items.size(), (size_t)pl.nslabs, (size_t)pl.ncnt}).first;
     }
     items = it->second[0];
@@ -2862,7 +2985,7 @@ int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const floa
     const TriReduce red{rpad, zpart, frob, N};
     const SmallTail tl{resid, rpad, z, apad, apart, sigma2, jitter, out, alpha, N};
     const int4* tab = reinterpret_cast<const int4*>(reinterpret_cast<char*>(state) + flag_bytes);
-    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps, pd->xcd_from};
+    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps, pd->xcd_from, tunables().long_split};
     // one workgroup per CU (16 KB of LDS padding): a pivot chain that shares its CU runs 1.5 - 3x slower
     const unsigned pad = tunables().long_pad ? 16 * 1024 : 0;
     hipLaunchKernelGGL(long_step_kernel, dim3(pd->nitems), dim3(256), pad, s, A, Winv, Y, info, Np, src, red, st, tl);
@@ -2967,7 +3090,7 @@ int volt_long_describe(int n, int first, int emin, int* items, int max_items, in
     if (n < 1 || n > 32) return -1;
     if (first < 1) return -2;
     if (emin < 0) return -3;
-    const LongPlan pl = long_build(n, first, emin);
+    const LongPlan pl = long_build(n, first, emin, tunables().long_xcd != 0, tunables().long_split != 0);
     if (nslabs) *nslabs = pl.nslabs;
     if (ncnt) *ncnt = pl.ncnt;
     if (items)

@@ -25,7 +25,8 @@
 
 namespace volt {
 
-enum LongKind { LG_D0 = 0, LG_SPINE = 1, LG_PANEL = 2, LG_U = 3, LG_T = 4, LG_TDIAG = 5, LG_E_PANEL = 6, LG_E_T = 7, LG_E_U = 8 };
+enum LongKind { LG_D0 = 0, LG_SPINE = 1, LG_PANEL = 2, LG_U = 3, LG_T = 4, LG_TDIAG = 5, LG_E_PANEL = 6, LG_E_T = 7, LG_E_U = 8,
+                LG_R = 9 };   // R(g): the second half of a split spine (rank-32 updates of the diagonal tile + diagonal block g)
 
 struct LongItem {            // 16 bytes, read as one int4 on the device
     int kind_ij;             // kind | a << 8 | b << 16:  D/S/U: a = k;  P, E_PANEL: a = tile row, b = diagonal block above;  T, E_T: a = i, b = j
@@ -46,7 +47,9 @@ struct LongPlan {
 // xcd_align: workgroup i runs on XCD i % 8, and a hand-off between workgroups of ONE XCD can be served by that XCD's L2
 // instead of a trip through the fabric.  The chain's hand-offs are spine to spine, so the spines are put at grid indices
 // that are multiples of 8: up to 7 tiles of row g-1 of the inverse (which do not depend on S(g)) go in front of S(g).
-inline LongPlan long_build(int n, int first, int emin, bool xcd_align = false) {
+// split_spine: S(g) only solves its tile (g,g-1) by substitution and hands its 32-column slabs on; R(g), right behind it in
+// the list and on another CU, takes the rank-32 updates of the diagonal tile and diagonal block g.
+inline LongPlan long_build(int n, int first, int emin, bool xcd_align = false, bool split_spine = false) {
     LongPlan pl;
     struct Slice { LongItem it; int ready; };
     std::vector<Slice> slices;
@@ -79,6 +82,7 @@ inline LongPlan long_build(int n, int first, int emin, bool xcd_align = false) {
             LongItem it = cut(LG_E_PANEL, g, g - 1, g - 2, [](int b1) { return b1 - 1; });
             it.kind_ij = pack(LG_SPINE, g, 0);
             G.push_back(it);
+            if (split_spine) G.push_back({pack(LG_R, g, 0), 0, 0, -1});
         }
         for (int i = g + 2; i < n; ++i) {   // P(i,g): K blocks 0 .. g-1, early part g-1 blocks
             LongItem it = cut(LG_E_PANEL, i, g, g - 1, [](int b1) { return b1 - 1; });
