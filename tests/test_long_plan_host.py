@@ -19,9 +19,10 @@ def plan(n, first=4, emin=2):
     return items, int(ns[0]), int(nc[0])
 
 
-@pytest.mark.parametrize("n,first", [(9, 4), (12, 4), (16, 3), (32, 4), (32, 2), (20, 6)])
-def test_pieces_are_in_dependency_order(n, first):
-    items, nslabs, ncnt = plan(n, first)
+@pytest.mark.parametrize("n,first,emin", [(9, 4, 2), (12, 4, 2), (16, 3, 2), (32, 4, 2), (32, 2, 2), (20, 6, 2),
+                                          (3, 3, 1), (4, 3, 1), (5, 3, 1), (8, 3, 1), (24, 3, 1), (32, 4, 1), (32, 4, 0)])
+def test_pieces_are_in_dependency_order(n, first, emin):
+    items, nslabs, ncnt = plan(n, first, emin)
     lf, yf, wf, uf = set(), set(), set(), set()      # tiles of L stored, tiles of Y stored, diagonal blocks done, look-ahead tiles parked
     cnt = {}                                          # slices delivered per counter
     ranges = {}                                       # counter -> list of (b0, b1)

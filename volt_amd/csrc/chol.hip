@@ -584,23 +584,10 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         }
     };
     int bad = 0;
-    // SLABS: the wave that handed slab c on (X_c and the L blocks below it, written through) raises slab[c] only once its
-    // stores have drained -- but it does not sit out that drain in front of the phase's barrier, where the pivot waves
-    // would wait for it too (2 - 3 us per phase when 250 other workgroups are streaming operands): it carries the slab
-    // number along and publishes at the start of its NEXT phase, in which it never is a pivot wave.
-    int pend = -1;
-    auto publish_pending = [&]() {
-        if (SLABS && pend >= 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_store(slab + pend, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pend = -1;
-        }
-    };
 #pragma unroll 1
     for (int kb = 0; kb <= 4; ++kb) {
         float a[32];                                     // wave 0: the factored rows of sub-block kb, phase A -> B
         f32x16 P = zero16();                             // kb = 4, waves 2, 3: partial sums of W's last block row, A4 -> T
-        publish_pending();
         // ---- phase A
         const int npw = kb > 3 ? 0 : (kb == 3 ? 1 : 3 - kb);               // pivot waves
         const int xw = kb == 1 ? 2 : (kb == 4 ? 0 : 1);                     // the wave that inverts sub-block kb - 1
@@ -631,10 +618,10 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, voff, 16 * q4, AUX_SC1);
                     }
                 }
-                pend = c;                                                   // (published at the start of this wave's next phase)
-#ifdef VOLT_PUBLISH_NOW
-                publish_pending();
-#endif
+                // (deferring this drain + flag to the wave's next phase, out of the way of the phase's barrier, was measured:
+                // 0.5 - 1 % slower at every size from 1 x 399 to 1 x 4096)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(slab + c, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else if (kb == 0) {                                               // wave 3: the zero blocks of W above the diagonal
             if (SLABS && pre && lane == 0) {            // and the hand-on of the tile the caller finished before this block:
@@ -673,8 +660,7 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
         __syncthreads();
         VOLT_STAMP(2 + 2 * kb);
         if (kb == 4) {
-            // ---- phase T: the last block row of W (wave 0: the last slab's flag, behind its drain)
-            publish_pending();
+            // ---- phase T: the last block row of W
             if (wave == 3) {
                 P = mm32_lds_lds(P, blk(3, 2), blk(0, 2));                                            // + L32 W20
                 w_out(wrs, 3, 0, nullptr, mm32_lds_reg(zero16(), blk(3, 3), P));                    // W30 = -X3 P
@@ -2286,7 +2272,7 @@ struct Tunables {
     int plain_spread = 320, split_spread = 700;   // plain / all-split launches of up to this many workgroups run one workgroup per CU
     int long_split = 1;                      // long series: the spine split in two workgroups (substitution | rank-32 updates + diagonal block)
     int long_xcd = 0;                        // long series: spines on one XCD, their hand-offs through its L2 (long_sched.h)
-    int long_on = 1, long_first = 4, long_emin = 2, long_pad = 1, long_nmin = 7;   // one long series in one launch: on/off, last slice's blocks, shortest sliced early part, a CU per workgroup
+    int long_on = 1, long_first = 0, long_emin = 1, long_pad = 1, long_nmin = 2;   // one long series in one launch: on/off, last slice's blocks (0: 3 up to 24 block columns, 4 above), shortest sliced early part, a CU per workgroup, block columns above which it takes one series
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
 };
@@ -2882,17 +2868,24 @@ struct LongPlanDev {
     int4* items = nullptr;                     // pinned host
     int nitems = 0, nslabs = 0, ncnt = 0, xcd_from = 0;
 };
+// blocks in the slice next to the tile (measured with the split spine, 1 x 1500 ... 1 x 4096: 3 wins up to 24 block columns
+// -- 1 x 2048 0.538 -> 0.527 ms --, 4 at 32 -- 1.235 -> 1.175)
+static int long_first_for(int n) {
+    const int f = tunables().long_first;
+    return f > 0 ? f : (n <= 24 ? 3 : 4);
+}
 static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
     static std::mutex mu;
     static std::map<std::array<int, 3>, LongPlanDev*> cache;
     const Tunables& tn = tunables();
-    const std::array<int, 3> key{n, tn.long_first, tn.long_emin};
+    const int first = long_first_for(n);
+    const std::array<int, 3> key{n, first, tn.long_emin};
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
-    const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0, tn.long_split != 0);
+    const LongPlan pl = long_build(n, first, tn.long_emin, tn.long_xcd != 0, tn.long_split != 0);
     static_assert(sizeof(LongItem) == sizeof(int4), "items are read as int4");
     LongPlanDev* pd = new LongPlanDev;
     pd->nitems = (int)pl.items.size();
@@ -2912,7 +2905,7 @@ static const LongPlanDev* get_long_plan(int n, hipStream_t s) {
 }
 static bool long_applies(int B, int n) {
     const Tunables& tn = tunables();
-    return tn.long_on && B == 1 && n > tn.long_nmin && n <= 32;     // (one series of 8 block columns: 0.289 ms here, 0.307 as a short series)
+    return tn.long_on && B == 1 && n > tn.long_nmin && n <= 32;     // (one series of 4 / 5 / 8 block columns: 0.133 / 0.168 / 0.257 ms here, 0.139 / 0.180 / 0.289 as a short series)
 }
 static size_t long_flag_ints(int n, int ncnt) { return (size_t)SMALL_HDR + (size_t)((4 + 11 * n + 2 * n * n + ncnt + 31) & ~31); }
 // sizes of the plan for n block columns (the workspace layout asks for them on every step: computed once)
@@ -2920,11 +2913,12 @@ static void long_sizes(int n, size_t& items, int& nslabs, int& ncnt) {
     static std::mutex mu;
     static std::map<std::array<int, 3>, std::array<size_t, 3>> cache;
     const Tunables& tn = tunables();
-    const std::array<int, 3> key{n, tn.long_first, tn.long_emin};
+    const int first = long_first_for(n);
+    const std::array<int, 3> key{n, first, tn.long_emin};
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it == cache.end()) {
-        const LongPlan pl = long_build(n, tn.long_first, tn.long_emin, tn.long_xcd != 0, tn.long_split != 0);
+        const LongPlan pl = long_build(n, first, tn.long_emin, tn.long_xcd != 0, tn.long_split != 0);
         it = cache.emplace(key, std::array<size_t, 3>{pl.items.size(), (size_t)pl.nslabs, (size_t)pl.ncnt}).first;
     }
     items = it->second[0];
