@@ -74,7 +74,8 @@ int volt_tune_small_stamps(long long* stamps);
 
 /* Host only: the piece list of the one-launch step for ONE LONG series of n block columns (csrc/long_sched.h): early
  * parts longer than `emin` K blocks cut into slices that grow geometrically away from the tile, the last one `first`
- * blocks.  items: up to max_items records of 4 ints {kind | a << 8 | b << 16, slices or b0 | b1 << 8, slab slot, slice
+ * blocks (first = 0 / emin = -1: the values the step itself uses; with the spine split -- the default -- S(g) is followed
+ * by R(g), kind 9, which owns diagonal block g).  items: up to max_items records of 4 ints {kind | a << 8 | b << 16, slices or b0 | b1 << 8, slab slot, slice
  * counter}; nslabs / ncnt (optional): slab slots and slice counters.  Returns the number of pieces (= workgroups). */
 int volt_long_describe(int n, int first, int emin, int* items, int max_items, int* nslabs, int* ncnt);
 

@@ -20,7 +20,7 @@ nb = ops.padded_n(n) // 128
 L = _lib.lib()
 LONG = nb > 8                      # one long series: the piece list comes from the library (csrc/long_sched.h)
 if LONG:
-    first, emin = int(os.environ.get("VOLT_LONG_FIRST", 4)), int(os.environ.get("VOLT_LONG_EMIN", 2))
+    first, emin = int(os.environ.get("VOLT_LONG_FIRST", 0)), int(os.environ.get("VOLT_LONG_EMIN", -1))
     npieces = L.volt_long_describe(nb, first, emin, None, 0, None, None)
     items = np.zeros((npieces, 4), dtype=np.int32)
     L.volt_long_describe(nb, first, emin, items.ctypes.data, npieces, None, None)

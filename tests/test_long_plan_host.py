@@ -20,7 +20,7 @@ def plan(n, first=4, emin=2):
 
 
 @pytest.mark.parametrize("n,first,emin", [(9, 4, 2), (12, 4, 2), (16, 3, 2), (32, 4, 2), (32, 2, 2), (20, 6, 2),
-                                          (3, 3, 1), (4, 3, 1), (5, 3, 1), (8, 3, 1), (24, 3, 1), (32, 4, 1), (32, 4, 0)])
+                                          (3, 3, 1), (4, 3, 1), (5, 3, 1), (8, 3, 1), (24, 3, 1), (32, 4, 1), (32, 4, 0), (3, 0, -1), (8, 0, -1), (24, 0, -1), (32, 0, -1)])
 def test_pieces_are_in_dependency_order(n, first, emin):
     items, nslabs, ncnt = plan(n, first, emin)
     lf, yf, wf, uf = set(), set(), set(), set()      # tiles of L stored, tiles of Y stored, diagonal blocks done, look-ahead tiles parked

@@ -3082,8 +3082,10 @@ int volt_sched_describe(int B, int n, int has_y, int k, int G, int S, float frac
 
 int volt_long_describe(int n, int first, int emin, int* items, int max_items, int* nslabs, int* ncnt) {
     if (n < 1 || n > 32) return -1;
-    if (first < 1) return -2;
-    if (emin < 0) return -3;
+    if (first < 0) return -2;
+    if (emin < -1) return -3;
+    if (first == 0) first = long_first_for(n);                      // 0 / -1: what the step itself uses
+    if (emin == -1) emin = tunables().long_emin;
     const LongPlan pl = long_build(n, first, emin, tunables().long_xcd != 0, tunables().long_split != 0);
     if (nslabs) *nslabs = pl.nslabs;
     if (ncnt) *ncnt = pl.ncnt;
