@@ -1,6 +1,16 @@
-# sweep of the one-launch long step's tunables with the split spine (run on the GPU box)
+# sweep of the one-launch long step's tunables (run on the GPU box);  with arguments: same-box A/B of a -D switch, e.g.
+# scripts/ab_split.sh -DVOLT_SOMETHING
 export TMPDIR=/tmp
 python -m volt_amd.build > /dev/null 2>&1
-VOLT_LONG_OWN=1 python -m pytest tests/test_gpu_contract.py -m gpu -x -q -k "short_series_run_as_one_launch" 2>&1 | tail -2
-for own in 0 1 2; do for sp in 1 2; do echo "== VOLT_LONG_OWN=$own VOLT_LONG_SPLIT=$sp"; VOLT_LONG_OWN=$own VOLT_LONG_SPLIT=$sp SHAPES=1x1023,1x2048,1x4096 python scripts/bench_small_step.py 2>&1 | grep "B="; done; done
-VOLT_LONG_OWN=1 SHOW=DSR python scripts/small_stamps.py 1 4096 2>&1 | grep -A3 "S(2[0-2])"
+S=${SHAPES:-1x2048,1x3000,1x4096}
+if [ $# -gt 0 ]; then
+  for r in 1 2; do echo "== default build"; SHAPES=$S python scripts/bench_small_step.py 2>&1 | grep "B="; done
+  export VOLT_EXTRA_FLAGS="$@"
+  python -m volt_amd.build > /dev/null 2>&1
+  for r in 1 2; do echo "== $VOLT_EXTRA_FLAGS"; SHAPES=$S python scripts/bench_small_step.py 2>&1 | grep "B="; done
+  python -m pytest tests/test_gpu_contract.py -m gpu -x -q -k "short_series_run_as_one_launch" 2>&1 | tail -2
+else
+  echo "== defaults"; SHAPES=$S python scripts/bench_small_step.py 2>&1 | grep "B="
+  for f in 3 4 5; do for e in 1 2; do echo "== FIRST=$f EMIN=$e"; VOLT_LONG_FIRST=$f VOLT_LONG_EMIN=$e SHAPES=$S python scripts/bench_small_step.py 2>&1 | grep "B="; done; done
+  echo "== XCD=1"; VOLT_LONG_XCD=1 SHAPES=$S python scripts/bench_small_step.py 2>&1 | grep "B="
+fi
