@@ -10,7 +10,14 @@
  *   VOLT_SCHED_MINB / _MAXB / _MAXB_POTRF   batch range of the balanced schedule (3 / 31 / 64)
  *   VOLT_SCHED_G / _S / _FRAC / _GROUPS / _KMIN   its slots (256), slices per tile (4), cut threshold (0.6), groups (2),
  *                          first scheduled block column (by batch size)
- *   VOLT_LONG_XCD          one long series: spines on one XCD, their slab hand-offs through its L2 (0; measured -1.7 %)
+ *   VOLT_LONG / _NMIN / _FIRST / _EMIN / _PAD   ONE series as one launch: on (1), block columns above which it
+ *                          takes a series (2), blocks in the slice next to the tile (0 = 3 up to 24 block columns, 4 above),
+ *                          shortest sliced early part (> 1 block), one workgroup per CU (1)
+ *   VOLT_LONG_SPLIT        its spine as two workgroups: S(g) solves tile (g,g-1) and hands its slabs on, R(g) takes the
+ *                          rank-32 updates of the diagonal tile and diagonal block g (1; 0: one workgroup, +4 .. 13 %)
+ *   VOLT_LONG_XCD          one long series: spines on one XCD, their slab hand-offs through its L2 (0; measured -1.7 %
+ *                          with the one-workgroup spine, within noise with the split one)
+ *   VOLT_EXTRA_FLAGS       (build time, volt_amd/build.py) extra hipcc flags for same-box A/B builds: scripts/ab_split.sh
  *   VOLT_PLAIN_SPREAD / VOLT_SPLIT_SPREAD   plain / all-split launches of up to this many workgroups run one workgroup
  *                          per CU (320 / 700)
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
