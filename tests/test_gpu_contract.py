@@ -576,7 +576,7 @@ def test_workspace_tables_are_optional_and_checked(ops):
 
 
 @pytest.mark.parametrize("B,n", [(1, 399), (3, 100), (8, 399), (64, 399), (5, 257), (16, 512), (130, 300), (1, 1023), (8, 640),
-                                 (3, 900), (12, 1024), (1, 1500), (1, 2048), (1, 4096)])
+                                 (3, 900), (12, 1024), (1, 1500), (1, 2048), (1, 4096), (1, 300), (1, 600), (1, 3000), (1, 3700)])
 def test_short_series_run_as_one_launch(ops, B, n):
     """Up to four block columns (N <= 512, the reference's ntrain = 400: experiments/stocks/ForecastGenerator.py:53-91)
     the whole gradient step is ONE launch (small_step_kernel: step-numbered flags between the pieces, the tiles below a
@@ -645,6 +645,27 @@ def test_short_series_state_is_checked_and_failures_reported(ops):
     assert ws.info.tolist() == [0, 0, 201, 0]
     keep = [0, 1, 3]
     assert torch.equal(out[keep], out1[keep])
+    assert torch.equal(ops.mll_step(K, r, s2, ws)[0], out1) and int(ws.info.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n,bad", [(399, 300), (1500, 0), (1500, 127), (1500, 700), (4096, 4095)])
+def test_one_long_series_reports_its_first_failed_pivot(ops, n, bad):
+    """ONE series goes through long_step_kernel from 3 block columns on, with the spine split in two workgroups (S(g) solves
+    tile (g,g-1), R(g) runs diagonal block g): a failed pivot in D(0), in an R piece or in the very last block is reported
+    as info = index + 1 like the launch-per-column path does, nothing hangs behind it, and the same workspace gives the
+    good matrix's bits again afterwards."""
+    B = 1
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    r = dev(y - mean)
+    s2 = torch.full((B,), SIG2, device="cuda")
+    ws = ops.MllWorkspace(B, n, True, K.device)
+    out1 = ops.mll_step(K, r, s2, ws)[0].clone()
+    assert int(ws.info.abs().sum()) == 0
+    Kbad = K.clone()
+    Kbad[0, bad, bad] = -1.0
+    ops.mll_step(Kbad, r, s2, ws)
+    assert ws.info.tolist() == [bad + 1]
     assert torch.equal(ops.mll_step(K, r, s2, ws)[0], out1) and int(ws.info.abs().sum()) == 0
 
 
