@@ -1393,6 +1393,35 @@ __device__ __forceinline__ void job_t0(const TriJob& jb, f32x16 (&T)[4]) {
 // the rank-32 update L'_j L'_j^T in that pipeline's K order, so that after the last slab only a quarter of the product is
 // left, and the result lands in the pivot image (lower triangle, zeros above) that diag_body works on.  MODE 2: a tile of
 // Y = L^-T (the same right-hand product against W_i): the slabs' products are kept in O for the reductions.
+// The four slab flags of a diagonal block sit in one aligned 16-byte word and go up in order: ONE load tells how many of
+// them are up, so a tile that arrives late polls once, not once per slab (every poll is a round trip on the chain).
+// Lane 0: returns how many leading flags equal `want` once that is more than j; -1 on a time-out.
+__device__ __forceinline__ int wait_slab_flags(const int* slab, int j, int want) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, 16, 0x00020000);
+    auto count = [&]() {
+        asm volatile("" ::: "memory");
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, 0, 0, AUX_SC1);
+        int c = 0;
+        if ((int)v[0] == want) {
+            c = 1;
+            if ((int)v[1] == want) {
+                c = 2;
+                if ((int)v[2] == want) c = (int)v[3] == want ? 4 : 3;
+            }
+        }
+        return c;
+    };
+    int c = count();
+    if (c > j) return c;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while ((c = count()) <= j) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return -1;
+    }
+    return c;
+}
+
 struct NoOp { __device__ __forceinline__ void operator()() const {} };
 template <int MODE, class F = NoOp, int AUXL = 16 /* AUX_SC1 */>
 __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __restrict__ Lkk, int Np,
@@ -1441,6 +1470,8 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
         }
     };
     f32x4 la[3][4];                                                // L_kk[j, m], m < j, for the slab after the one in hand
+    int nready = 0;
+    const bool vec_flags = (reinterpret_cast<uintptr_t>(slab) & 15) == 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // ---- between the flags: what the slabs already here owe slab j (their L_kk blocks came with THEIR flags), and
@@ -1466,7 +1497,17 @@ __device__ __forceinline__ bool substitute_tile(f32x16 (&T)[4], const float* __r
         }
         hand_on();                                                 // (the previous slab's stores have had that long to drain)
         // ---- behind flag j: one product
-        if (lane == 0) ok = wait_flag(slab + j, want, 2) && ok;
+        if (j >= nready) {                                         // (wave-uniform: flags 0 .. nready-1 have been seen up)
+            if (vec_flags) {
+                int c = 0;
+                if (lane == 0) c = wait_slab_flags(slab, j, want);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c < 0) { ok = false; c = 4; }
+                nready = c;
+            } else if (lane == 0) {
+                ok = wait_flag(slab + j, want, 2) && ok;
+            }
+        }
         asm volatile("" ::: "memory");                             // the loads below stay below the poll
         SUB_STAMP(6 + j);
         f32x4 xb[4];
