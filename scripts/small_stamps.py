@@ -18,7 +18,8 @@ for _ in range(10):
     ops.mll_step(K, r, s2, ws)
 nb = ops.padded_n(n) // 128
 L = _lib.lib()
-LONG = nb > 8                      # one long series: the piece list comes from the library (csrc/long_sched.h)
+# ONE series of more than VOLT_LONG_NMIN (2) block columns runs long_step_kernel: the piece list comes from the library (csrc/long_sched.h)
+LONG = B == 1 and nb > int(os.environ.get("VOLT_LONG_NMIN", 2)) and nb <= 32 and os.environ.get("VOLT_LONG", "1") != "0"
 if LONG:
     first, emin = int(os.environ.get("VOLT_LONG_FIRST", 0)), int(os.environ.get("VOLT_LONG_EMIN", -1))
     npieces = L.volt_long_describe(nb, first, emin, None, 0, None, None)
