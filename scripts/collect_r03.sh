@@ -52,7 +52,11 @@ small)
   # one long series: the one-launch step with sliced early parts against the launch-per-column path
   (SHAPES=1x1100,1x1500,1x2048,1x3000,1x4096 python scripts/bench_small_step.py; SHAPES=1x1100,1x1500,1x2048,1x3000,1x4096 VOLT_LONG=0 python scripts/bench_small_step.py per-column) 2>&1 | grep -v amdgpu.ids | tee $OUT/long_step_table.txt
   SHOW=DSR python scripts/small_stamps.py 1 4096 2>&1 | grep -v amdgpu.ids > $OUT/long_step_stamps.txt
+  cd /tmp
+  SHAPES=1x4096 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/long -o long -- python $R/scripts/bench_small_step.py > $OUT/long_trace.log 2>&1
+  cd $R
+  cp $(find $OUT/long -name "*kernel_stats.csv" | head -1) $OUT/long_step_kernel_stats.csv
   head -4 $OUT/small_step_kernel_stats.csv;;
 esac; done
-rm -rf $OUT/t1 $OUT/t2 $OUT/roll $OUT/f64 $OUT/small
+rm -rf $OUT/t1 $OUT/t2 $OUT/roll $OUT/f64 $OUT/small $OUT/long
 ls -la $OUT
