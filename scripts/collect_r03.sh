@@ -43,7 +43,7 @@ tables)
 small)
   # the one-launch step for short series against the launch-per-column path (VOLT_SMALL_NMAX=0), the per-piece stamps of
   # one step at the reference's own size, and rocprofv3's view of the launch
-  (python scripts/bench_small_step.py; VOLT_SMALL_NMAX=0 python scripts/bench_small_step.py) 2>&1 | grep -v amdgpu.ids | tee $OUT/small_step_table.txt
+  (python scripts/bench_small_step.py; VOLT_SMALL_NMAX=0 VOLT_LONG=0 python scripts/bench_small_step.py per-column) 2>&1 | grep -v amdgpu.ids | tee $OUT/small_step_table.txt
   (SHOW=DSRPUT python scripts/small_stamps.py 1 399; python scripts/small_stamps.py 8 399) 2>&1 | grep -v amdgpu.ids > $OUT/small_step_stamps.txt
   cd /tmp
   SHAPES=1x399,8x399,32x399 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small -o small -- python $R/scripts/bench_small_step.py > $OUT/small_trace.log 2>&1
