@@ -46,7 +46,7 @@ for c in range(cases):
         a32 = torch.cholesky_solve(torch.tensor(y[b] - mean[b], device="cuda").float().unsqueeze(-1), torch.linalg.cholesky(Kb.float())).squeeze(-1).double().cpu().numpy()
         ea_ven = float(np.abs(a32 - ref["alpha"]).max() / np.abs(ref["alpha"]).max())
         worst["alpha_vs_vendor"] = max(worst.get("alpha_vs_vendor", 0.0), float(np.abs(a[b] - ref["alpha"]).max() / np.abs(ref["alpha"]).max()) / max(ea_ven, 1e-6))
-    print(f"case {c}: N={n} B={B} ok   fwd-vs-grad mll rel {fd.max():.1e} (series {int(fd.argmax())}, raw {raw[int(fd.argmax())]:.2f}, mll {o[int(fd.argmax()), 0]:.4f})", flush=True)
+    print(f"case {c}: N={n} B={B} ok   worst so far potrf x{worst['potrf']:.2f} alpha x{worst['alpha_vs_vendor']:.2f} (vendor alpha err {ea_ven:.1e}, raw {raw[b]:.2f})   fwd-vs-grad mll rel {fd.max():.1e} (series {int(fd.argmax())}, raw {raw[int(fd.argmax())]:.2f}, mll {o[int(fd.argmax()), 0]:.4f})", flush=True)
 print("cases", cases, "worst", worst)
 # potrf / alpha_vs_vendor: error relative to the vendor fp32 factorisation's error on the same matrix.  Reported, not
 # gated: panels are solved by multiplication with the inverted diagonal block ("accuracy against conditioning"),

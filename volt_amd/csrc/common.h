@@ -171,6 +171,59 @@ __device__ __forceinline__ void frag_mma(const Frag<WL>& f, f32x16 (&acc)[4]) {
     for (int m = 0; m < 4; ++m) frag_mma_m<WL>(f, m, acc);
 }
 
+// ---- two-level summation (round 4) ------------------------------------------------------------------------------
+// A left-looking tile sums K = 128 k products per element.  As ONE fp32 chain that starts at -A (what rounds 1-3 did)
+// every one of those K roundings happens at the magnitude of A, and the factor came out 5 - 30 x further from the fp64
+// factor than the vendor's blocked right-looking potrf (scripts/acc_diag.py: the ratio grows with the block column),
+// whose trailing update rounds at that magnitude once per block step.  The fp32 MFMA itself is an exact chain of RNE
+// FMAs (scripts/ubench/mfma_round.hip), so the remedy is the order of summation: the products of SEG_CHUNKS chunks (128
+// of K) are summed from ZERO in a second accumulator set -- the first MFMAs of a segment take the constant 0 as C -- and
+// the segment is then added to the running sum (64 v_add per thread and segment).
+#ifndef VOLT_SEG_CHUNKS
+#define VOLT_SEG_CHUNKS 4
+#endif
+#ifndef VOLT_SEG_TRI
+#define VOLT_SEG_TRI 1
+#endif
+#ifndef VOLT_SEG_SQ
+#define VOLT_SEG_SQ 1
+#endif
+constexpr int SEG_CHUNKS = VOLT_SEG_CHUNKS;
+__device__ __forceinline__ f32x16 zero16c() {
+    f32x16 z;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) z[q] = 0.f;
+    return z;
+}
+// K sub-step 0 of a fragment set into accumulators that start from zero
+template <int WL>
+__device__ __forceinline__ void frag_mma_m0_zero(const Frag<WL>& f, f32x16 (&acc)[4]) {
+    const f32x16 z = zero16c();
+    if constexpr (WL == 0) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], f.b0[0], z, 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], f.b1[0], z, 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], f.b0[0], z, 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], f.b1[0], z, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][0], f.b0[0], z, 0, 0, 0);
+    }
+}
+template <int WL, bool FIRST>
+__device__ __forceinline__ void frag_mma_seg(const Frag<WL>& f, f32x16 (&acc)[4]) {
+    if constexpr (FIRST) {
+        frag_mma_m0_zero<WL>(f, acc);
+#pragma unroll
+        for (int m = 1; m < 4; ++m) frag_mma_m<WL>(f, m, acc);
+    } else {
+        frag_mma<WL>(f, acc);
+    }
+}
+__device__ __forceinline__ void seg_flush(f32x16 (&T)[4], const f32x16 (&P)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T[i] += P[i];
+}
+
 #define VOLT_SB() __builtin_amdgcn_sched_barrier(0)
 
 // piece p (of 4) of a staging action: one row group of A and of B
@@ -190,7 +243,7 @@ __device__ __forceinline__ void stage_load_piece(StageRegs& s, const StageAddr& 
 // before its first use): each step's fragment reads are issued a full step (16 MFMAs = 1024 cycles) ahead, and the
 // staging traffic -- LDS write of chunk c+1 behind step 1 (`st`, if do_st), global loads of chunk c+3 behind step 2
 // (`ld`, if do_ld) -- goes out two instructions at a time between groups of four MFMAs.
-template <int WL, bool STEADY>
+template <int WL, bool STEADY, bool FIRST = false>
 __device__ __forceinline__ void chunk_run(const float* cur, float* nxt, bool more_, Frag<WL>& F0, Frag<WL>& F1,
                                          f32x16 (&acc)[4], StageRegs& s, bool do_st_, bool do_ld_, const StageAddr& sa,
                                          int k_ld) {
@@ -198,7 +251,7 @@ __device__ __forceinline__ void chunk_run(const float* cur, float* nxt, bool mor
     const bool more = STEADY || more_, do_st = STEADY || do_st_, do_ld = STEADY || do_ld_;
     frag_load<WL>(F1, cur, 1);
     VOLT_SB();
-    frag_mma<WL>(F0, acc);
+    frag_mma_seg<WL, FIRST>(F0, acc);
     VOLT_SB();
     frag_load<WL>(F0, cur, 2);
     VOLT_SB();
@@ -239,18 +292,44 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
     frag_load<WL>(F0, smem, 0);
     float* b0 = smem;
     float* b1 = smem + STAGE_FLOATS;
+    f32x16 P[4];                                // the segment's products, summed from zero (two-level summation, above)
     int c = 0;
+#if VOLT_SEG_SQ
+    for (; c + SEG_CHUNKS + 4 <= nchunks; c += SEG_CHUNKS) {   // steady state: every load / store / next-chunk read exists
+        chunk_run<WL, true, true>(b0, b1, true, F0, F1, P, s0, true, true, sa, (c + 3) * BK);
+        chunk_run<WL, true>(b1, b0, true, F0, F1, P, s1, true, true, sa, (c + 4) * BK);
+#pragma unroll
+        for (int u = 2; u < SEG_CHUNKS; u += 2) {
+            chunk_run<WL, true>(b0, b1, true, F0, F1, P, s0, true, true, sa, (c + u + 3) * BK);
+            chunk_run<WL, true>(b1, b0, true, F0, F1, P, s1, true, true, sa, (c + u + 4) * BK);
+        }
+        seg_flush(acc, P);
+    }
+    for (; c < nchunks; c += SEG_CHUNKS) {      // the last segment (and any chunk count that is not a multiple of it)
+        // chunk c (b0): write chunk c+1 (s0) into b1, request chunk c+3 into s0
+        chunk_run<WL, false, true>(b0, b1, c + 1 < nchunks, F0, F1, P, s0, c + 1 < nchunks, c + 3 < nchunks, sa, (c + 3) * BK);
+        // chunk c+1 (b1): write chunk c+2 (s1) into b0, request chunk c+4 into s1
+        if (c + 1 < nchunks)
+            chunk_run<WL, false>(b1, b0, c + 2 < nchunks, F0, F1, P, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
+        for (int u = 2; u < SEG_CHUNKS && c + u < nchunks; u += 2) {
+            chunk_run<WL, false>(b0, b1, c + u + 1 < nchunks, F0, F1, P, s0, c + u + 1 < nchunks, c + u + 3 < nchunks, sa, (c + u + 3) * BK);
+            if (c + u + 1 < nchunks)
+                chunk_run<WL, false>(b1, b0, c + u + 2 < nchunks, F0, F1, P, s1, c + u + 2 < nchunks, c + u + 4 < nchunks, sa, (c + u + 4) * BK);
+        }
+        seg_flush(acc, P);
+    }
+#else
+    (void)P;
     for (; c + 4 < nchunks; c += 2) {           // steady state: every load / store / next-chunk read exists
         chunk_run<WL, true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
         chunk_run<WL, true>(b1, b0, true, F0, F1, acc, s1, true, true, sa, (c + 4) * BK);
     }
     for (; c + 1 < nchunks; c += 2) {           // the last <= 4 chunks
-        // chunk c (b0): write chunk c+1 (s0) into b1, request chunk c+3 into s0
         chunk_run<WL, false>(b0, b1, true, F0, F1, acc, s0, true, c + 3 < nchunks, sa, (c + 3) * BK);
-        // chunk c+1 (b1): write chunk c+2 (s1) into b0, request chunk c+4 into s1
         chunk_run<WL, false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
     }
     if (c < nchunks) chunk_run<WL, false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
+#endif
     __syncthreads();                           // smem is free for reuse on return
 }
 
@@ -287,8 +366,10 @@ struct TriSrc {
     int n1, nall;
 };
 
+// PH1: the chunk is known (at compile time) to be a phase-1 chunk -- the steady state; otherwise decided at run time
+template <bool PH1 = false>
 __device__ __forceinline__ void tri_load_piece(StageRegs& s, const TriSrc& ts, int c, int p) {
-    if (c < ts.n1) {
+    if (PH1 || c < ts.n1) {
         const int sa = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pa);
         const int sb = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pb);
         s.a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.ra, ts.va, sa, 0));
@@ -298,29 +379,30 @@ __device__ __forceinline__ void tri_load_piece(StageRegs& s, const TriSrc& ts, i
         s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rw, ts.vw, so, 0));
     }
 }
+template <bool PH1 = false>
 __device__ __forceinline__ void tri_store_piece(const StageRegs& s, float* __restrict__ buf, const TriSrc& ts, int c, int p) {
     const int t = threadIdx.x;
     const int row = t >> 3, cq = (t & 7) * 4;
-    if (c < ts.n1) *reinterpret_cast<f32x4*>(buf + (row + 32 * p) * SLD + cq) = s.a[p];
+    if (PH1 || c < ts.n1) *reinterpret_cast<f32x4*>(buf + (row + 32 * p) * SLD + cq) = s.a[p];
     *reinterpret_cast<f32x4*>(buf + TS * SLD + (row + 32 * p) * SLD + cq) = s.b[p];
 }
 
 // phase-1 chunk `c` living in `cur`: stores chunk c+1 (from `s`) into `nxt`, requests chunk c+3 into `s`
-template <bool STEADY>
+template <bool STEADY, bool FIRST = false>
 __device__ __forceinline__ void tri_chunk_p1(const float* cur, float* nxt, int c, Frag<1>& F0, Frag<1>& F1,
                                              f32x16 (&T)[4], StageRegs& s, const TriSrc& ts) {
     const bool more = STEADY || (c + 1 < ts.n1);               // is the next chunk a phase-1 chunk (Frag<1> reads)?
     const bool do_st = STEADY || (c + 1 < ts.nall), do_ld = STEADY || (c + 3 < ts.nall);
     frag_load<1>(F1, cur, 1);
     VOLT_SB();
-    frag_mma<1>(F0, T);
+    frag_mma_seg<1, FIRST>(F0, T);
     VOLT_SB();
     frag_load<1>(F0, cur, 2);
     VOLT_SB();
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         frag_mma_m<1>(F1, m, T);
-        if (do_st) tri_store_piece(s, nxt, ts, c + 1, m);
+        if (do_st) tri_store_piece<STEADY>(s, nxt, ts, c + 1, m);
         VOLT_SB();
     }
     frag_load<1>(F1, cur, 3);
@@ -328,7 +410,7 @@ __device__ __forceinline__ void tri_chunk_p1(const float* cur, float* nxt, int c
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         frag_mma_m<1>(F0, m, T);
-        if (do_ld) tri_load_piece(s, ts, c + 3, m);
+        if (do_ld) tri_load_piece<STEADY>(s, ts, c + 3, m);
         VOLT_SB();
     }
     __syncthreads();
@@ -443,7 +525,6 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     ts.pb = (int)(32 * t.ldz * 4);
     ts.n1 = t.n1;
     ts.nall = t.n1 + 4;
-    zero_acc(O);
     bool ok = true;
     if (t.flag && t.n1 == 0) {                       // no phase 1 to hide behind: W is the first thing needed
         ok = flag_wait_one_lane(t.flag, t.want);
@@ -463,8 +544,30 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     __syncthreads();
     int c = 0;
     if (t.n1 > 0) {
+        // two-level summation (see SEG_CHUNKS): O, idle until phase 2, takes the products of one segment (4 chunks = 128
+        // of K) from zero; the segment is then added to T.  n1 is a multiple of 4.
         Frag<1> F0, F1;
         frag_load<1>(F0, b0, 0);
+#if VOLT_SEG_TRI
+        for (; c + SEG_CHUNKS + 4 <= t.n1; c += SEG_CHUNKS) {     // steady state: phase-1 chunks whose prefetches are phase-1 too
+            tri_chunk_p1<true, true>(b0, b1, c, F0, F1, O, s0, ts);
+            tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, O, s1, ts);
+#pragma unroll
+            for (int u = 2; u < SEG_CHUNKS; u += 2) {
+                tri_chunk_p1<true>(b0, b1, c + u, F0, F1, O, s0, ts);
+                tri_chunk_p1<true>(b1, b0, c + u + 1, F0, F1, O, s1, ts);
+            }
+            seg_flush(T, O);
+        }
+        for (; c < t.n1; c += 4) {                   // last chunks of phase 1: the W chunks come into view
+            if (t.flag && c == t.n1 - 4) ok = flag_wait_one_lane(t.flag, t.want);   // barriers below order the acquire
+            tri_chunk_p1<false, true>(b0, b1, c, F0, F1, O, s0, ts);
+            tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, O, s1, ts);
+            tri_chunk_p1<false>(b0, b1, c + 2, F0, F1, O, s0, ts);
+            tri_chunk_p1<false>(b1, b0, c + 3, F0, F1, O, s1, ts);
+            seg_flush(T, O);
+        }
+#else
         for (; c + 4 < t.n1; c += 2) {               // steady state: phase-1 chunks whose prefetches are phase-1 too
             tri_chunk_p1<true>(b0, b1, c, F0, F1, T, s0, ts);
             tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
@@ -474,7 +577,9 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
             tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
             tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
         }
+#endif
     }
+    zero_acc(O);
     // phase 2: chunks n1 .. n1+3 (n1 is even: chunk n1 sits in buffer 0)
     tri_chunk_p2<0>(b0, b1, T, O, s0, ts);
     tri_chunk_p2<1>(b1, b0, T, O, s1, ts);
@@ -516,6 +621,26 @@ __device__ __forceinline__ void tri_phase1_only(const TriTile& t, f32x16 (&T)[4]
     Frag<1> F0, F1;
     frag_load<1>(F0, b0, 0);
     int c = 0;
+#if VOLT_SEG_TRI
+    f32x16 P[4];                                     // two-level summation (see SEG_CHUNKS)
+    for (; c + SEG_CHUNKS + 4 <= t.n1; c += SEG_CHUNKS) {
+        tri_chunk_p1<true, true>(b0, b1, c, F0, F1, P, s0, ts);
+        tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, P, s1, ts);
+#pragma unroll
+        for (int u = 2; u < SEG_CHUNKS; u += 2) {
+            tri_chunk_p1<true>(b0, b1, c + u, F0, F1, P, s0, ts);
+            tri_chunk_p1<true>(b1, b0, c + u + 1, F0, F1, P, s1, ts);
+        }
+        seg_flush(T, P);
+    }
+    for (; c < t.n1; c += 4) {
+        tri_chunk_p1<false, true>(b0, b1, c, F0, F1, P, s0, ts);
+        tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, P, s1, ts);
+        tri_chunk_p1<false>(b0, b1, c + 2, F0, F1, P, s0, ts);
+        tri_chunk_p1<false>(b1, b0, c + 3, F0, F1, P, s1, ts);
+        seg_flush(T, P);
+    }
+#else
     for (; c + 4 < t.n1; c += 2) {
         tri_chunk_p1<true>(b0, b1, c, F0, F1, T, s0, ts);
         tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
@@ -524,6 +649,7 @@ __device__ __forceinline__ void tri_phase1_only(const TriTile& t, f32x16 (&T)[4]
         tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
         tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
     }
+#endif
     __syncthreads();                                 // smem is free for reuse on return
 }
 
