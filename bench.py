@@ -94,6 +94,10 @@ def main():
     ap.add_argument("--n", "--series-len", dest="n", type=int, default=N_SERIES)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE shapes)")
+    ap.add_argument("--with-rollouts", action="store_true", help="run the rollout leg even under --no-aux-legs")
+    ap.add_argument("--rollout-samples", type=int, default=10000)
+    ap.add_argument("--rollout-horizon", type=int, default=256)
     ap.add_argument("--no-aux-legs", action="store_true",
                     help="skip the ms/Cholesky and forward-only legs (used for the rocprofv3 summaries in profiles/, so "
                          "that every factor_step_kernel<true> launch in the trace is a gradient-step launch)")
@@ -164,12 +168,14 @@ def main():
     fill_ms = float(np.median(fills))
     fill_gbs = Bmax * n * n * 4 / (fill_ms * 1e-3) / 1e9
 
-    def make_step(Bs):
-        """The training-loop body over this rank's first Bs series (K resident)."""
-        Ks, ys = K_all[:Bs], y_all[:Bs]
+    def make_step(Bs, Ks=None, ys=None, n_=None):
+        """The training-loop body over Bs series (K resident): this rank's first Bs series of the headline shape, or the
+        given (Ks, ys) of another shape (the `configs` block) -- the SAME body either way."""
+        if Ks is None:
+            Ks, ys, n_ = K_all[:Bs], y_all[:Bs], n
         raw = torch.full((Bs,), 1e-5, device=dev, requires_grad=True)    # train_utils.py:222
         opt_ = torch.optim.Adam([raw], lr=0.1)                             # train_utils.py:236-238
-        ws_ = ops.MllWorkspace(Bs, n, True, dev)
+        ws_ = ops.MllWorkspace(Bs, n_, True, dev)
         red_ = torch.zeros(2, device=dev)
 
         def step():
@@ -336,10 +342,22 @@ def main():
                                   "and log-det")
         del A, Winv, f, pws
 
-    # ---- rollouts leg (rank 0): BASELINE config 5's per-GPU share -- 8 series x 10,000 paths x 256 steps at this N
+    # ---- rollouts leg: BASELINE config 5 (64 series x 10,000 paths x 256 steps over 8 GPUs).  N = 1: its per-GPU share,
+    # 8 series.  N > 1: EVERY rank rolls out its 64 / N series (series shard first), the job's rate is the
+    # series of all ranks / the slowest rank, and the final gather of the [S, H] samples -- the one place xGMI bandwidth
+    # is exercised -- is timed on its own.
     roll = None
-    if rank == 0 and not args.no_rollouts and not args.no_aux_legs:
-        roll = rollout_leg(x, F, vol, dev, n)
+    if not args.no_rollouts and (args.with_rollouts or not args.no_aux_legs):
+        G_roll = 8 if world == 1 else max(1, min(Bmax, 64 // world))
+        roll = rollout_leg(x, F, vol, dev, n, G=G_roll, S=args.rollout_samples, H=args.rollout_horizon,
+                           dist=dist, world=world, rank=rank)
+
+    # ---- the other BASELINE shapes (rank 0, N=1): same loop body, same timing loop as the headline
+    cfgs = None
+    if rank == 0 and world == 1 and not args.no_aux_legs and not args.no_configs:
+        del ws
+        cfgs = configs_leg(make_step, timed, dev, K_all, y_all, n, args.batch)
+        ws = ops.MllWorkspace(B, n, True, dev)
 
     # ---- API leg (rank 0, N=1): what a caller of the drop-in surface pays per iteration
     api = None
@@ -383,6 +401,7 @@ def main():
             "api_step": api,
             "fp64": f64,
             "rollouts": roll,
+            "configs": cfgs,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
@@ -472,19 +491,59 @@ def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):
     return out
 
 
-def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
-    """BASELINE config 5 (10k sample paths x 256-step horizon, 64 series over 8 GPUs) at its per-GPU share: 8 series.
+def configs_leg(make_step, timed, dev, K_all, y_all, n_head, batch_head, steps=50, warmup=5):
+    """Every BASELINE.json configuration beside the metric (and the reference's own default size), driver-run: the
+    training-loop body of the headline (EWMA mean -> softplus -> volt_mll_step_f32 -> chain rule -> Adam) through the same
+    timing loop, `steps` steps each.  frac = algorithmic 2 N^3 / 3 flop per series / ms_per_step / the fp32 MFMA peak."""
+    from volt_amd import ops
+    from volt_amd.synthetic import sde_batch
+    shapes = [("C2_1x4096", 1, 4096, "BASELINE config 2: one series, N=4096 (voltron/train_utils.py:243-254 trains exactly one)"),
+              ("C3_64x2048", 64, 2048, "BASELINE config 3: 64 tickers, N=2048"),
+              ("C4_share_32x4096", 32, 4096, "BASELINE config 4 (256 stations over 8 GPUs): the per-GPU share"),
+              ("B8_8x4096", 8, 4096, "the metric (64 x 4096) strong-scaled over 8 GPUs: the per-GPU share"),
+              ("B16_16x4096", 16, 4096, "the metric strong-scaled over 4 GPUs: the per-GPU share"),
+              ("ref_default_64x399", 64, 399, "the reference's default ntrain=400 (experiments/stocks/ForecastGenerator.py), 64 tickers")]
+    out = {}
+    for name, Bc, nc, what in shapes:
+        if nc == n_head and Bc <= K_all.shape[0]:
+            Ks, ys = K_all[:Bc], y_all[:Bc]
+        else:
+            x, F, vol = sde_batch(Bc, nc, seed=2019)
+            Ks = ops.fill(ops.cumtrapz(torch.tensor(vol, device=dev), torch.tensor(x, device=dev), square=True))
+            ys = torch.log(torch.tensor(F[:, 1:], device=dev))
+        step, _, ws_, _ = make_step(Bc, Ks, ys, nc)
+        dt, _, info = timed(step, warmup, steps)
+        ms = dt / steps * 1e3
+        tf = Bc * 2 * nc ** 3 / 3 / (ms * 1e-3) / 1e12
+        out[name] = {"what": what, "batch": Bc, "n": nc, "steps": steps, "ms_per_step": round(ms, 4), "tflops": round(tf, 2),
+                     "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "not_pd": int((info != 0).sum().item())}
+        del step, ws_, Ks, ys
+    return out
+
+
+# VALU issue model of the rollout kernel (round 4): the kernel is neither HBM- nor MFMA-bound -- one wave walks H
+# dependent steps of a path -- so its roofline is the rate at which the chip issues wave-instructions:
+# 256 CUs x 4 SIMDs x 1 VALU wave-instruction per 2 cycles (MI355X_MICROARCH.md, per-instruction cycle constants:
+# v_fma_f32 wave64 = 2 cycles throughput) at 2.4 GHz = 1.23e12 / s.  `achieved` counts the kernel's VALU wave-instructions from the PMC pass kept in profiles/r04/ (SQ_INSTS_VALU).
+VALU_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
+
+
+def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256, dist=None, world=1, rank=0):
+    """BASELINE config 5 (10k sample paths x 256-step horizon, 64 series over 8 GPUs).
     The engine as shipped: per-sample bordered factor extended by ONE entry per step (the volatility kernel's
-    cross-covariance prefix is step-invariant), train block through the closed form K^-1 u = e_last ("closed") or
-    through the reference's own route -- fp64 factorisation of the noise-free train block + two solves,
-    rollout_utils.py:35-36 ("factor": that work is inside its total).  Algorithmic HBM bytes of the kernel: pred_vol and
-    z read, samples written = 12 B per sample-step.  `resubstitute` = the same paths with every sample's triangular
-    system re-solved from its stored rows at every step, the round-2 engine: H^3/6 * 4 B per path that an append-only
-    w_s does not need -- reported as `redundant_bytes`, credited to nothing."""
+    cross-covariance prefix is step-invariant).  The train block enters through two scalars per series; `total_s` takes
+    them the way the REFERENCE does (rollout_utils.py:35-36: factor the noise-free train block -- here in fp64 on
+    volt_potrf_f64 -- and two solves: that work is inside the total); `closed_form` is the same run with K^-1 u = e_last
+    taken analytically (an identity of this kernel, SURVEY 4: reserved for testing, reported beside).  Algorithmic HBM
+    bytes of the kernel: pred_vol and z read, samples written = 12 B per sample-step.  `resubstitute` = the same paths
+    with every sample's triangular system re-solved from its stored rows at every step, the round-2 engine: H^3/6 * 4 B
+    per path that an append-only w_s does not need -- reported as `redundant_bytes`, credited to nothing.
+    world > 1: every rank runs its G series; rank 0 reports the job's aggregate and the timed gather."""
     from volt_amd import rollout_engine as re_
+    from volt_amd import distributed as vd
     from volt_amd.synthetic import rollout_inputs
     G = min(G, F.shape[0])
-    pv, z = rollout_inputs(vol[:G, -1], S, H, seed=3)
+    pv, z = rollout_inputs(vol[:G, -1], S, H, seed=3 + rank)
     tx = torch.tensor(x, device=dev)
     test_x = torch.arange(H, device=dev) / 252. + tx[-1] + tx[1]
     logy = torch.log(torch.tensor(F[:G, 1:], device=dev))
@@ -495,6 +554,8 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
         best_total, best_kernel, info = None, None, None
         for rep in range(3):
             tm = {}
+            if dist is not None:
+                dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             samples, info = re_.rollout_series(tx, logy, lv, test_x, pvd, zd, 0, EWMA_K, timing=tm, **kw)
@@ -509,28 +570,79 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256):
     tot_c, ker_c, bad_c, smp_c = run(solve="closed")
     tot_f, ker_f, bad_f, smp_f = run(solve="factor")
     dev_cf = float((smp_c - smp_f).abs().max().item())
+    multi = None
+    if dist is not None:
+        # the job: every rank's series / the slowest rank; then the gather of the samples every rank holds
+        tt = torch.tensor([tot_f, tot_c, float(bad_f)], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        gathers = []
+        for rep in range(3):
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            parts = vd.gather_samples(smp_f)
+            torch.cuda.synchronize()
+            gathers.append(time.perf_counter() - t0)
+        gt = torch.tensor([min(gathers[1:])], device=dev, dtype=torch.float64)
+        allg = [torch.zeros_like(gt) for _ in range(world)]
+        dist.all_gather(allg, gt)
+        nbytes = sum(int(p_.numel()) * 4 for p_ in parts)
+        slow_f = max(float(t[0]) for t in allt)
+        slow_c = max(float(t[1]) for t in allt)
+        g_s = max(float(g[0]) for g in allg)
+        multi = {"ranks": world, "series_per_rank": G, "series_total": G * world,
+                 "total_s_by_rank": [round(float(t[0]), 5) for t in allt], "total_s": round(slow_f, 5),
+                 "aggregate_sample_steps_per_s": round(world * G * S * H / slow_f),
+                 "closed_form_total_s": round(slow_c, 5), "non_pd_paths": int(sum(float(t[2]) for t in allt)),
+                 "gather_samples_s": round(g_s, 5), "gathered_bytes_per_rank": nbytes,
+                 "gather_GBps_per_rank": round(nbytes * (world - 1) / world / g_s / 1e9, 2),
+                 "with_gather_sample_steps_per_s": round(world * G * S * H / (slow_f + g_s)),
+                 "note": "every rank rolls out its own series (no collective in the rollout); gather_samples = "
+                         "volt_amd.distributed.gather_samples (all_gather of [G,S,H] fp32), max over ranks, best of 2"}
+        del parts
     del smp_f
-    tot_r, ker_r, bad_r, smp_r = run(solve="closed", resubstitute=True)
-    same = bool(torch.equal(smp_c, smp_r))
-    del smp_r, smp_c
+    if rank != 0:
+        return None
+    res = None
+    if dist is None:
+        tot_r, ker_r, bad_r, smp_r = run(solve="closed", resubstitute=True)
+        same = bool(torch.equal(smp_c, smp_r))
+        del smp_r
+        red = G * S * H ** 3 / 6 * 4
+        res = {"total_s": round(tot_r, 5), "kernel_ms": round(ker_r * 1e3, 3), "non_pd_paths": bad_r,
+               "bitwise_equal_to_default": same, "redundant_bytes": int(red),
+               "streamed_GBps": round(red / ker_r / 1e9, 1),
+               "frac_of_hbm_peak_on_redundant_bytes": round(red / ker_r / 1e9 / HBM_PEAK_GBS, 4)}
+    del smp_c
     alg = G * S * H * 12.0
-    red = G * S * H ** 3 / 6 * 4
-    return {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5, per-GPU share); append-only bordered "
-                        "engine, train block by the closed form (value) and by the fp64 factorisation (factor_route)",
-            "total_s": round(tot_c, 5), "kernel_ms": round(ker_c * 1e3, 3),
-            "sample_steps_per_s": round(G * S * H / tot_c), "non_pd_paths": bad_c,
-            "factor_route": {"total_s": round(tot_f, 5), "kernel_ms": round(ker_f * 1e3, 3),
-                             "sample_steps_per_s": round(G * S * H / tot_f), "non_pd_paths": bad_f,
-                             "max_abs_dev_from_closed": dev_cf,
-                             "includes": f"volt_potrf_f64 of {G} x {n}^2 + two fp64 triangular solves per series"},
-            "roofline": {"kernel": "rollout_bordered_kernel<1,false>", "bound": "hbm", "achieved": round(alg / ker_c / 1e9, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ker_c / 1e9 / HBM_PEAK_GBS, 4),
-                         "algorithmic_GB": round(alg / 1e9, 3),
-                         "note": "one wave per path, H dependent steps each: latency-bound, not bandwidth-bound"},
-            "resubstitute": {"total_s": round(tot_r, 5), "kernel_ms": round(ker_r * 1e3, 3), "non_pd_paths": bad_r,
-                             "bitwise_equal_to_default": same, "redundant_bytes": int(red),
-                             "streamed_GBps": round(red / ker_r / 1e9, 1),
-                             "frac_of_hbm_peak_on_redundant_bytes": round(red / ker_r / 1e9 / HBM_PEAK_GBS, 4)}}
+    # VALU wave-instructions per sample-step of rollout_bordered_kernel<1,false>, from the PMC pass in profiles/r04/
+    # (scripts/pmc_rollouts.sh: SQ_INSTS_VALU / (G S H)); null when the summary is not there or is for another shape
+    issue = None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "rollout_pmc.json")))
+        per = float(pj["valu_wave_insts_per_sample_step"])
+        ach = G * S * H * per / ker_f
+        issue = {"kernel": "rollout_bordered_kernel<1,false>", "bound": "valu_issue", "achieved": round(ach / 1e12, 3),
+                 "peak": round(VALU_WAVE_INSTS_PER_S / 1e12, 3), "unit": "T wave-instructions/s",
+                 "frac": round(ach / VALU_WAVE_INSTS_PER_S, 4), "valu_wave_insts_per_sample_step": per,
+                 "source": "profiles/r04/rollout_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU ...), kernel time live (HIP events)"}
+    except Exception:
+        issue = None
+    return {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5"
+                        + (", per-GPU share" if dist is None else f", {G} of 64 series on each of {world} ranks")
+                        + "); append-only bordered engine; train block by the reference's route (fp64 factorisation + two "
+                          "solves, inside total_s) with the closed form beside it",
+            "solve": "factor", "total_s": round(tot_f, 5), "kernel_ms": round(ker_f * 1e3, 3),
+            "sample_steps_per_s": round(G * S * H / tot_f), "non_pd_paths": bad_f,
+            "includes": f"volt_potrf_f64 of {G} x {n}^2 + two fp64 triangular solves per series",
+            "closed_form": {"total_s": round(tot_c, 5), "kernel_ms": round(ker_c * 1e3, 3),
+                            "sample_steps_per_s": round(G * S * H / tot_c), "non_pd_paths": bad_c,
+                            "max_abs_dev_from_factor_route": dev_cf},
+            "roofline": issue,
+            "hbm": {"algorithmic_GB": round(alg / 1e9, 3), "GBps": round(alg / ker_f / 1e9, 1),
+                    "note": "12 B per sample-step: far from HBM-bound (one wave per path, H dependent steps each)"},
+            "resubstitute": res, "multi_rank": multi}
 
 
 def _cpu_worker(idx, threads, Kc, yc, mc, reps, barrier, q):
