@@ -314,11 +314,12 @@ def main():
 
         def potrf_once():                                   # what ops.potrf calls: the factor of K + s2 I straight from K
             _lib.check(L_.volt_potrf_k_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), Winv.data_ptr(),
-                                           inf.data_ptr(), B, n, pws_ptr, pws_bytes, _lib.stream_ptr()), "potrf")
+                                           inf.data_ptr(), B, n, pws_ptr, pws_bytes,
+                                           _lib.WS_INITIALISED if pws_ptr else 0, _lib.stream_ptr()), "potrf")
 
         def fwd_once():
             _lib.check(L_.volt_mll_step_f32(K.data_ptr(), n, n * n, y.data_ptr(), s2.data_ptr(), 0.0, ws.out.data_ptr(),
-                                            ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n, 0, _lib.stream_ptr()),
+                                            ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n, 0, _lib.stream_ptr()),   # forward only: the workspace was sized and initialised for the gradient step, so no VOLT_WS_INITIALISED here
                        "mll fwd")
         res = {}
         for name, fn in (("chol", potrf_once), ("fwd", fwd_once)):

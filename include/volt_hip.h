@@ -15,10 +15,12 @@
  *     life of the process (the batched factorisation runs groups of matrices on them, forked from and joined
  *     back into `stream`); calls on one device serialise on the host while they ENQUEUE, never on the device.
  *     And HOST-side only: a cache of launch schedules per (batch size, block columns, inverse?) -- a few hundred KB of
- *     tables in pinned host memory (3 <= B <= 64, csrc/sched.h) -- and a note of which caller workspaces
- *     volt_mll_workspace_init_f32 / volt_potrf_workspace_init_f32 copied a table into.  The library owns NO device
- *     memory; a workspace that was not initialised (or whose table region was overwritten since: every table-driven
- *     launch checks it, info = INT_MIN + 1) simply gets the table-free schedules.
+ *     tables in pinned host memory (3 <= B <= 64, csrc/sched.h), a pure function of the shape.  The library owns NO
+ *     device memory and keeps NO record of caller workspaces: volt_mll_workspace_init_f32 / volt_potrf_workspace_init_f32
+ *     copy a table into the caller's scratch, and the caller states that it did so with the VOLT_WS_INITIALISED flag of
+ *     the entry points that take a workspace.  Without the flag a call runs the table-free schedules; with it every
+ *     table-driven launch checks the header in the scratch first, so a region that was never initialised, or was
+ *     overwritten since, is reported (info = INT_MIN + 1), never followed.
  *   - Return value: 0 = enqueued; -k = argument k (1-based) is invalid; >0 = hipError_t of a
  *     failed launch.  A matrix that is not positive definite is NOT an error return: LAPACK-style
  *     `info[b]` (0, or the 1-based index of the first non-positive / NaN pivot) is written to a
@@ -42,6 +44,9 @@ extern "C" {
 #endif
 
 #define VOLT_TILE 128
+/* flag bits of the `flags` / `ws_flags` arguments below */
+#define VOLT_WANT_GRAD 1          /* volt_mll_step_*: also produce the gradient outputs (the triangular inverse) */
+#define VOLT_WS_INITIALISED 2     /* the workspace passed went through its *_workspace_init_f32 for this shape */
 
 /* ---- introspection ------------------------------------------------------------------------ */
 int volt_abi_version(void);                 /* bumps when a signature changes */
@@ -96,16 +101,18 @@ int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream
  * of 3..31) -- one 4096^2 matrix 4.4 -> 1.3 ms.  ws == NULL is volt_potrf_f32. */
 size_t volt_potrf_workspace_bytes(int B, int Np);
 /* Once per scratch buffer (and again should the caller have overwritten it): copies the launch-schedule table for
- * (B, Np) into its table region, asynchronously on `stream`.  Optional -- scratch that was never initialised runs the
- * table-free schedules (3 .. 64 matrices: 2-25 % slower in the late block columns). */
+ * (B, Np) into its table region, asynchronously on `stream`.  Optional: the factorisation follows the table only when
+ * the caller passes ws_flags = VOLT_WS_INITIALISED (and then checks its header on the device: info = INT_MIN + 1 for
+ * scratch that does not hold it); ws_flags = 0 runs the table-free schedules (3 .. 64 matrices: 2-25 % slower in the
+ * late block columns). */
 int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void* stream);
-int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream);
+int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, int ws_flags, void* stream);
 /* volt_prepare_f32 + volt_potrf_ws_f32 in one: the factor of K + (sigma2 + jitter) I (K [B,N,N], row stride ldk, batch
  * stride bsk, lower triangle read; sigma2 [B] or NULL) lands in A [B,Np,Np], Np = volt_padded_n(N), without a copy-in
  * pass -- the tiles are read from K by the workgroups that update them (what torch.linalg.cholesky(K + s2 I) is to the
  * reference: gpytorch's MLL, psd_safe_cholesky at rollout_utils.py:35).  ws as for volt_potrf_ws_f32 (may be NULL). */
 int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, float* Winv,
-                     int* info, int B, int N, void* ws, size_t ws_bytes, void* stream);
+                     int* info, int B, int N, void* ws, size_t ws_bytes, int ws_flags, void* stream);
 
 /* fp64 twins on v_mfma_f64_16x16x4_f64 (the reference keeps the caller's dtype, VolKernel.py:28-33; the
  * noise-free train block of rollout_utils.py:35 has condition number 1e6 (N = 400) .. 1e8 (N = 4096), beyond
@@ -186,8 +193,8 @@ int volt_adam_step_f32(const void* slots, int nslots, long long total, const flo
  *     out[b,1] = d mll / d sigma2 = 1/2 (alpha'alpha - tr K_s^-1) / N
  *     out[b,2] = z'z   out[b,3] = logdet   out[b,4] = tr K_s^-1   out[b,5] = alpha'alpha
  *     alpha[b,:] (= K_s^-1 r;  d mll / d mean = alpha / N)
- * resid [B,N] = y - mean(x).  If `want_grad` == 0 the triangular inverse is skipped (forward
- * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written.
+ * resid [B,N] = y - mean(x).  `flags`: VOLT_WANT_GRAD -- without it the triangular inverse is skipped (forward
+ * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written; VOLT_WS_INITIALISED -- see below.
  * workspace: volt_mll_workspace_bytes(B,N,want_grad) bytes, 256-byte aligned. */
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
 /* Once per workspace (and again should the caller have overwritten it), asynchronously on `stream`: copies the
@@ -196,15 +203,16 @@ size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
  * flags its workgroups hand tiles on with (for ONE series of 1025 .. 4096 points also the list of its pieces, and the
  * workspace holds the slabs of their K-slices) -- volt_mll_step_f32 then enqueues one kernel for the whole step instead of
  * eleven (the counter lives on the device, so the launch replays from a hipGraph as it is).  Optional, like
- * volt_potrf_workspace_init_f32: a workspace that was never initialised gets the launch-per-column path.  The library
- * recognises the regions it initialised BY ADDRESS and every launch that follows a table or the state checks the
- * header there first: a region that was initialised, freed and handed out again at the same address without a new init
- * is reported like one that was overwritten (info = INT_MIN + 1), never followed -- initialise every workspace or none.
+ * volt_potrf_workspace_init_f32: the step uses what the init wrote only when the caller passes VOLT_WS_INITIALISED in
+ * `flags` -- the library keeps no record of workspaces (rounds 2-3 recognised them by address) -- and every launch that
+ * follows a table or the state checks the header there first: a region that does not hold what the init wrote (never
+ * initialised, overwritten, or freed and handed out again) is reported (info = INT_MIN + 1), never followed.  Without the
+ * flag the step runs the launch-per-column path.
  * (The workspace of volt_gpcv_step_f32 begins with an MLL workspace: same call, want_grad = 1.) */
 int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, void* stream);
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid,
                       const float* sigma2, float jitter, float* out /*[B,8]*/, float* alpha /*[B,N]*/,
-                      int* info, void* workspace, int B, int N, int want_grad, void* stream);
+                      int* info, void* workspace, int B, int N, int flags, void* stream);
 
 /* The same step in double precision for double-precision models (the reference keeps the caller's dtype,
  * voltron/kernels/VolKernel.py:28-33; gpytorch computes log_prob in it): K, resid, sigma2, out [B,8], alpha [B,N] are
@@ -248,7 +256,7 @@ size_t volt_gpcv_workspace_bytes(int B, int N, int want_dk);
 int volt_gpcv_step_f32(const float* K, int64_t ldk, int64_t bsk, float jitter, const float* resid, const float* m,
                        const float* Lq, const float* y, const float* gh_x, const float* gh_w, int Q, float min_var,
                        float min_scale, float w_ell, float w_kl, float* out, float* grad_m, float* grad_mu,
-                       float* grad_Lq, float* grad_K, int* info, void* workspace, int B, int N, void* stream);
+                       float* grad_Lq, float* grad_K, int* info, void* workspace, int B, int N, int ws_flags, void* stream);
 
 #ifdef __cplusplus
 }

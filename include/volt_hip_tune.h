@@ -2,8 +2,9 @@
  * (include/volt_hip.h): nothing on the product path calls these; bench.py's roofline leg, the scripts under scripts/
  * and tests/test_sched_host.py do.  They live in the same shared library so that what they time is the shipped code.
  *
- * Environment knobs.  The schedule defaults below are compiled in and were measured on MI355X;
- * every one can be overridden for experiments through ONE table read once per process (csrc/chol.hip, `tunables()`):
+ * Environment knobs.  The schedule defaults below are compiled in and were measured on MI355X; a
+ * deployment reads NO environment variable.  Only a process started with VOLT_TUNE=1 (the experiment scripts) may
+ * override them, through ONE table read once per process (csrc/chol.hip `tunables()`, csrc/chol64.hip `tune_int`):
  *   VOLT_GROUPS            stream groups for batches >= 16 (2)        VOLT_SPLITK_TARGET  workgroups per split launch (512)
  *   VOLT_SPLITK_MINL       shortest K-slice in blocks (2)            VOLT_SPLITK_MAXS    most slices per tile (8)
  *   VOLT_SPLITK_GROUPS / _MAXB   two split groups for 10 <= B < 22   VOLT_SCHED          balanced schedule on/off (1)

@@ -1,3 +1,4 @@
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 # sweep of the one-launch long step's tunables (run on the GPU box);  with arguments: same-box A/B of a -D switch, e.g.
 # scripts/ab_split.sh -DVOLT_SOMETHING
 export TMPDIR=/tmp

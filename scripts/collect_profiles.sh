@@ -1,4 +1,5 @@
 #!/bin/bash
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 # End-of-round evidence: bench line + rocprofv3 kernel-trace summaries of the same command in both schedules.
 # usage (GPU box): scripts/collect_profiles.sh <tag>      -> gpurun_out/prof_<tag>/
 TAG=${1:-x}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 # Round-3 evidence in one go (GPU box, through gpurun): bench line, rocprofv3 kernel-trace summaries of the same command
 # in both schedules, the rollout and fp64 kernels' stats, PMC traffic passes, and the tables DESIGN.md quotes.
 # usage: scripts/collect_r03.sh [part ...]   parts: bench trace roll f64 pmc tables small   (default: all)

@@ -1,3 +1,4 @@
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 run() { python bench.py --batch $1 --n $2 --steps ${3:-100} --no-rollouts --no-cpu-baseline --no-aux-legs 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readlines()[-1]); print('B=%-4d N=%-5d %8.3f ms/step  %6.1f TF/s' % ($1, $2, d['ms_per_step'], d['step_tflops']))"; }

@@ -1,3 +1,4 @@
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp

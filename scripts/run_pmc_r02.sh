@@ -1,3 +1,4 @@
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 set -x
 export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -o "TCC_EA0_RD[A-Z0-9_]*\|TCC_EA0_WR[A-Z0-9_]*\|TCC_REQ[A-Z0-9_]*\|TCC_BUBBLE[A-Z_0-9]*" | sort -u | head -40 > gpurun_out/tcc_counters.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+export VOLT_TUNE=1   # the VOLT_* schedule knobs are read only then (include/volt_hip_tune.h)
 # ms/step of the MLL+grad step over a grid of shapes, default schedules against the alternatives (which knob would have
 # been better where): scripts/shape_sweep.sh > gpurun_out/shape_sweep.txt
 run() { env $3 python bench.py --n $1 --batch $2 --steps 40 --no-rollouts --no-cpu-baseline --no-aux-legs 2>/dev/null | python -c "

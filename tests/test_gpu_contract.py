@@ -327,17 +327,17 @@ def test_potrf_with_scratch_small_and_late_column_schedules(ops, B, n):
     assert need > 0
     ws = torch.empty(need + 512, dtype=torch.uint8, device="cuda")
     base = ((ws.data_ptr() + 255) // 256) * 256
-    assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base + 4, need, _lib.stream_ptr()) == -6
-    assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need - 1, _lib.stream_ptr()) == -7
+    assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base + 4, need, 0, _lib.stream_ptr()) == -6
+    assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need - 1, 0, _lib.stream_ptr()) == -7
     # the copy-in + in-place pair (volt_prepare_f32 + volt_potrf_ws_f32) gives bitwise the factor ops.potrf's one call
     # (volt_potrf_k_f32: tiles read from K by the workgroups that update them) does -- same schedule, same arithmetic
     _lib.check(lib.volt_potrf_workspace_init_f32(base, need, B, Np, _lib.stream_ptr()), "ws init")
     _lib.check(lib.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n, _lib.stream_ptr()), "prepare")
-    _lib.check(lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need, _lib.stream_ptr()), "potrf_ws")
+    _lib.check(lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need, _lib.WS_INITIALISED, _lib.stream_ptr()), "potrf_ws")
     assert int(info.abs().sum()) == 0
     assert torch.equal(torch.tril(A[:, :n, :n]), L1)
     assert lib.volt_potrf_k_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), W.data_ptr(), info.data_ptr(), B, n,
-                                base + 4, need, _lib.stream_ptr()) == -11
+                                base + 4, need, 0, _lib.stream_ptr()) == -11
 
 
 def test_potrf_from_a_strided_view_with_jitter(ops):
@@ -544,8 +544,9 @@ def test_exact_mll_keeps_fp64_and_its_gradient(ops):
 # ------------------------------------------------------------------ schedule tables live in caller scratch
 def test_workspace_tables_are_optional_and_checked(ops):
     """The balanced schedule's tables are copied into the caller's workspace by volt_mll_workspace_init_f32 (the library
-    owns no device memory).  A workspace that was never initialised runs the table-free schedules and gives the same
-    answer; one whose table was overwritten after the init is REPORTED (info = INT_MIN + 1), never followed."""
+    owns no device memory and keeps no record of workspaces: the caller passes VOLT_WS_INITIALISED).  A workspace not
+    declared initialised runs the table-free schedules and gives the same answer; one declared initialised that does not
+    hold the table -- never initialised, or overwritten after the init -- is REPORTED (info = INT_MIN + 1), never followed."""
     from volt_amd import _lib
     B, n = 6, 3000                                  # 24 block columns: the late ones run the balanced schedule
     x, vol, y, mean = _series_problem(B, n)
@@ -557,8 +558,7 @@ def test_workspace_tables_are_optional_and_checked(ops):
     assert int(ws.info.abs().sum()) == 0
     _check_vs_oracle(K[:1].cpu().numpy(), y, mean, 1e-5, out1.cpu().numpy(), ws.alpha.cpu().numpy(), [0])
     L = _lib.lib()
-    # never initialised -- and at an address no initialised workspace ever had (the library recognises the regions it
-    # initialised by their address; torch hands freed blocks out again, 512-byte aligned)
+    # never initialised, and not declared so (flags = VOLT_WANT_GRAD only): the launch-per-column / table-free schedules
     raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 1024, dtype=torch.uint8, device="cuda")
     ptr = (raw.data_ptr() + 511) // 512 * 512 + 256
     out2, alpha2 = torch.empty(B, 8, device="cuda"), torch.empty(B, n, device="cuda")
@@ -567,6 +567,10 @@ def test_workspace_tables_are_optional_and_checked(ops):
                                    info2.data_ptr(), ptr, B, n, 1, _lib.stream_ptr()), "step")
     assert int(info2.abs().sum()) == 0
     assert torch.allclose(out2[:, :6], out1[:, :6], rtol=2e-5, atol=1e-6)
+    # declared initialised (VOLT_WS_INITIALISED) but never was -- e.g. a block the allocator handed out again: REPORTED
+    _lib.check(L.volt_mll_step_f32(K.data_ptr(), n, n * n, r.data_ptr(), s2.data_ptr(), 0.0, out2.data_ptr(), alpha2.data_ptr(),
+                                   info2.data_ptr(), ptr, B, n, _lib.WANT_GRAD | _lib.WS_INITIALISED, _lib.stream_ptr()), "step")
+    assert bool((info2 == -2147483647).all())
     ws.buf.zero_()                                                   # the caller tramples its initialised workspace
     ops.mll_step(K, r, s2, ws)
     assert bool((ws.info == -2147483647).all())
@@ -595,8 +599,7 @@ def test_short_series_run_as_one_launch(ops, B, n):
     rows = sorted({0, B // 2, B - 1})
     _check_vs_oracle(K[rows].cpu().numpy(), y, mean, 1e-5, out1.cpu().numpy(), alpha1.cpu().numpy(), rows)
     L = _lib.lib()
-    # never initialised -- and at an address no initialised workspace ever had (the library recognises the regions it
-    # initialised by their address; torch hands freed blocks out again, 512-byte aligned)
+    # never initialised, and not declared so (flags = VOLT_WANT_GRAD only): the launch-per-column / table-free schedules
     raw = torch.zeros(L.volt_mll_workspace_bytes(B, n, 1) + 1024, dtype=torch.uint8, device="cuda")
     ptr = (raw.data_ptr() + 511) // 512 * 512 + 256
     out2, alpha2 = torch.empty(B, 8, device="cuda"), torch.empty(B, n, device="cuda")

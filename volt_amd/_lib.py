@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- load torch's libamdhip64 first so the library bin
 from .build import LIB, build_lib, source_hash, sources_present
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
+WANT_GRAD, WS_INITIALISED = 1, 2       # include/volt_hip.h: VOLT_WANT_GRAD, VOLT_WS_INITIALISED
 
 _i32, _i64, _f32, _f64, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 
@@ -27,8 +28,8 @@ _SIGS = {
     "volt_potrf_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_workspace_bytes": (C.c_size_t, [_i32, _i32]),
     "volt_potrf_workspace_init_f32": (C.c_int, [_ptr, C.c_size_t, _i32, _i32, _ptr]),
-    "volt_potrf_ws_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
-    "volt_potrf_k_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, C.c_float, _ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
+    "volt_potrf_ws_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _i32, _ptr]),
+    "volt_potrf_k_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, C.c_float, _ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _i32, _ptr]),
     "volt_prepare_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, _f64, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
@@ -51,7 +52,7 @@ _SIGS = {
                                    _i32, _i32, _i32, _i32, _ptr]),
     "volt_gpcv_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "volt_gpcv_step_f32": (C.c_int, [_ptr, _i64, _i64, _f32] + [_ptr] * 6 + [_i32, _f32, _f32, _f32, _f32] + [_ptr] * 7
-                           + [_i32, _i32, _ptr]),
+                           + [_i32, _i32, _i32, _ptr]),
 }
 
 # measurement / tuning hooks: include/volt_hip_tune.h, not part of the drop-in boundary

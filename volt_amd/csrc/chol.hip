@@ -2304,8 +2304,9 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
 
 using namespace volt;
 
-// Schedule parameters: compiled-in defaults (measured on MI355X), each overridable for experiments
-// through its VOLT_* environment variable (include/volt_hip_tune.h) -- read ONCE per process, here and nowhere else.
+// Schedule parameters: compiled-in defaults (measured on MI355X).  A deployment reads NO environment:
+// only a process started with VOLT_TUNE=1 (the experiment scripts) may override them through the VOLT_* variables listed in
+// include/volt_hip_tune.h -- read ONCE, here and in chol64.hip's tune_int, nowhere else.
 struct Tunables {
     int groups = 2;                  // stream groups of a large batch (2 >= 4 > 8 with one launch per block column)
     int splitk_target = 512, splitk_minl = 2, splitk_maxs = 8, splitk_groups = 2, splitk_maxb = 22;
@@ -2323,6 +2324,8 @@ struct Tunables {
 static const Tunables& tunables() {
     static const Tunables tn = [] {
         Tunables t;
+        const char* tune = getenv("VOLT_TUNE");
+        if (!tune || atoi(tune) == 0) return t;              // the frozen defaults
         auto geti = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
         geti("VOLT_GROUPS", t.groups);
         geti("VOLT_SPLITK_TARGET", t.splitk_target);
@@ -2509,13 +2512,11 @@ static bool sched_choice(int B, int n, bool has_y, int cap, int& Gs, SchedParams
 }
 
 // The tables live in the CALLER's scratch, put there once by volt_*_workspace_init (below) -- the library owns no device
-// memory and copies nothing per call.  What it keeps is a host-side note of which scratch regions it initialised with
-// which table; a factorisation uses the balanced schedule only for a region it finds here (anything else gets the
-// table-free schedules), and every table-driven launch checks the header in the region against the table it expects,
-// so scratch that was overwritten since is reported (info = INT_MIN + 1), never followed.
-static std::mutex g_installed_mu;
-static std::map<std::pair<int, const void*>, const SchedDev*> g_installed;
-
+// memory, copies nothing per call and keeps NO record of which scratch it initialised (rounds 2-3 kept an address-keyed
+// map: a region freed and handed out again at the same address was then taken for initialised).  The caller says so
+// itself (the VOLT_WS_INITIALISED flag of the entry points that take a workspace); a factorisation is handed the table
+// region only then, and every table-driven launch checks the header in the region against the table it expects, so scratch
+// that was never initialised or was overwritten since is reported (info = INT_MIN + 1), never followed.
 static int sched_install(void* tab, size_t tab_bytes, int B, int n, bool has_y, int cap, hipStream_t s) {
     int Gs = 1;
     SchedParams sp;
@@ -2523,19 +2524,7 @@ static int sched_install(void* tab, size_t tab_bytes, int B, int n, bool has_y, 
     const SchedDev* sd = get_sched(B / Gs, n, has_y, sp, s);
     if (!sd || sd->bytes > tab_bytes) return 0;
     hipError_t e = hipMemcpyAsync(tab, sd->items, sd->bytes, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(g_installed_mu);
-    g_installed[{dev, tab}] = sd;
-    return 0;
-}
-static const SchedDev* sched_installed(const void* tab) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(g_installed_mu);
-    auto it = g_installed.find({dev, tab});
-    return it == g_installed.end() ? nullptr : it->second;
+    return e != hipSuccess ? (int)e : 0;
 }
 
 // Everything one group of matrices needs: the batch is cut into contiguous groups that run the same
@@ -2755,11 +2744,14 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     if (can_split) {
         int Gs = 1;
         SchedParams sp;
-        const SchedDev* sd = o.sk.tab ? sched_installed(o.sk.tab) : nullptr;     // what volt_*_workspace_init put there
+        // o.sk.tab != nullptr: the caller declared its scratch initialised -- the table volt_*_workspace_init copied there
+        // is the one get_sched returns for this shape (a pure function of it; the launches check the header on the device)
+        const SchedDev* sd = nullptr;
+        if (o.sk.tab && sched_choice(B, n, o.Y != nullptr, o.sk.cap, Gs, sp) && (Gs == 1 || (pool && !capturing)))
+            sd = get_sched(B / Gs, n, o.Y != nullptr, sp, s);
         // short matrices never reach the scheduled columns; below 8 matrices the alternative is the all-split schedule,
         // which is the better one while most columns are early ones (B = 4, n = 16: 0.92 ms all-split, 1.04 hybrid)
-        if (sd && sched_choice(B, n, o.Y != nullptr, o.sk.cap, Gs, sp) && (Gs == 1 || (pool && !capturing)) &&
-            sd == get_sched(B / Gs, n, o.Y != nullptr, sp, s) && n > sd->kmin + (B < 8 ? 7 : 1)) {
+        if (sd && sd->bytes <= o.sk.tab_bytes && n > sd->kmin + (B < 8 ? 7 : 1)) {
             // (the early columns as all-split launches instead of plain ones were measured too: no better, B = 7 4.13 vs 3.82)
             G = Gs;
             o1.sk.S = 2;                                     // > 1: the counters are cleared below, the slab is shared out
@@ -2865,17 +2857,12 @@ size_t volt_internal_small_bytes(int B, int n) {
     if (!small_applies(B, n)) return 0;
     return (((size_t)SMALL_HDR + (size_t)B * small_stride(n)) * sizeof(int) + 255) & ~(size_t)255;
 }
-static std::map<std::pair<int, const void*>, std::pair<int, int>> g_small_installed;
 static long long* g_small_stamps = nullptr;    // volt_tune_small_stamps
 int volt_internal_small_install(void* state, size_t bytes, int B, int n, void* stream) {
     if (!state || !small_applies(B, n) || bytes < volt_internal_small_bytes(B, n)) return 0;
     const int count = SMALL_HDR + B * small_stride(n);
     hipLaunchKernelGGL(small_init_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int*)state, count, B, n);
     VOLT_LAUNCH_CHECK();
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(g_installed_mu);
-    g_small_installed[{dev, state}] = {B, n};
     return 0;
 }
 // 1: the step has been enqueued (one launch);  0: not applicable here (the caller runs the launch-per-column path)
@@ -2884,14 +2871,7 @@ int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const flo
                              float* frob, float* z, float* apad, float* apart, float* out, float* alpha, void* state,
                              int B, int N, void* stream) {
     const int Np = volt_padded_n(N), n = Np / TS;
-    if (!state || !Y || !apart || !small_applies(B, n)) return 0;
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lock(g_installed_mu);
-        auto it = g_small_installed.find({dev, state});
-        if (it == g_small_installed.end() || it->second != std::make_pair(B, n)) return 0;
-    }
+    if (!state || !Y || !apart || !small_applies(B, n)) return 0;    // (state: only passed for a workspace declared initialised)
     int* base = (int*)state;
     const SmallState st{base, base + SMALL_HDR, small_stride(n), g_small_stamps};
     const KSource src{K, ldk, bsk, sigma2, jitter, N};
@@ -2983,7 +2963,6 @@ size_t volt_internal_long_slab_floats(int B, int n) {
     long_sizes(n, items, nslabs, ncnt);
     return (size_t)nslabs * TS * TS;
 }
-static std::map<std::pair<int, const void*>, int> g_long_installed;
 int volt_internal_long_install(void* state, size_t bytes, int B, int n, void* stream) {
     if (!state || !long_applies(B, n) || bytes < volt_internal_long_bytes(B, n)) return 0;
     const LongPlanDev* pd = get_long_plan(n, (hipStream_t)stream);
@@ -2993,12 +2972,7 @@ int volt_internal_long_install(void* state, size_t bytes, int B, int n, void* st
     VOLT_LAUNCH_CHECK();
     char* tab = reinterpret_cast<char*>(state) + (((size_t)count * sizeof(int) + 255) & ~(size_t)255);
     hipError_t e = hipMemcpyAsync(tab, pd->items, (size_t)(pd->nitems + n) * sizeof(int4), hipMemcpyHostToDevice, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(g_installed_mu);
-    g_long_installed[{dev, state}] = n;
-    return 0;
+    return e != hipSuccess ? (int)e : 0;
 }
 // 1: enqueued (one launch);  0: not applicable (launch-per-column path)
 int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2,
@@ -3007,14 +2981,7 @@ int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const floa
                             void* state, int B, int N, void* stream) {
     const int Np = volt_padded_n(N), n = Np / TS;
     hipStream_t s = (hipStream_t)stream;
-    if (!state || !Y || !apart || !eslab || !long_applies(B, n)) return 0;
-    {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::lock_guard<std::mutex> lock(g_installed_mu);
-        auto it = g_long_installed.find({dev, state});
-        if (it == g_long_installed.end() || it->second != n) return 0;
-    }
+    if (!state || !Y || !apart || !eslab || !long_applies(B, n)) return 0;   // (state: only for a workspace declared initialised)
     const LongPlanDev* pd = get_long_plan(n, s);
     if (!pd) return 0;
     int* base = (int*)state;
@@ -3187,7 +3154,7 @@ int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void
                          false, potrf_ws_rows(B), (hipStream_t)stream);
 }
 
-int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {
+int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, int ws_flags, void* stream) {
     if (!A) return -1;
     if (!Winv) return -2;
     if (!info) return -3;
@@ -3204,8 +3171,10 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
             sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
             sk.cap = potrf_ws_rows(B);
             sk.tab_bytes = volt_internal_sched_bytes(B, Np / TS);
-            sk.tab = sk.tab_bytes ? reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) +
-                                                            potrf_ws_count_bytes(B, Np)) : nullptr;
+            // the table region is followed only on the caller's word that volt_potrf_workspace_init_f32 ran on this scratch
+            sk.tab = (sk.tab_bytes && (ws_flags & VOLT_WS_INITIALISED))
+                         ? reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np))
+                         : nullptr;
         }
     }
     FactorOpts o{KSource{nullptr, 0, 0, nullptr, 0.f, 0}, nullptr, TriReduce{nullptr, nullptr, nullptr, 0}, sk};
@@ -3213,14 +3182,14 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
 }
 
 int volt_potrf_f32(float* A, float* Winv, int* info, int B, int Np, void* stream) {
-    return volt_potrf_ws_f32(A, Winv, info, B, Np, nullptr, 0, stream);
+    return volt_potrf_ws_f32(A, Winv, info, B, Np, nullptr, 0, 0, stream);
 }
 
 // Factor of K + (sigma2 + jitter) I straight from K: only block column 0 is copied, every other tile is read from K by
 // the workgroup that updates it (as the MLL step does) -- volt_prepare_f32's pass over the lower triangle (2.2 GB in,
 // 2.2 GB out and 0.82 ms for 64 x 4096^2: 7 % of the factorisation) disappears.
 int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A, float* Winv,
-                     int* info, int B, int N, void* ws, size_t ws_bytes, void* stream) {
+                     int* info, int B, int N, void* ws, size_t ws_bytes, int ws_flags, void* stream) {
     if (!K) return -1;
     if (ldk < N) return -2;
     if (!A) return -6;
@@ -3240,8 +3209,10 @@ int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
             sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
             sk.cap = potrf_ws_rows(B);
             sk.tab_bytes = volt_internal_sched_bytes(B, Np / TS);
-            sk.tab = sk.tab_bytes ? reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) +
-                                                            potrf_ws_count_bytes(B, Np)) : nullptr;
+            // the table region is followed only on the caller's word that volt_potrf_workspace_init_f32 ran on this scratch
+            sk.tab = (sk.tab_bytes && (ws_flags & VOLT_WS_INITIALISED))
+                         ? reinterpret_cast<int4*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np))
+                         : nullptr;
         }
     }
     hipStream_t s = (hipStream_t)stream;

@@ -700,6 +700,14 @@ struct VoltAux {
 };
 bool volt_internal_aux(VoltAux* out);
 
+// Experiment knobs: compiled-in defaults unless the process was started with VOLT_TUNE=1 (like tunables() in chol.hip)
+static int tune_int(const char* name, int dflt) {
+    static const bool on = [] { const char* t = getenv("VOLT_TUNE"); return t && atoi(t) != 0; }();
+    if (!on) return dflt;
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 #define VOLT_TRY64(call)                            \
     do {                                            \
         hipError_t e__ = (call);                    \
@@ -713,11 +721,11 @@ bool volt_internal_aux(VoltAux* out);
 // pairs them up, two share one MFMA pipe and the launch lasts as long as the slower pair (8 x 4096 potrf / inverse / MLL
 // step, ms: no spreading 6.38 / 6.05 / 11.7, up to 256 5.93 / 6.05 / 11.5, **up to 512 5.64 / 4.77 / 9.57**; flat beyond).
 static unsigned spread64(int workgroups) {
-    static const int lim = getenv("VOLT_F64_SPREAD") ? atoi(getenv("VOLT_F64_SPREAD")) : 512;
+    static const int lim = tune_int("VOLT_F64_SPREAD", 512);
     return workgroups <= lim ? 16 * 1024 : 0;
 }
 static int trtri64_slices(int i, int B) {                       // row i: i B tiles of 1 .. i K blocks
-    static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
+    static const int target = tune_int("VOLT_F64_SPLIT_TARGET", 512);
     int S = target / (i * B);
     if (S > (i + 1) / 2) S = (i + 1) / 2;
     if (S > 16) S = 16;
@@ -728,7 +736,7 @@ static int trtri64_slices(int i, int B) {                       // row i: i B ti
 // B <= 4 -1 %, B = 8 10.3 -> 12.0, 16: 17.6 -> 20.3 (from 8 matrices on the inverse is bound by the 128x128 fp64 core's
 // throughput, not by its chain, and one more stream only gets in the factorisation's way): up to 4 matrices.
 static bool trtri64_lookahead(int B) {
-    static const int env = getenv("VOLT_F64_TRTRI_LOOKAHEAD") ? atoi(getenv("VOLT_F64_TRTRI_LOOKAHEAD")) : -1;
+    static const int env = tune_int("VOLT_F64_TRTRI_LOOKAHEAD", -1);
     return env >= 0 ? env != 0 : B <= 4;
 }
 static void trtri64_begin(double* Y, int B, int Np, hipStream_t s, bool lookahead = false) {
@@ -866,9 +874,9 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
     // look-ahead depth: 0 = one stream, 1 = one column, 2 = two columns.  Measured (N = 4096, potrf / MLL step, ms, depth 1 ->
     // depth 2): B = 8 6.55 -> 5.87 / 10.6 -> 10.2, B = 16 11.6 -> 9.7 / 19.2 -> 17.6, 32 x 2048 3.81 -> 3.28 / 6.82 -> 6.54; B <= 4
     // potrf +-2 % and the step 1 - 5 % SLOWER (the third stream competes with the rows of the inverse): depth 2 from B = 6
-    static const int look_env = getenv("VOLT_F64_LOOKAHEAD") ? atoi(getenv("VOLT_F64_LOOKAHEAD")) : -1;
+    static const int look_env = tune_int("VOLT_F64_LOOKAHEAD", -1);
     const int look = look_env >= 0 ? look_env : (B >= 6 ? 2 : 1);
-    static const int target = getenv("VOLT_F64_SPLIT_TARGET") ? atoi(getenv("VOLT_F64_SPLIT_TARGET")) : 512;
+    static const int target = tune_int("VOLT_F64_SPLIT_TARGET", 512);
     auto slices = [&](int tiles, int kblocks) {
         int S = tiles > 0 ? target / tiles : 1;
         if (S > kblocks / 2) S = kblocks / 2;                          // a slice is at least two K blocks long

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define VOLT_ABI_VERSION 4
+#define VOLT_ABI_VERSION 5
 
 namespace volt {
 

@@ -316,7 +316,7 @@ size_t volt_gpcv_workspace_bytes(int B, int N, int want_dk) {
 int volt_gpcv_step_f32(const float* K, int64_t ldk, int64_t bsk, float jitter, const float* resid, const float* m,
                        const float* Lq, const float* y, const float* gh_x, const float* gh_w, int Q, float min_var,
                        float min_scale, float w_ell, float w_kl, float* out, float* grad_m, float* grad_mu,
-                       float* grad_Lq, float* grad_K, int* info, void* workspace, int B, int N, void* stream) {
+                       float* grad_Lq, float* grad_K, int* info, void* workspace, int B, int N, int ws_flags, void* stream) {
     if (!K) return -1;
     if (ldk < N) return -2;
     if (!resid) return -5;
@@ -347,7 +347,8 @@ int volt_gpcv_step_f32(const float* K, int64_t ldk, int64_t bsk, float jitter, c
     hipLaunchKernelGGL(transpose_tri_kernel, dim3(Np / 32, Np / 32, B), dim3(256), 0, s, Lq, (int64_t)N,
                        (int64_t)N * N, w.LqT, N, Np, 1);
     // K + jitter I = L L',  Y = L^-T,  beta = K^-1 resid,  quad, logdet K, tr K^-1, |beta|^2  (exact-GP step)
-    int rc = volt_mll_step_f32(K, ldk, bsk, resid, nullptr, jitter, w.mllout, w.beta, info, w.mll, B, N, 1, stream);
+    int rc = volt_mll_step_f32(K, ldk, bsk, resid, nullptr, jitter, w.mllout, w.beta, info, w.mll, B, N,
+                               VOLT_WANT_GRAD | (ws_flags & VOLT_WS_INITIALISED), stream);
     if (rc) return rc;
     const float* Y = volt_internal_mll_y(workspace, B, N);
     hipLaunchKernelGGL(transpose_tri_kernel, dim3(Np / 32, Np / 32, B), dim3(256), 0, s, Y, (int64_t)Np, mat, w.W, Np, Np,

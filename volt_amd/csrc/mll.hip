@@ -273,8 +273,12 @@ int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, vo
 }
 
 int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* resid, const float* sigma2, float jitter,
-                      float* out, float* alpha, int* info, void* workspace, int B, int N, int want_grad,
+                      float* out, float* alpha, int* info, void* workspace, int B, int N, int flags,
                       void* stream) {
+    const int want_grad = flags & VOLT_WANT_GRAD;
+    // the caller's word that volt_mll_workspace_init_f32 ran on this workspace for this shape: only then are the regions
+    // that hold tables / one-launch state handed on (and checked on the device before they are followed)
+    const bool ready = (flags & VOLT_WS_INITIALISED) != 0;
     if (!K) return -1;
     if (ldk < N) return -2;
     if (!resid) return -4;
@@ -289,13 +293,13 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     const int Np = volt_padded_n(N);
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
-    if (want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
+    if (ready && want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
         rc = volt_internal_long_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                      w.z, w.apad, w.apart, w.eslab, out, alpha, w.lng, B, N, stream);
         if (rc == 1) return 0;
         if (rc) return rc > 0 ? rc : -1;
     }
-    if (want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
+    if (ready && want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
         rc = volt_internal_small_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                       w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
         if (rc == 1) return 0;
@@ -305,7 +309,7 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
     if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
                                    want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx, w.sk_slab,
-                                   w.sk_count, w.sk_rows, w.tab, w.tab_bytes)))
+                                   w.sk_count, w.sk_rows, ready ? w.tab : nullptr, w.tab_bytes)))
         return rc > 0 ? rc : -1;
     VOLT_LAUNCH_CHECK();
     return 0;

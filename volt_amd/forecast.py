@@ -70,8 +70,10 @@ def _window_pass(train_x, test_x, train_y, nsample, mean, k, gpcv_iters, vol_ite
         vol = LearnGPCV(train_x, train_y, train_iters=gpcv_iters, graph=graph)           # all series at once
     else:
         vol = vol_fn(train_x, train_y)                                                   # [b, ntrain-1]
+    # the shards are independent series and the ranks may run different numbers of fits (a failed window is redone series
+    # by series on the rank that saw it): no collective in here
     model, lh, _ = TrainVoltMagpieBatch(train_x, train_y[:, 1:], vol, train_iters=data_iters, k=k, mean_func=mean,
-                                        graph=graph)
+                                        graph=graph, reduce_across_ranks=False)
     vmod, vlh = TrainVolModelBatch(train_x, vol, train_iters=vol_iters, graph=graph)
     vmod.eval()
     pred_vol = vmod(test_x).sample(torch.Size((nsample,))).exp().transpose(0, 1).contiguous().detach()   # [b,S,H]

@@ -26,6 +26,16 @@ class _NoOpSetting(contextlib.ContextDecorator):
         return False
 
 
+def _baseline_kernel(name):
+    """gpytorch.kernels.{ScaleKernel,RBFKernel,MaternKernel,SpectralMixtureKernel}: imported unconditionally by the
+    reference's drivers (experiments/stocks/GenerateMultiMeanPreds.py:16), out of this package's scope -- resolved lazily
+    (baselines/ of the source tree, or a stand-in that raises when called)."""
+    from ._out_of_scope import WHERE, resolve
+    if WHERE.get(name) == "gpkernels":
+        return resolve(name)
+    raise AttributeError(f"module 'gpytorch.kernels' (volt_amd stand-in) has no attribute {name!r}")
+
+
 def build() -> types.ModuleType:
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -38,7 +48,7 @@ def build() -> types.ModuleType:
     utils = mod("gpytorch.utils", cholesky=cholesky, errors=errors, warnings=warns)
     subs = {
         "means": mod("gpytorch.means", Mean=gp.Mean, ConstantMean=gp.ConstantMean, LinearMean=gp.LinearMean),
-        "kernels": mod("gpytorch.kernels", Kernel=gp.Kernel),
+        "kernels": mod("gpytorch.kernels", Kernel=gp.Kernel, __getattr__=_baseline_kernel),
         "likelihoods": mod("gpytorch.likelihoods", GaussianLikelihood=gp.GaussianLikelihood),
         "mlls": mod("gpytorch.mlls", ExactMarginalLogLikelihood=gp.ExactMarginalLogLikelihood,
                     VariationalELBO=variational.VariationalELBO),

@@ -142,7 +142,8 @@ def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0
         # 3 block columns)
         wp, nbytes = _potrf_workspace(B, Np, K.device)
         _lib.check(L.volt_potrf_k_f32(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(),
-                                      Winv.data_ptr(), info.data_ptr(), B, n, wp, nbytes, st), "volt_potrf_k")
+                                      Winv.data_ptr(), info.data_ptr(), B, n, wp, nbytes,
+                                      _lib.WS_INITIALISED if wp else 0, st), "volt_potrf_k")
     else:
         _lib.check(L.volt_prepare_f64(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(), B, n, st),
                    "volt_prepare")
@@ -202,9 +203,11 @@ class MllWorkspace:
         nbytes = query(B, N, int(want_grad))
         self.buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
         self.ptr = (self.buf.data_ptr() + 255) // 256 * 256
+        self.flags = int(bool(want_grad)) * _lib.WANT_GRAD
         if dtype == torch.float32:                      # the launch-schedule table of this shape, once (mid-size batches)
             with torch.cuda.device(self.buf.device):
                 _lib.check(L.volt_mll_workspace_init_f32(self.ptr, B, N, int(want_grad), _lib.stream_ptr()), "volt_mll_workspace_init")
+            self.flags |= _lib.WS_INITIALISED           # ... and the step is told so (the library keeps no record of it)
         self.out = torch.empty(B, 8, dtype=dtype, device=device)
         self.alpha = torch.empty(B, N, dtype=dtype, device=device)
         self.info = torch.empty(B, dtype=torch.int32, device=device)
@@ -231,7 +234,8 @@ def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: Mll
         ws = MllWorkspace(B, n, want_grad, K.device, dt)
     fn = _lib.lib().volt_mll_step_f32 if dt == torch.float32 else _lib.lib().volt_mll_step_f64
     _lib.check(fn(K.data_ptr(), K.stride(1), K.stride(0), resid.data_ptr(), s2.data_ptr(), float(jitter), ws.out.data_ptr(),
-                  ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n, int(want_grad), _lib.stream_ptr()), "volt_mll_step")
+                  ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n, ws.flags if dt == torch.float32 else int(want_grad),
+                  _lib.stream_ptr()), "volt_mll_step")
     return ws.out, ws.alpha, ws.info
 
 
@@ -302,7 +306,7 @@ def gpcv_step(K, resid, m, Lq, y, gh_x, gh_w, ws: GpcvWorkspace | None = None, w
         K.data_ptr(), K.stride(1), K.stride(0), float(jitter), resid.data_ptr(), m.data_ptr(), Lq.data_ptr(),
         y.data_ptr(), gh_x.data_ptr(), gh_w.data_ptr(), gh_x.numel(), float(min_var), float(min_scale), float(w_ell), float(w_kl),
         ws.out.data_ptr(), ws.grad_m.data_ptr(), ws.grad_mu.data_ptr(), ws.grad_Lq.data_ptr(),
-        ws.grad_K.data_ptr() if want_dk else None, ws.info.data_ptr(), ws.ptr, B, n, _lib.stream_ptr()),
+        ws.grad_K.data_ptr() if want_dk else None, ws.info.data_ptr(), ws.ptr, B, n, _lib.WS_INITIALISED, _lib.stream_ptr()),
         "volt_gpcv_step")
     return ws
 

@@ -103,7 +103,7 @@ class _Snapshot:
                 t.copy_(s)
 
 
-def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, scale=1.0, warm=3, defer=False):
+def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, scale=1.0, warm=3, defer=False, agree=None):
     """``train_iters`` times: zero_grad -> ``iteration()`` (forward + backward, returns the loss) -> print every 50th
     -> optimizer.step() -- the body of train_utils.py:243-254 and its siblings.
 
@@ -114,8 +114,15 @@ def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, sc
     iterations are replayed with the per-step check -- the trajectory is the plain loop's, without its host round trips.
     graph=True: after `warm` eager iterations ONE iteration (every HIP launch of the step, the torch glue, the Adam
     update) is captured into a hipGraph and replayed; a failed factorisation inside the replays is answered the same
-    way: restore the post-warm-up snapshot and finish eagerly with the ladder."""
+    way: restore the post-warm-up snapshot and finish eagerly with the ladder.
+    ``agree`` (distributed loops): maps this rank's "a factorisation failed" to the job's (an all-reduce MAX), so that
+    EVERY rank replays the same stretch -- a replayed iteration issues the step's collective again, and a rank-local
+    decision would pair iterations up with the wrong partner and leave an unmatched all-reduce at the end."""
     loss = None
+
+    def any_bad():
+        bad = chk.any_bad()
+        return agree(bad) if agree is not None else bad
 
     def one(i):
         nonlocal loss
@@ -163,7 +170,7 @@ def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, sc
                 if printing and i % PRINT_EVERY == 0:
                     print('Iter %d/%d - Loss: %.3f' % (i + 1, train_iters, static_loss.item() * scale))
             loss = static_loss
-            if chk.any_bad():
+            if any_bad():
                 warnings.warn("a factorisation failed inside the captured loop: rerunning it eagerly with the jitter ladder",
                               gp.NumericalWarning)
                 replay_eagerly(warm, train_iters)
@@ -173,7 +180,7 @@ def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, sc
             hi = min(i + CHECK_EVERY, train_iters)
             for j in range(i, hi):
                 one(j)
-            if chk.any_bad():                                         # the only host read of this stretch
+            if any_bad():                                             # the only host read of this stretch
                 replay_eagerly(snap.it, hi)
             if hi < train_iters:
                 snap.take(hi)
@@ -196,8 +203,11 @@ def _capture_pays(target):
     return batch * ((n + 127) // 128 + 1) < 700
 
 
+_WARNED_NO_CAPTURE = False
+
+
 def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=False, defer=False, batched=False,
-               post_backward=None, scale=1.0):
+               post_backward=None, scale=1.0, agree=None):
     """Adam on -mll(model(train_x), target); a batched model's per-series losses are summed for ONE backward (the
     series are independent and Adam is elementwise, so every series gets its own loop's update)."""
     model.train()
@@ -205,7 +215,14 @@ def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, gr
     if graph and not _capture_pays(target):
         # A step whose launches fill the chip is not launch-bound: capturing it buys nothing and costs the second stream
         # group the library runs such batches in (64 x 4096: 25.9 ms per captured iteration against 22.5 eager).  The
-        # request is honoured where it pays; otherwise the loop runs eagerly with the deferred check.
+        # request is honoured where it pays; otherwise the loop runs eagerly with the deferred check -- and says so, once.
+        global _WARNED_NO_CAPTURE
+        if not _WARNED_NO_CAPTURE:
+            _WARNED_NO_CAPTURE = True
+            n_ = target.shape[-1]
+            warnings.warn(f"graph=True declined for {target.numel() // max(n_, 1)} x N={n_}: a step whose launches fill the "
+                          "chip is not launch-bound, and captured it loses the library's second stream group (+14 % at 64 x "
+                          "4096); running eagerly with the deferred info check instead", RuntimeWarning, stacklevel=3)
         graph, defer = False, True
     optimizer = _adam([{'params': params}], lr, graph)
     mll = ExactMarginalLogLikelihood(lh, model)
@@ -220,7 +237,7 @@ def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, gr
             return post_backward(loss)
         return loss
 
-    _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=scale, defer=defer)
+    _run_iterations(iteration, optimizer, train_iters, printing, graph, scale=scale, defer=defer, agree=agree)
     return last.get("losses")
 
 
@@ -335,12 +352,15 @@ def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_it
 
 
 def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, printing=False, process_group=None,
-                         shared_noise=False, mean_func="ewma", theta=0.5, graph=False, defer=True):
+                         shared_noise=False, mean_func="ewma", theta=0.5, graph=False, defer=True, reduce_across_ranks=True):
     """B independent series in one batched model (train_y [B,N] raw prices[1:], vol_path [B,N]).  Per-series raw_noise
     by default (each series is its own GP, as in the reference's loop over tickers); ``shared_noise`` ties one
     likelihood across series AND ranks, whose gradient is then all-reduced.  ``mean_func`` as in
     TrainVoltMagpieModel; constant / loglinear / linear means get one parameter set PER SERIES.  The per-step ``info``
-    read-back is deferred (``defer``, see _run_iterations); ``graph=True`` captures the iteration (single process only).
+    read-back is deferred (``defer``, see _run_iterations; under torch.distributed the "replay?" decision is taken
+    collectively); ``graph=True`` captures the iteration (single process only: with ranks it falls back to the eager loop
+    with a warning).  ``reduce_across_ranks=False`` keeps the fit rank-local even when torch.distributed is up -- no
+    collective at all -- for callers whose ranks run DIFFERENT numbers of fits (the sharded forecast drivers).
     Returns (model, likelihood, last per-series losses)."""
     from . import distributed as vdist
     B = train_y.shape[0]
@@ -351,9 +371,14 @@ def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, pri
     if mean_func.lower() != "ewma":
         _set_mean(model, mean_func, train_x, log_y, k, theta, torch.Size([B]))
     params = _train_noise_and_mean(model, lh)
-    distributed = vdist._dist() is not None and vdist._dist().get_world_size(process_group) > 1
+    distributed = (reduce_across_ranks and vdist._dist() is not None
+                   and vdist._dist().get_world_size(process_group) > 1)
+    if shared_noise and not reduce_across_ranks and vdist._dist() is not None and vdist._dist().get_world_size(process_group) > 1:
+        raise ValueError("TrainVoltMagpieBatch: shared_noise ties the likelihood across ranks and needs reduce_across_ranks=True")
     if graph and distributed:
-        raise ValueError("TrainVoltMagpieBatch: graph=True is for single-process runs (the all-reduce stays eager)")
+        warnings.warn("TrainVoltMagpieBatch: graph=True is for single-process runs (the all-reduce stays eager); running the "
+                      "eager loop with the deferred check", RuntimeWarning, stacklevel=2)
+        graph = False
     count = torch.tensor(float(B), device=dev)
 
     def reduce(loss):                                     # the path's one collective: summed loss (and a shared gradient)
@@ -364,6 +389,18 @@ def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, pri
             vdist.all_reduce_(lh.raw_noise.grad, process_group)
         return total[0] / total[1]
 
+    def agree(bad):                                       # every rank replays, or none does (see _run_iterations)
+        flag = torch.tensor([1.0 if bad else 0.0], device=dev)
+        vdist._dist().all_reduce(flag, op=vdist._dist().ReduceOp.MAX, group=process_group)
+        return bool(flag.item() > 0)
+
     losses = _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph, defer=defer and not graph,
-                        batched=True, post_backward=reduce)
+                        batched=True, post_backward=reduce, agree=agree if distributed else None)
     return model, lh, losses                                          # None for train_iters = 0 (GPGenerator.py:89-92)
+
+
+def __getattr__(name):                                   # TrainBasicModel (voltron/train_utils.py:146-189): out of scope, but
+    if name == "TrainBasicModel":                        # experiments/stocks/GenerateMultiMeanPreds.py:18 imports it
+        from ._out_of_scope import resolve
+        return resolve(name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
