@@ -21,7 +21,12 @@ What the reference builds there (citations under /root/reference):
   ``num_gauss_hermite_locs(75)``, Adam lr 0.01   ``train_utils.py:37-58``
 * the readout ``likelihood(model(train_x)).scale.mean(0)``   ``train_utils.py:60-63``
 
-PINNING STATUS: **parity unpinned.**  The arithmetic of the ELBO lives in gpytorch
+PINNING STATUS: **reference-owned parts pinned; ELBO arithmetic unpinned.**  ``scaled_returns``, ``bm_cov``,
+``init_variational`` (running std, clamped inverse Hessian, S = L (L'HL + I)^-1 L', 10 chol(S), the mean constant)
+and the "exp" likelihood's scale are checked against ``tests/golden/gpcv.npz``, which
+``tests/golden/make_golden_gpcv.py`` produces by EXECUTING the reference's own
+``initialize_variational_parameters``, ``VolatilityGaussianLikelihood.forward`` and ``BMKernel.forward`` behind
+dense stand-ins for the gpytorch names they import.  The arithmetic of the ELBO lives in gpytorch
 (``UnwhitenedVariationalStrategy``, ``CholeskyVariationalDistribution``, ``VariationalELBO``,
 ``GaussHermiteQuadrature1D``, the MVN-MVN KL) and botorch (``GPyTorchModel``); neither is vendored
 in /root/reference nor installed (setup.py:19 ``gpytorch>=1.0.1``, no pin), and the reference's two

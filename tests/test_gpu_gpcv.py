@@ -115,6 +115,43 @@ def test_initialize_variational_parameters_matches_oracle():
     assert float((cov_h - cov_r).abs().max() / cov_r.abs().max()) < 5e-4
 
 
+@pytest.mark.parametrize("tag", ["n60_f64", "n120_f64", "n90_f32", "n80_wind_f64"])
+def test_start_up_matches_the_reference_code(golden, tag):
+    """The HIP-backed initialize_variational_parameters, BMKernel and the "exp" likelihood against tests/golden/gpcv.npz --
+    outputs of the reference's OWN code for them (single_task_variational_gp.py:204-254, BMKernel.py:38-52,
+    volatility_likelihood.py:42-50, executed by tests/golden/make_golden_gpcv.py).  The product computes in fp32: mean and
+    constant 1e-5, the covariance the factor stands for 2e-3 (its condition number is > 1e6)."""
+    from volt_amd.kernels import BMKernel
+    from volt_amd.likelihoods import VolatilityGaussianLikelihood
+    from volt_amd.models import SingleTaskVariationalGP
+    from volt_amd import gp
+    g = golden("gpcv")
+    x = torch.tensor(g[f"{tag}_x"]).float().cuda()
+    yy = torch.tensor(g[f"{tag}_y"]).float().cuda()
+    lh = VolatilityGaussianLikelihood(param="exp")
+    kern = BMKernel().cuda()
+    assert abs(float(kern.vol) - float(g[f"{tag}_vol"])) < 1e-6
+    from volt_amd.gp import _dense
+    kuu = _dense(kern(x.view(-1, 1))).cpu().double()
+    kg = torch.tensor(g[f"{tag}_kuu"]).double()
+    assert float((kuu - kg).abs().max()) <= 1e-6 * float(kg.abs().max())
+    model = SingleTaskVariationalGP(init_points=x.view(-1, 1), likelihood=lh, use_piv_chol_init=False,
+                                    mean_module=gp.ConstantMean(), covar_module=kern,
+                                    learn_inducing_locations=False, use_whitened_var_strat=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model.initialize_variational_parameters(lh, x, y=yy)
+    d = model.variational_strategy._variational_distribution
+    assert float((d.variational_mean.detach().cpu().double() - torch.tensor(g[f"{tag}_mean"]).double()).abs().max()) < 1e-5
+    assert abs(float(model.mean_module.constant.detach()) - float(g[f"{tag}_const"].reshape(-1)[0])) < 1e-5
+    S_hip, S_ref = d.chol_variational_covar.cpu().double(), torch.tensor(g[f"{tag}_chol"]).double()
+    cov_h, cov_r = S_hip @ S_hip.mT, S_ref @ S_ref.mT
+    assert float((cov_h - cov_r).abs().max() / cov_r.abs().max()) < 2e-3
+    f = torch.tensor(g["lik_f"]).cuda()
+    assert torch.allclose(lh.forward(f).scale.cpu(), torch.tensor(g["lik_scale"]), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("kernel", ["bm", "fbm"])
 def test_learn_gpcv_tracks_oracle(kernel):
     """40 Adam iterations of LearnGPCV (train_utils.py:15-67) against the fp64 oracle loop.  Adam's first steps are

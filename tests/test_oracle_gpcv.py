@@ -120,3 +120,46 @@ def test_learn_gpcv_recovers_the_volatility_path_shape():
     vol, _ = GO.learn_gpcv(x, torch.tensor(F), train_iters=60, eps=torch.zeros(1, n), record=rec)
     assert rec[-1] < rec[0] and np.isfinite(rec).all()
     assert vol.shape == (n,) and bool((vol > 0).all())
+
+
+# ---- the reference-owned half of the stage, pinned (round 4): tests/golden/gpcv.npz is produced by EXECUTING
+# voltron/models/single_task_variational_gp.py:204-254, voltron/likelihoods/volatility_likelihood.py:42-50 and
+# voltron/kernels/BMKernel.py:38-52 (tests/golden/make_golden_gpcv.py); the ELBO arithmetic (gpytorch's) stays unpinned.
+import os
+
+import pytest
+
+_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpcv.npz")
+
+
+@pytest.mark.parametrize("tag,tol", [("n60_f64", 1e-8), ("n120_f64", 1e-8), ("n80_wind_f64", 1e-8), ("n90_f32", 2e-3)])
+def test_oracle_start_up_matches_the_reference_code(tag, tol):
+    """oracle init_variational / bm_cov / scaled_returns against the outputs of the reference's own
+    initialize_variational_parameters and BMKernel.forward on the same prices.  fp64 fixtures to 1e-8; the fp32 one (the
+    dtype the reference runs in) to 2e-3 on the covariance the factor stands for -- the start-up covariance has condition
+    number > 1e6 (K[0,0] = 0 is pure jitter), two fp32 LAPACK orders differ by that much."""
+    g = np.load(_GOLD)
+    x, prices = torch.tensor(g[f"{tag}_x"]), torch.tensor(g[f"{tag}_prices"])
+    yy = GO.scaled_returns(x, prices)
+    assert torch.allclose(yy, torch.tensor(g[f"{tag}_y"]), rtol=1e-6 if "f32" in tag else 1e-12, atol=0)
+    kuu = GO.bm_cov(x, torch.tensor(float(g[f"{tag}_vol"]), dtype=x.dtype))
+    assert torch.allclose(kuu, torch.tensor(g[f"{tag}_kuu"]), rtol=1e-6 if "f32" in tag else 1e-12, atol=0)
+    f, S_root, c0 = GO.init_variational(x, yy, vol=float(g[f"{tag}_vol"]))
+    fm = torch.tensor(g[f"{tag}_mean"])
+    assert float((f - fm).abs().max()) <= (1e-5 if "f32" in tag else 1e-12)
+    assert abs(float(c0) - float(g[f"{tag}_const"].reshape(-1)[0])) <= (1e-5 if "f32" in tag else 1e-12)
+    Sg = torch.tensor(g[f"{tag}_chol"])
+    cov_o, cov_g = S_root @ S_root.mT, Sg @ Sg.mT
+    assert float((cov_o - cov_g).abs().max() / cov_g.abs().max()) <= tol
+    if "f64" in tag:
+        assert float((S_root - Sg).abs().max() / Sg.abs().max()) <= 1e-7          # the factor itself, too
+
+
+def test_oracle_exp_likelihood_scale_matches_the_reference_code():
+    """MIN_SCALE and the "exp" parameterisation (volatility_likelihood.py:46-50): scale = exp(f).clamp(min=1e-3), as
+    gpcv_oracle.pred_scale / elbo_terms use it."""
+    g = np.load(_GOLD)
+    for k, tol in (("", 1e-6), ("64", 1e-14)):
+        f, sc = torch.tensor(g["lik_f" + k]), torch.tensor(g["lik_scale" + k])
+        assert torch.allclose(f.exp().clamp(min=GO.MIN_SCALE), sc, rtol=tol, atol=0)
+        assert float(sc.min()) == pytest.approx(1e-3, rel=1e-6)                    # the clamp is hit in the fixture
