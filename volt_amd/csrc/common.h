@@ -176,55 +176,66 @@ __device__ __forceinline__ void frag_mma(const Frag<WL>& f, f32x16 (&acc)[4]) {
 // every one of those K roundings happens at the magnitude of A, and the factor came out 5 - 30 x further from the fp64
 // factor than the vendor's blocked right-looking potrf (scripts/acc_diag.py: the ratio grows with the block column),
 // whose trailing update rounds at that magnitude once per block step.  The fp32 MFMA itself is an exact chain of RNE
-// FMAs (scripts/ubench/mfma_round.hip), so the remedy is the order of summation: the products of SEG_CHUNKS chunks (128
-// of K) are summed from ZERO in a second accumulator set -- the first MFMAs of a segment take the constant 0 as C -- and
-// the segment is then added to the running sum (64 v_add per thread and segment).
-#ifndef VOLT_SEG_CHUNKS
-#define VOLT_SEG_CHUNKS 4
-#endif
-#ifndef VOLT_SEG_TRI
-#define VOLT_SEG_TRI 1
-#endif
-#ifndef VOLT_SEG_SQ
-#define VOLT_SEG_SQ 1
-#endif
-constexpr int SEG_CHUNKS = VOLT_SEG_CHUNKS;
+// FMAs (scripts/ubench/mfma_round.hip), so the remedy is the order of summation: the products of 4 chunks (128 of K)
+// are summed from ZERO in a second accumulator set -- the first MFMAs of a segment take the constant 0 as C -- and the
+// segment is then added to the running sum (64 v_add per thread and segment, in the shadow of MFMAs: below).
+constexpr int SEG_CHUNKS = 4;                  // TS / BK: every K range handed to the pipelines below is a multiple of it
 __device__ __forceinline__ f32x16 zero16c() {
     f32x16 z;
 #pragma unroll
     for (int q = 0; q < 16; ++q) z[q] = 0.f;
     return z;
 }
-// K sub-step 0 of a fragment set into accumulators that start from zero
-template <int WL>
-__device__ __forceinline__ void frag_mma_m0_zero(const Frag<WL>& f, f32x16 (&acc)[4]) {
-    const f32x16 z = zero16c();
-    if constexpr (WL == 0) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], f.b0[0], z, 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[0], f.b1[0], z, 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], f.b0[0], z, 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[0], f.b1[0], z, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[tm][0], f.b0[0], z, 0, 0, 0);
-    }
-}
-template <int WL, bool FIRST>
-__device__ __forceinline__ void frag_mma_seg(const Frag<WL>& f, f32x16 (&acc)[4]) {
-    if constexpr (FIRST) {
-        frag_mma_m0_zero<WL>(f, acc);
-#pragma unroll
-        for (int m = 1; m < 4; ++m) frag_mma_m<WL>(f, m, acc);
-    } else {
-        frag_mma<WL>(f, acc);
-    }
-}
-__device__ __forceinline__ void seg_flush(f32x16 (&T)[4], const f32x16 (&P)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) T[i] += P[i];
-}
-
 #define VOLT_SB() __builtin_amdgcn_sched_barrier(0)
+// MFMA (m, t) of a fragment set: K sub-step m, accumulator t
+template <int WL>
+__device__ __forceinline__ f32x16 frag_mma_one(const Frag<WL>& f, int m, int t, const f32x16& c) {
+    if constexpr (WL == 0) {
+        const float a = (t & 2) ? f.a1[m] : f.a0[m], b = (t & 1) ? f.b1[m] : f.b0[m];
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][m], f.b0[m], c, 0, 0, 0);
+    }
+}
+// The flush of a segment rides in the shadow of MFMAs (the adds of a quarter issue while the NEXT MFMA occupies the pipe,
+// which accepted it only when the quarter's own last MFMA was done): three quarters behind the last three MFMAs of the
+// segment, the fourth behind the first MFMA of the next one -- which is why P[3] starts as zero and is added once more
+// after the last segment.  (As one block of 32 v_pk_add_f32 between two segments the flush cost 0.9 % of the step.)
+// First 16 MFMAs of a segment: the products start from the constant 0
+template <int WL>
+__device__ __forceinline__ void seg_first_group(const Frag<WL>& f, f32x16 (&P)[4], f32x16 (&T)[4]) {
+    const f32x16 z = zero16c();
+    P[0] = frag_mma_one<WL>(f, 0, 0, z);
+    VOLT_SB();
+    T[3] += P[3];                                   // the previous segment's last quarter (zero before the first segment)
+    VOLT_SB();
+    P[1] = frag_mma_one<WL>(f, 0, 1, z);
+    P[2] = frag_mma_one<WL>(f, 0, 2, z);
+    P[3] = frag_mma_one<WL>(f, 0, 3, z);
+#pragma unroll
+    for (int m = 1; m < 4; ++m) frag_mma_m<WL>(f, m, P);
+}
+// Last 16 MFMAs of a segment
+template <int WL>
+__device__ __forceinline__ void seg_last_group(const Frag<WL>& f, f32x16 (&P)[4], f32x16 (&T)[4]) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m) frag_mma_m<WL>(f, m, P);
+    P[0] = frag_mma_one<WL>(f, 3, 0, P[0]);
+    P[1] = frag_mma_one<WL>(f, 3, 1, P[1]);
+    VOLT_SB();
+    T[0] += P[0];
+    VOLT_SB();
+    P[2] = frag_mma_one<WL>(f, 3, 2, P[2]);
+    VOLT_SB();
+    T[1] += P[1];
+    VOLT_SB();
+    P[3] = frag_mma_one<WL>(f, 3, 3, P[3]);
+    VOLT_SB();
+    T[2] += P[2];
+    VOLT_SB();
+}
+enum SegRole { SEG_MID = 0, SEG_FIRST = 1, SEG_LAST = 2 };
+
 
 // piece p (of 4) of a staging action: one row group of A and of B
 __device__ __forceinline__ void stage_store_piece(const StageRegs& s, float* __restrict__ buf, int p) {
@@ -243,22 +254,24 @@ __device__ __forceinline__ void stage_load_piece(StageRegs& s, const StageAddr& 
 // before its first use): each step's fragment reads are issued a full step (16 MFMAs = 1024 cycles) ahead, and the
 // staging traffic -- LDS write of chunk c+1 behind step 1 (`st`, if do_st), global loads of chunk c+3 behind step 2
 // (`ld`, if do_ld) -- goes out two instructions at a time between groups of four MFMAs.
-template <int WL, bool STEADY, bool FIRST = false>
-__device__ __forceinline__ void chunk_run(const float* cur, float* nxt, bool more_, Frag<WL>& F0, Frag<WL>& F1,
-                                         f32x16 (&acc)[4], StageRegs& s, bool do_st_, bool do_ld_, const StageAddr& sa,
-                                         int k_ld) {
-    // STEADY: everything is on (compile-time), so the loop body is one basic block
-    const bool more = STEADY || more_, do_st = STEADY || do_st_, do_ld = STEADY || do_ld_;
+template <int WL, bool MORE, bool ST, bool LD, int ROLE = SEG_MID>
+__device__ __forceinline__ void chunk_run(const float* cur, float* nxt, Frag<WL>& F0, Frag<WL>& F1, f32x16 (&acc)[4],
+                                         f32x16 (&run)[4], StageRegs& s, const StageAddr& sa, int k_ld) {
+    // MORE: a chunk follows (its first fragments are read behind the barrier);  ST: chunk c+1 goes from `s` into `nxt`;
+    // LD: chunk c+3 is requested into `s`.  All compile-time -- a K range is a whole number of 4-chunk segments, so every
+    // chunk's position relative to the end is known: the loop bodies are single basic blocks.  acc = the segment's
+    // products, run = the running sum they are flushed into (ROLE: first / last chunk of a segment, see seg_first_group)
     frag_load<WL>(F1, cur, 1);
     VOLT_SB();
-    frag_mma_seg<WL, FIRST>(F0, acc);
+    if constexpr (ROLE == SEG_FIRST) seg_first_group<WL>(F0, acc, run);
+    else frag_mma<WL>(F0, acc);
     VOLT_SB();
     frag_load<WL>(F0, cur, 2);
     VOLT_SB();
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         frag_mma_m<WL>(F1, m, acc);
-        if (do_st) stage_store_piece(s, nxt, m);
+        if constexpr (ST) stage_store_piece(s, nxt, m);
         VOLT_SB();
     }
     frag_load<WL>(F1, cur, 3);
@@ -267,13 +280,14 @@ __device__ __forceinline__ void chunk_run(const float* cur, float* nxt, bool mor
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         frag_mma_m<WL>(F0, m, acc);
-        if (do_ld) stage_load_piece(s, sa, so, m);
+        if constexpr (LD) stage_load_piece(s, sa, so, m);
         VOLT_SB();
     }
     __syncthreads();
-    if (more) frag_load<WL>(F0, nxt, 0);
+    if constexpr (MORE) frag_load<WL>(F0, nxt, 0);
     VOLT_SB();
-    frag_mma<WL>(F1, acc);
+    if constexpr (ROLE == SEG_LAST) seg_last_group<WL>(F1, acc, run);
+    else frag_mma<WL>(F1, acc);
     VOLT_SB();
 }
 
@@ -283,53 +297,32 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
     if (nchunks <= 0) return;
     StageRegs s0, s1;
     const StageAddr sa = stage_addr(A, lda, B, ldb);
-    stage_load_buf(s0, sa, 0);
+    stage_load_buf(s0, sa, 0);                 // (nchunks >= 4: chunks 1 and 2 exist)
     stage_store(s0, smem);
-    if (nchunks > 1) stage_load_buf(s0, sa, BK);
-    if (nchunks > 2) stage_load_buf(s1, sa, 2 * BK);
+    stage_load_buf(s0, sa, BK);
+    stage_load_buf(s1, sa, 2 * BK);
     __syncthreads();
     Frag<WL> F0, F1;
     frag_load<WL>(F0, smem, 0);
     float* b0 = smem;
     float* b1 = smem + STAGE_FLOATS;
-    f32x16 P[4];                                // the segment's products, summed from zero (two-level summation, above)
+    // two-level summation: P takes the products of one segment (4 chunks = 128 of K) from zero, acc is the running sum.
+    // nchunks is a multiple of 4 at every call site ((kb1 - kb0) * TS / BK).
+    f32x16 P[4];
+    P[3] = zero16c();
     int c = 0;
-#if VOLT_SEG_SQ
-    for (; c + SEG_CHUNKS + 4 <= nchunks; c += SEG_CHUNKS) {   // steady state: every load / store / next-chunk read exists
-        chunk_run<WL, true, true>(b0, b1, true, F0, F1, P, s0, true, true, sa, (c + 3) * BK);
-        chunk_run<WL, true>(b1, b0, true, F0, F1, P, s1, true, true, sa, (c + 4) * BK);
-#pragma unroll
-        for (int u = 2; u < SEG_CHUNKS; u += 2) {
-            chunk_run<WL, true>(b0, b1, true, F0, F1, P, s0, true, true, sa, (c + u + 3) * BK);
-            chunk_run<WL, true>(b1, b0, true, F0, F1, P, s1, true, true, sa, (c + u + 4) * BK);
-        }
-        seg_flush(acc, P);
+    for (; c + SEG_CHUNKS < nchunks; c += SEG_CHUNKS) {        // every segment but the last: all loads / stores / reads exist
+        chunk_run<WL, true, true, true, SEG_FIRST>(b0, b1, F0, F1, P, acc, s0, sa, (c + 3) * BK);
+        chunk_run<WL, true, true, true>(b1, b0, F0, F1, P, acc, s1, sa, (c + 4) * BK);
+        chunk_run<WL, true, true, true>(b0, b1, F0, F1, P, acc, s0, sa, (c + 5) * BK);
+        chunk_run<WL, true, true, true, SEG_LAST>(b1, b0, F0, F1, P, acc, s1, sa, (c + 6) * BK);
     }
-    for (; c < nchunks; c += SEG_CHUNKS) {      // the last segment (and any chunk count that is not a multiple of it)
-        // chunk c (b0): write chunk c+1 (s0) into b1, request chunk c+3 into s0
-        chunk_run<WL, false, true>(b0, b1, c + 1 < nchunks, F0, F1, P, s0, c + 1 < nchunks, c + 3 < nchunks, sa, (c + 3) * BK);
-        // chunk c+1 (b1): write chunk c+2 (s1) into b0, request chunk c+4 into s1
-        if (c + 1 < nchunks)
-            chunk_run<WL, false>(b1, b0, c + 2 < nchunks, F0, F1, P, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
-        for (int u = 2; u < SEG_CHUNKS && c + u < nchunks; u += 2) {
-            chunk_run<WL, false>(b0, b1, c + u + 1 < nchunks, F0, F1, P, s0, c + u + 1 < nchunks, c + u + 3 < nchunks, sa, (c + u + 3) * BK);
-            if (c + u + 1 < nchunks)
-                chunk_run<WL, false>(b1, b0, c + u + 2 < nchunks, F0, F1, P, s1, c + u + 2 < nchunks, c + u + 4 < nchunks, sa, (c + u + 4) * BK);
-        }
-        seg_flush(acc, P);
-    }
-#else
-    (void)P;
-    for (; c + 4 < nchunks; c += 2) {           // steady state: every load / store / next-chunk read exists
-        chunk_run<WL, true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
-        chunk_run<WL, true>(b1, b0, true, F0, F1, acc, s1, true, true, sa, (c + 4) * BK);
-    }
-    for (; c + 1 < nchunks; c += 2) {           // the last <= 4 chunks
-        chunk_run<WL, false>(b0, b1, true, F0, F1, acc, s0, true, c + 3 < nchunks, sa, (c + 3) * BK);
-        chunk_run<WL, false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
-    }
-    if (c < nchunks) chunk_run<WL, false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
-#endif
+    // the last segment: chunk c+3 is the last to be requested, chunk c+3 the last to be stored
+    chunk_run<WL, true, true, true, SEG_FIRST>(b0, b1, F0, F1, P, acc, s0, sa, (c + 3) * BK);
+    chunk_run<WL, true, true, false>(b1, b0, F0, F1, P, acc, s1, sa, 0);
+    chunk_run<WL, true, true, false>(b0, b1, F0, F1, P, acc, s0, sa, 0);
+    chunk_run<WL, false, false, false, SEG_LAST>(b1, b0, F0, F1, P, acc, s1, sa, 0);
+    acc[3] += P[3];                            // the last segment's last quarter
     __syncthreads();                           // smem is free for reuse on return
 }
 
@@ -366,10 +359,12 @@ struct TriSrc {
     int n1, nall;
 };
 
-// PH1: the chunk is known (at compile time) to be a phase-1 chunk -- the steady state; otherwise decided at run time
-template <bool PH1 = false>
+// KIND (compile time): 1 = a phase-1 chunk (both operands), 2 = a W chunk (B operand only, chunk index c - n1), 0 = nothing;
+// -1 = decided at run time from c (the prologue)
+template <int KIND = -1>
 __device__ __forceinline__ void tri_load_piece(StageRegs& s, const TriSrc& ts, int c, int p) {
-    if (PH1 || c < ts.n1) {
+    if constexpr (KIND == 0) return;
+    if (KIND == 1 || (KIND < 0 && c < ts.n1)) {
         const int sa = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pa);
         const int sb = __builtin_amdgcn_readfirstlane(c * BK * 4 + p * ts.pb);
         s.a[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.ra, ts.va, sa, 0));
@@ -379,44 +374,48 @@ __device__ __forceinline__ void tri_load_piece(StageRegs& s, const TriSrc& ts, i
         s.b[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ts.rw, ts.vw, so, 0));
     }
 }
-template <bool PH1 = false>
+template <int KIND = -1>
 __device__ __forceinline__ void tri_store_piece(const StageRegs& s, float* __restrict__ buf, const TriSrc& ts, int c, int p) {
+    if constexpr (KIND == 0) return;
     const int t = threadIdx.x;
     const int row = t >> 3, cq = (t & 7) * 4;
-    if (PH1 || c < ts.n1) *reinterpret_cast<f32x4*>(buf + (row + 32 * p) * SLD + cq) = s.a[p];
+    if (KIND == 1 || (KIND < 0 && c < ts.n1)) *reinterpret_cast<f32x4*>(buf + (row + 32 * p) * SLD + cq) = s.a[p];
     *reinterpret_cast<f32x4*>(buf + TS * SLD + (row + 32 * p) * SLD + cq) = s.b[p];
 }
 
 // phase-1 chunk `c` living in `cur`: stores chunk c+1 (from `s`) into `nxt`, requests chunk c+3 into `s`
-template <bool STEADY, bool FIRST = false>
+// MORE: the next chunk is a phase-1 chunk too (Frag<1> reads behind the barrier);  STK / LDK: what chunk c+1 (stored from
+// `s` into `nxt`) and chunk c+3 (requested into `s`) are -- 1 a phase-1 chunk, 2 a W chunk, 0 nothing.  Compile-time, like
+// chunk_run's flags: phase 1 is a whole number of segments, so every chunk knows where it stands relative to the W chunks.
+template <bool MORE, int STK, int LDK, int ROLE = SEG_MID>
 __device__ __forceinline__ void tri_chunk_p1(const float* cur, float* nxt, int c, Frag<1>& F0, Frag<1>& F1,
-                                             f32x16 (&T)[4], StageRegs& s, const TriSrc& ts) {
-    const bool more = STEADY || (c + 1 < ts.n1);               // is the next chunk a phase-1 chunk (Frag<1> reads)?
-    const bool do_st = STEADY || (c + 1 < ts.nall), do_ld = STEADY || (c + 3 < ts.nall);
+                                             f32x16 (&P)[4], f32x16 (&T)[4], StageRegs& s, const TriSrc& ts) {
     frag_load<1>(F1, cur, 1);
     VOLT_SB();
-    frag_mma_seg<1, FIRST>(F0, T);
+    if constexpr (ROLE == SEG_FIRST) seg_first_group<1>(F0, P, T);
+    else frag_mma<1>(F0, P);
     VOLT_SB();
     frag_load<1>(F0, cur, 2);
     VOLT_SB();
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        frag_mma_m<1>(F1, m, T);
-        if (do_st) tri_store_piece<STEADY>(s, nxt, ts, c + 1, m);
+        frag_mma_m<1>(F1, m, P);
+        tri_store_piece<STK>(s, nxt, ts, c + 1, m);
         VOLT_SB();
     }
     frag_load<1>(F1, cur, 3);
     VOLT_SB();
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        frag_mma_m<1>(F0, m, T);
-        if (do_ld) tri_load_piece<STEADY>(s, ts, c + 3, m);
+        frag_mma_m<1>(F0, m, P);
+        tri_load_piece<LDK>(s, ts, c + 3, m);
         VOLT_SB();
     }
     __syncthreads();
-    if (more) frag_load<1>(F0, nxt, 0);
+    if constexpr (MORE) frag_load<1>(F0, nxt, 0);
     VOLT_SB();
-    frag_mma<1>(F1, T);
+    if constexpr (ROLE == SEG_LAST) seg_last_group<1>(F1, P, T);
+    else frag_mma<1>(F1, P);
     VOLT_SB();
 }
 
@@ -454,7 +453,7 @@ __device__ __forceinline__ void tri_chunk_p2(const float* cur, float* nxt, f32x1
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         fragw_mma_m(G1, T[TP], TP, 1, m, O);
-        if (TP < 3) tri_store_piece(s, nxt, ts, c + 1, m);
+        if (TP < 3) tri_store_piece<2>(s, nxt, ts, c + 1, m);
         VOLT_SB();
     }
     fragw_load(G1, cur, TP, 3);
@@ -462,7 +461,7 @@ __device__ __forceinline__ void tri_chunk_p2(const float* cur, float* nxt, f32x1
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         fragw_mma_m(G0, T[TP], TP, 2, m, O);
-        if (TP == 0) tri_load_piece(s, ts, c + 3, m);           // only chunk n1+3 is still to be requested
+        if (TP == 0) tri_load_piece<2>(s, ts, c + 3, m);        // only chunk n1+3 is still to be requested
         VOLT_SB();
     }
     __syncthreads();
@@ -545,39 +544,24 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     int c = 0;
     if (t.n1 > 0) {
         // two-level summation (see SEG_CHUNKS): O, idle until phase 2, takes the products of one segment (4 chunks = 128
-        // of K) from zero; the segment is then added to T.  n1 is a multiple of 4.
+        // of K) from zero; the segment is added to T in the shadow of its last MFMAs.  n1 is a multiple of 4.
         Frag<1> F0, F1;
         frag_load<1>(F0, b0, 0);
-#if VOLT_SEG_TRI
-        for (; c + SEG_CHUNKS + 4 <= t.n1; c += SEG_CHUNKS) {     // steady state: phase-1 chunks whose prefetches are phase-1 too
-            tri_chunk_p1<true, true>(b0, b1, c, F0, F1, O, s0, ts);
-            tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, O, s1, ts);
-#pragma unroll
-            for (int u = 2; u < SEG_CHUNKS; u += 2) {
-                tri_chunk_p1<true>(b0, b1, c + u, F0, F1, O, s0, ts);
-                tri_chunk_p1<true>(b1, b0, c + u + 1, F0, F1, O, s1, ts);
-            }
-            seg_flush(T, O);
+        O[3] = zero16c();
+        for (; c + SEG_CHUNKS < t.n1; c += SEG_CHUNKS) {          // every segment but the last: its prefetches are phase-1 chunks too
+            tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, O, T, s0, ts);
+            tri_chunk_p1<true, 1, 1>(b1, b0, c + 1, F0, F1, O, T, s1, ts);
+            tri_chunk_p1<true, 1, 1>(b0, b1, c + 2, F0, F1, O, T, s0, ts);
+            tri_chunk_p1<true, 1, 1, SEG_LAST>(b1, b0, c + 3, F0, F1, O, T, s1, ts);
         }
-        for (; c < t.n1; c += 4) {                   // last chunks of phase 1: the W chunks come into view
-            if (t.flag && c == t.n1 - 4) ok = flag_wait_one_lane(t.flag, t.want);   // barriers below order the acquire
-            tri_chunk_p1<false, true>(b0, b1, c, F0, F1, O, s0, ts);
-            tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, O, s1, ts);
-            tri_chunk_p1<false>(b0, b1, c + 2, F0, F1, O, s0, ts);
-            tri_chunk_p1<false>(b1, b0, c + 3, F0, F1, O, s1, ts);
-            seg_flush(T, O);
-        }
-#else
-        for (; c + 4 < t.n1; c += 2) {               // steady state: phase-1 chunks whose prefetches are phase-1 too
-            tri_chunk_p1<true>(b0, b1, c, F0, F1, T, s0, ts);
-            tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
-        }
-        for (; c < t.n1; c += 2) {                   // last 4 chunks of phase 1: the W chunks come into view
-            if (t.flag && c == t.n1 - 4) ok = flag_wait_one_lane(t.flag, t.want);   // barriers below order the acquire
-            tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
-            tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
-        }
-#endif
+        // the last segment of phase 1: the W chunks (n1 .. n1+3) come into view
+        if (t.flag) ok = flag_wait_one_lane(t.flag, t.want);      // barriers below order the acquire
+        tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, O, T, s0, ts);
+        tri_chunk_p1<true, 1, 2>(b1, b0, c + 1, F0, F1, O, T, s1, ts);
+        tri_chunk_p1<true, 1, 2>(b0, b1, c + 2, F0, F1, O, T, s0, ts);
+        tri_chunk_p1<false, 2, 2, SEG_LAST>(b1, b0, c + 3, F0, F1, O, T, s1, ts);
+        c += SEG_CHUNKS;
+        T[3] += O[3];                                // the last segment's last quarter
     }
     zero_acc(O);
     // phase 2: chunks n1 .. n1+3 (n1 is even: chunk n1 sits in buffer 0)
@@ -621,35 +605,19 @@ __device__ __forceinline__ void tri_phase1_only(const TriTile& t, f32x16 (&T)[4]
     Frag<1> F0, F1;
     frag_load<1>(F0, b0, 0);
     int c = 0;
-#if VOLT_SEG_TRI
     f32x16 P[4];                                     // two-level summation (see SEG_CHUNKS)
-    for (; c + SEG_CHUNKS + 4 <= t.n1; c += SEG_CHUNKS) {
-        tri_chunk_p1<true, true>(b0, b1, c, F0, F1, P, s0, ts);
-        tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, P, s1, ts);
-#pragma unroll
-        for (int u = 2; u < SEG_CHUNKS; u += 2) {
-            tri_chunk_p1<true>(b0, b1, c + u, F0, F1, P, s0, ts);
-            tri_chunk_p1<true>(b1, b0, c + u + 1, F0, F1, P, s1, ts);
-        }
-        seg_flush(T, P);
+    P[3] = zero16c();
+    for (; c + SEG_CHUNKS < t.n1; c += SEG_CHUNKS) {
+        tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, P, T, s0, ts);
+        tri_chunk_p1<true, 1, 1>(b1, b0, c + 1, F0, F1, P, T, s1, ts);
+        tri_chunk_p1<true, 1, 1>(b0, b1, c + 2, F0, F1, P, T, s0, ts);
+        tri_chunk_p1<true, 1, 1, SEG_LAST>(b1, b0, c + 3, F0, F1, P, T, s1, ts);
     }
-    for (; c < t.n1; c += 4) {
-        tri_chunk_p1<false, true>(b0, b1, c, F0, F1, P, s0, ts);
-        tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, P, s1, ts);
-        tri_chunk_p1<false>(b0, b1, c + 2, F0, F1, P, s0, ts);
-        tri_chunk_p1<false>(b1, b0, c + 3, F0, F1, P, s1, ts);
-        seg_flush(T, P);
-    }
-#else
-    for (; c + 4 < t.n1; c += 2) {
-        tri_chunk_p1<true>(b0, b1, c, F0, F1, T, s0, ts);
-        tri_chunk_p1<true>(b1, b0, c + 1, F0, F1, T, s1, ts);
-    }
-    for (; c < t.n1; c += 2) {
-        tri_chunk_p1<false>(b0, b1, c, F0, F1, T, s0, ts);
-        tri_chunk_p1<false>(b1, b0, c + 1, F0, F1, T, s1, ts);
-    }
-#endif
+    tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, P, T, s0, ts);      // the last segment: nothing follows it
+    tri_chunk_p1<true, 1, 0>(b1, b0, c + 1, F0, F1, P, T, s1, ts);
+    tri_chunk_p1<true, 1, 0>(b0, b1, c + 2, F0, F1, P, T, s0, ts);
+    tri_chunk_p1<false, 0, 0, SEG_LAST>(b1, b0, c + 3, F0, F1, P, T, s1, ts);
+    T[3] += P[3];
     __syncthreads();                                 // smem is free for reuse on return
 }
 

@@ -54,7 +54,7 @@ struct GemmArgs {
     float* frob;
 };
 
-__global__ __launch_bounds__(NT) void gemm_nt_struct_kernel(GemmArgs g, int nbatch) {
+__global__ __launch_bounds__(NT, 2) void gemm_nt_struct_kernel(GemmArgs g, int nbatch) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     int tile, b;
     decode_tile_batch(g.mt * g.nt, nbatch, tile, b);
