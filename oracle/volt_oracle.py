@@ -72,6 +72,15 @@ def cumtrapz(y: np.ndarray, x: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------- a2
+def volatility_kernel_last_dim_is_batch(x: np.ndarray, vol_path: np.ndarray, diag: bool = False) -> np.ndarray:
+    """VolKernel.py:24-26,35-40 (``last_dim_is_batch=True``; "TODO: check this" in the reference, mirrored as written):
+    vol_path [N, D] is transposed, K [D,N,N] permuted to [N,N,D]; with ``diag`` the diagonal of THAT over its last two
+    dims, i.e. out[i, d] = V[d, min(i, d)] for d < min(N, D)."""
+    K = volatility_kernel(x, np.swapaxes(np.asarray(vol_path), -1, -2))          # [D,N,N]
+    res = np.transpose(K, (1, 2, 0))
+    return np.diagonal(res, axis1=-2, axis2=-1).copy() if diag else res
+
+
 def volatility_kernel(x: np.ndarray, vol_path: np.ndarray, diag: bool = False) -> np.ndarray:
     """VolKernel.py:18-42.  K[..., i, j] = V[..., min(i, j)], V = cumtrapz(vol^2, x).
     The second argument is the volatility path, not a second set of inputs."""

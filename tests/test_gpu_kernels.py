@@ -239,6 +239,18 @@ def test_mll_step_baseline_batches_properties(ops, B, n):
     assert torch.allclose(a2, a[perm], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["n12d3", "n9d9", "n5d8", "n130d2"])
+def test_last_dim_is_batch_golden_bit_exact(ops, golden, tag):
+    """VolatilityKernel.forward(..., last_dim_is_batch=True) with and without diag (VolKernel.py:24-26,35-40) against the
+    reference's own outputs (tests/golden/fill_ldb.npz): bit-exact."""
+    from volt_amd.kernels import VolatilityKernel
+    g = golden("fill_ldb")
+    x, vol = dev(g[f"{tag}_x"]), dev(g[f"{tag}_vol"])
+    kern = VolatilityKernel()
+    assert np.array_equal(kern.forward(x, vol, last_dim_is_batch=True).cpu().numpy(), g[f"{tag}_K"])
+    assert np.array_equal(kern.forward(x, vol, diag=True, last_dim_is_batch=True).cpu().numpy(), g[f"{tag}_diag"])
+
+
 def test_ops_refuse_cpu_tensors(ops):
     from volt_amd._lib import VoltHipError
     with pytest.raises(VoltHipError):

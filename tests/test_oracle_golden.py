@@ -121,3 +121,13 @@ def test_fp64_factor_and_solve_fixture(golden):
     np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-10 * np.abs(Lref).max())
     sol = np.linalg.solve(L.T, np.linalg.solve(L, g["rhs"]))
     np.testing.assert_allclose(sol, g["sol"], rtol=0, atol=1e-8 * np.abs(g["sol"]).max())
+
+
+@pytest.mark.parametrize("tag", ["n12d3", "n9d9", "n5d8", "n130d2"])
+def test_last_dim_is_batch_matches_the_reference_code(golden, tag):
+    """VolKernel.py:24-26,35-40 (``last_dim_is_batch``, with and without ``diag`` -- "TODO: check this" upstream, mirrored as
+    written): fixtures from the reference's own forward (tests/golden/make_golden_ldb.py), bit-exact."""
+    g = golden("fill_ldb")
+    x, vol = g[f"{tag}_x"], g[f"{tag}_vol"]
+    assert np.array_equal(vo.volatility_kernel_last_dim_is_batch(x, vol), g[f"{tag}_K"])
+    assert np.array_equal(vo.volatility_kernel_last_dim_is_batch(x, vol, diag=True), g[f"{tag}_diag"])

@@ -38,7 +38,13 @@ class VolatilityKernel(Kernel):
         vol_int = ops.cumtrapz(vol_path, x, square=True)          # CumTrapz(vol_path * vol_path, x), :28
         if diag:
             if last_dim_is_batch:
-                raise NotImplementedError("diag with last_dim_is_batch (reference marks this branch 'TODO: check this')")
+                # :35-40 as written: the [D,N,N] result is permuted to [N,N,D] FIRST and the diagonal is then taken over its
+                # last two dims -- entry [i, d] = V[d, min(i, d)], d < min(N, D) (the branch the reference marks "TODO: check
+                # this"; mirrored, pinned by tests/golden/fill_ldb.npz).  An O(N D) gather of V, not a fill.
+                D, N = vol_int.shape[-2], vol_int.shape[-1]
+                i = torch.arange(N, device=vol_int.device).unsqueeze(-1)
+                d = torch.arange(min(N, D), device=vol_int.device).unsqueeze(0)
+                return vol_int[d, torch.minimum(i, d)]
             return vol_int                                        # diagonal of V[min(i,j)] is V, :39-40
         res = ops.fill(vol_int)                                   # :30-33
         if last_dim_is_batch:
