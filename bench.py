@@ -618,7 +618,7 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256, dist=None, world=1, rank
     del smp_c
     alg = G * S * H * 12.0
     # VALU wave-instructions per sample-step of rollout_bordered_kernel<1,false>, from the PMC pass in profiles/r04/
-    # (scripts/pmc_rollouts.sh: SQ_INSTS_VALU / (G S H)); null when the summary is not there or is for another shape
+    # (scripts/pmc_rollout_issue.sh: SQ_INSTS_VALU / (G S H)); null when the summary is not there or is for another shape
     issue = None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "rollout_pmc.json")))
