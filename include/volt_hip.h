@@ -47,6 +47,7 @@ extern "C" {
 /* flag bits of the `flags` / `ws_flags` arguments below */
 #define VOLT_WANT_GRAD 1          /* volt_mll_step_*: also produce the gradient outputs (the triangular inverse) */
 #define VOLT_WS_INITIALISED 2     /* the workspace passed went through its *_workspace_init_f32 for this shape */
+#define VOLT_REFINE_ALPHA 4       /* volt_mll_step_f32 with VOLT_WANT_GRAD: one step of iterative refinement of alpha */
 
 /* ---- introspection ------------------------------------------------------------------------ */
 int volt_abi_version(void);                 /* bumps when a signature changes */
@@ -194,7 +195,12 @@ int volt_adam_step_f32(const void* slots, int nslots, long long total, const flo
  *     out[b,2] = z'z   out[b,3] = logdet   out[b,4] = tr K_s^-1   out[b,5] = alpha'alpha
  *     alpha[b,:] (= K_s^-1 r;  d mll / d mean = alpha / N)
  * resid [B,N] = y - mean(x).  `flags`: VOLT_WANT_GRAD -- without it the triangular inverse is skipped (forward
- * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written; VOLT_WS_INITIALISED -- see below.
+ * solve instead) and out[b,1], out[b,4], out[b,5] and alpha are not written; VOLT_WS_INITIALISED -- see below;
+ * VOLT_REFINE_ALPHA (with VOLT_WANT_GRAD, opt-in) -- alpha <- alpha + K_s^-1 (r - K_s alpha) with the residual formed
+ * against the caller's K in fp64 accumulation (BOTH triangles of K are read) and the correction solved through the
+ * fp32 factor; out[b,0], out[b,1], out[b,2], out[b,5] are recomputed from the refined alpha and out[b,7] = 1.  Takes
+ * alpha from the fp32 floor (cond * eps: 1e-5 .. 4e-5 of its max at sigma^2 = 1e-4, N = 4096, what the reference's own
+ * fp32 path has) to < 1e-6 for one more pass over K and two triangular solves (+8 % of a step at 64 x 4096).
  * workspace: volt_mll_workspace_bytes(B,N,want_grad) bytes, 256-byte aligned. */
 size_t volt_mll_workspace_bytes(int B, int N, int want_grad);
 /* Once per workspace (and again should the caller have overwritten it), asynchronously on `stream`: copies the

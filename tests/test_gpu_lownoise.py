@@ -79,6 +79,36 @@ def test_mll_step_low_noise_vs_oracle(ops, B, n, rows):
             assert err <= 3 * max(np.abs(av - ref["alpha"]).max() / amax, 2e-6), (b, raw_v[b], "alpha vs vendor")
 
 
+@pytest.mark.parametrize("B,n,raw", [(2, 4096, -11.8), (8, 2048, -9.0), (3, 1000, -11.8), (1, 4096, -9.0), (4, 399, -11.8), (64, 2048, -6.0)])
+def test_refined_alpha_at_the_noise_floor(ops, B, n, raw):
+    """VOLT_REFINE_ALPHA (opt-in): one step of iterative refinement of alpha against K with an fp64-accumulated residual.
+    Every schedule (one long series, short series in one launch, split-K, balanced, two groups) ends in the same refinement.
+    Gates: alpha within 2e-6 of max|alpha| of the fp64 oracle (unrefined: 1e-5 .. 4e-5 there, the fp32 floor), the scalars
+    recomputed from it (quad, a'a -> mll, d/d sigma2) no worse than the unrefined step's tolerances, out[:,7] = 1."""
+    x, F, vol = sde_batch(B, n)
+    Kd = ops.fill(ops.cumtrapz(torch.as_tensor(vol).cuda(), torch.as_tensor(x).cuda(), square=True))
+    y = torch.log(torch.as_tensor(F[:, 1:]).cuda())
+    ymean = y.mean(-1, keepdim=True).expand_as(y)
+    r = (y - ymean).float()
+    s2 = torch.full((B,), float(vo.noise_from_raw(raw)), dtype=torch.float32).cuda()
+    o0, a0, info = ops.mll_step(Kd, r, s2, want_grad=True)
+    o0, a0 = o0.cpu().double().numpy(), a0.cpu().double().numpy()
+    o1, a1, info = ops.mll_step(Kd, r, s2, want_grad=True, refine_alpha=True)
+    assert int(info.abs().sum()) == 0
+    o1, a1 = o1.cpu().double().numpy(), a1.cpu().double().numpy()
+    assert (o1[:, 7] == 1).all() and (o0[:, 7] == 0).all()
+    tol = TOL[raw]
+    for b in sorted({0, B - 1}):
+        ref = vo.mll_and_grads(Kd[b].cpu().numpy(), y[b].cpu().numpy(), ymean[b].cpu().numpy(), raw)
+        amax = np.abs(ref["alpha"]).max()
+        e0, e1 = np.abs(a0[b] - ref["alpha"]).max() / amax, np.abs(a1[b] - ref["alpha"]).max() / amax
+        assert e1 <= 2e-6 and e1 <= e0 + 1e-7, (b, e0, e1)
+        assert abs(o1[b, 0] - ref["mll"]) <= tol["mll"] * max(1.0, abs(ref["mll"]))
+        dsig = 0.5 * (ref["aa"] - ref["trinv"]) / n
+        assert abs(o1[b, 1] - dsig) <= tol["dsig"] * abs(dsig)
+        assert abs(o1[b, 2] - ref["quad"]) <= 1e-4 * abs(ref["quad"]) and abs(o1[b, 5] - ref["aa"]) <= 1e-4 * ref["aa"]
+
+
 def test_fuzz_schedules_vs_oracle_and_vendor(ops):
     """scripts/fuzz_sched.py's cases under pytest: random N in 2177..4096, B in 1..31, raw_noise in [-5, 1], every
     schedule of DESIGN 4.6; absolute gates vs the fp64 oracle, and the factor / alpha error relative to the vendor's fp32

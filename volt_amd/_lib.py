@@ -11,7 +11,7 @@ from .build import LIB, build_lib, source_hash, sources_present
 
 _lib = None
 ABI_VERSION = 5
-WANT_GRAD, WS_INITIALISED = 1, 2       # include/volt_hip.h: VOLT_WANT_GRAD, VOLT_WS_INITIALISED
+WANT_GRAD, WS_INITIALISED, REFINE_ALPHA = 1, 2, 4       # include/volt_hip.h: VOLT_WANT_GRAD, VOLT_WS_INITIALISED, VOLT_REFINE_ALPHA
 
 _i32, _i64, _f32, _f64, _ptr, _sz = C.c_int, C.c_int64, C.c_float, C.c_double, C.c_void_p, C.c_size_t
 

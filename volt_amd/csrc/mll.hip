@@ -113,6 +113,78 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
     }
 }
 
+// ---- optional iterative refinement of alpha (VOLT_REFINE_ALPHA, round 4) ------------------------------------------------
+// alpha <- alpha + K_s^-1 (r - K_s alpha): the residual is formed against the caller's K ITSELF with every product and the
+// row sum in fp64 (K's entries and alpha are exact fp32 numbers; an fp32-accumulated residual loses the correction in its
+// own rounding -- measured: up to 89x WORSE than no refinement at the noise floor, scripts/acc_diag.py), the correction is
+// two triangular solves against the fp32 factor.  One pass over K (both triangles are read: the refinement needs the full
+// symmetric K the reference's kernels return) -- an HBM stream, one wave per row, float4 lanes.
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+__global__ __launch_bounds__(256) void refine_resid_kernel(const float* __restrict__ K, int64_t ldk, int64_t bsk,
+                                                           const float* __restrict__ resid, const float* __restrict__ alpha,
+                                                           const float* __restrict__ sigma2, float jitter,
+                                                           float* __restrict__ r1pad, int N, int Np) {
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= Np) return;
+    if (i >= N) {
+        if (lane == 0) r1pad[(int64_t)b * Np + i] = 0.f;
+        return;
+    }
+    const float* Ki = K + (int64_t)b * bsk + (int64_t)i * ldk;
+    const float* ab = alpha + (int64_t)b * N;
+    double acc = 0.0;
+    const bool vec = ((ldk & 3) == 0) && ((bsk & 3) == 0) && (((uintptr_t)K & 15) == 0) && ((N & 3) == 0) && (((uintptr_t)alpha & 15) == 0);
+    if (vec) {
+        for (int j = lane * 4; j < N; j += 256) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(Ki + j);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ab + j);
+            acc += ((double)kv[0] * av[0] + (double)kv[1] * av[1]) + ((double)kv[2] * av[2] + (double)kv[3] * av[3]);
+        }
+    } else {
+        for (int j = lane; j < N; j += 64) acc += (double)Ki[j] * ab[j];
+    }
+    acc = wave_sum_d(acc);
+    if (lane == 0) {
+        const double s = (double)(sigma2 ? sigma2[b] : 0.f) + (double)jitter;
+        r1pad[(int64_t)b * Np + i] = (float)((double)resid[(int64_t)b * N + i] - acc - s * (double)ab[i]);
+    }
+}
+// alpha += delta, and the scalars that depend on alpha: quad = r'alpha, a'a, mll, d mll / d sigma2
+__global__ __launch_bounds__(256) void refine_finish_kernel(const float* __restrict__ delta_pad, const float* __restrict__ resid,
+                                                            float* __restrict__ alpha, float* __restrict__ out, int N, int Np) {
+    __shared__ double red[2][256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double q = 0, aa = 0;
+    for (int i = tid; i < N; i += 256) {
+        const float an = alpha[(int64_t)b * N + i] + delta_pad[(int64_t)b * Np + i];
+        alpha[(int64_t)b * N + i] = an;
+        q += (double)resid[(int64_t)b * N + i] * an;
+        aa += (double)an * an;
+    }
+    red[0][tid] = q;
+    red[1][tid] = aa;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { red[0][tid] += red[0][tid + s]; red[1][tid] += red[1][tid + s]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double LOG_2PI = 1.8378770664093453;
+        float* o = out + (int64_t)b * 8;
+        o[0] = (float)(-0.5 * (red[0][0] + (double)o[3] + N * LOG_2PI) / N);
+        o[1] = (float)(0.5 * (red[1][0] - (double)o[4]) / N);
+        o[2] = (float)red[0][0];
+        o[5] = (float)red[1][0];
+        o[7] = 1.f;                                       // marks a refined alpha
+    }
+}
+
 struct MllWs {
     float *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *zpart, *frob, *sk_slab, *apart;
     int sk_rows;
@@ -293,24 +365,35 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     const int Np = volt_padded_n(N);
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
+    bool done = false;
     if (ready && want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
         rc = volt_internal_long_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                      w.z, w.apad, w.apart, w.eslab, out, alpha, w.lng, B, N, stream);
-        if (rc == 1) return 0;
-        if (rc) return rc > 0 ? rc : -1;
+        if (rc == 1) done = true;
+        else if (rc) return rc > 0 ? rc : -1;
     }
-    if (ready && want_grad && w.small && w.apart) {           // short series: the whole step in one launch (chol.hip)
+    if (!done && ready && want_grad && w.small && w.apart) {   // short series: the whole step in one launch (chol.hip)
         rc = volt_internal_small_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                       w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
-        if (rc == 1) return 0;
-        if (rc) return rc > 0 ? rc : -1;
+        if (rc == 1) done = true;
+        else if (rc) return rc > 0 ? rc : -1;
     }
-    hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
-    TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
-    if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
-                                   want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx, w.sk_slab,
-                                   w.sk_count, w.sk_rows, ready ? w.tab : nullptr, w.tab_bytes)))
-        return rc > 0 ? rc : -1;
+    if (!done) {
+        hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
+        TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
+        if ((rc = volt_internal_factor(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info,
+                                       want_grad ? w.rpad : nullptr, w.zpart, w.frob, B, N, stream, mll_tail, &ctx, w.sk_slab,
+                                       w.sk_count, w.sk_rows, ready ? w.tab : nullptr, w.tab_bytes)))
+            return rc > 0 ? rc : -1;
+    }
+    if (want_grad && (flags & VOLT_REFINE_ALPHA)) {
+        // one step of iterative refinement (opt-in): fp64-accumulated residual against K, correction through the factor
+        hipLaunchKernelGGL(refine_resid_kernel, dim3((Np + 3) / 4, B), dim3(256), 0, s, K, ldk, bsk, resid, alpha, sigma2, jitter,
+                           w.rpad, N, Np);
+        if ((rc = volt_trsv_lower_f32(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
+        if ((rc = volt_trsv_lower_t_f32(w.A, w.Winv, w.z, w.apad, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
+        hipLaunchKernelGGL(refine_finish_kernel, dim3(B), dim3(256), 0, s, w.apad, resid, alpha, out, N, Np);
+    }
     VOLT_LAUNCH_CHECK();
     return 0;
 }

@@ -392,6 +392,27 @@ class ExactGP(Module):
 
 
 # --------------------------------------------------------------------------------------- MLL
+class refine_alpha:
+    """Opt-in context (``with gp.refine_alpha(): loss = -mll(model(x), y)``): the fp32 MLL step refines alpha = K_s^-1 (y - m)
+    by one step of iterative refinement against K itself (VOLT_REFINE_ALPHA) -- for models whose mean has trainable
+    parameters (d mll / d mean = alpha / N; voltron/train_utils.py:213-220) and that train to the noise floor, where any
+    fp32 factorisation leaves alpha at cond * eps (the reference's own path included).  Default off: the step then does
+    what the reference's fp32 path does.  Costs one more pass over K and two triangular solves per step."""
+    _on = False
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self._prev = refine_alpha._on
+        refine_alpha._on = self.on
+        return self
+
+    def __exit__(self, *exc):
+        refine_alpha._on = self._prev
+        return False
+
+
 class _ExactMLL(torch.autograd.Function):
     """mll[b] = log N(y_b; m_b, K_b + s2_b I) / N  with analytic backward:
     d/d s2 = 1/2 (a'a - tr K_s^-1)/N,  d/d m = a/N,  d/d y = -a/N,  a = K_s^-1 (y - m)."""
@@ -412,7 +433,7 @@ class _ExactMLL(torch.autograd.Function):
         noise = noise.to(dt)
         # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
         # NumericalWarning, then NotPSDError.  Same ladder here; the jitter is added inside the fused step.
-        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0)
+        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0, refine_alpha=refine_alpha._on)
         chk = deferred_checks.deferring()
         if chk is not None:
             chk.note(info)
@@ -427,7 +448,7 @@ class _ExactMLL(torch.autograd.Function):
             first = int(info[info != 0][0].item())
             for i in range(3):
                 jitter = (1e-6 if dt == torch.float32 else 1e-8) * (10 ** i)      # gpytorch's defaults per dtype
-                out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter)
+                out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter, refine_alpha=refine_alpha._on)
                 if not bool((info != 0).any().item()):
                     warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
                     break

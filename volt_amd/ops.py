@@ -217,10 +217,11 @@ class MllWorkspace:
 
 
 def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: MllWorkspace | None = None,
-             want_grad: bool = True, jitter: float = 0.0):
+             want_grad: bool = True, jitter: float = 0.0, refine_alpha: bool = False):
     """One MLL(+grad) evaluation with K resident, in K's dtype: fp32 -> volt_mll_step_f32 (v_mfma_f32_32x32x2), fp64 ->
     volt_mll_step_f64 (v_mfma_f64_16x16x4).  Returns (out [B,8], alpha [B,N], info [B]); see include/volt_hip.h for the
-    meaning of out's columns."""
+    meaning of out's columns.  ``refine_alpha`` (fp32, with want_grad; opt-in): one step of iterative refinement of alpha
+    against K itself (VOLT_REFINE_ALPHA) -- both triangles of K must hold the symmetric matrix."""
     _need_gpu(K, resid, sigma2)
     if K.ndim != 3 or K.dtype not in (torch.float32, torch.float64):
         raise ValueError("K must be [B,N,N] fp32 or fp64")
@@ -234,7 +235,8 @@ def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: Mll
         ws = MllWorkspace(B, n, want_grad, K.device, dt)
     fn = _lib.lib().volt_mll_step_f32 if dt == torch.float32 else _lib.lib().volt_mll_step_f64
     _lib.check(fn(K.data_ptr(), K.stride(1), K.stride(0), resid.data_ptr(), s2.data_ptr(), float(jitter), ws.out.data_ptr(),
-                  ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n, ws.flags if dt == torch.float32 else int(want_grad),
+                  ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n,
+                  (ws.flags | (_lib.REFINE_ALPHA if (refine_alpha and want_grad) else 0)) if dt == torch.float32 else int(want_grad),
                   _lib.stream_ptr()), "volt_mll_step")
     return ws.out, ws.alpha, ws.info
 
