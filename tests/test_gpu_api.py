@@ -576,8 +576,8 @@ def test_deferred_check_replays_a_failed_stretch(va, graph, monkeypatch):
     real = ops.mll_step
     calls = {"n": 0, "injected": 0}
 
-    def flaky(K, resid, sigma2, ws=None, want_grad=True, jitter=0.0):
-        out, alpha, info = real(K, resid, sigma2, ws, want_grad=want_grad, jitter=jitter)
+    def flaky(K, resid, sigma2, ws=None, want_grad=True, jitter=0.0, **kw):
+        out, alpha, info = real(K, resid, sigma2, ws, want_grad=want_grad, jitter=jitter, **kw)
         calls["n"] += 1
         if calls["n"] == 33 and not graph:                  # one step of the deferred stretch reports a failed pivot
             info[1] = 7

@@ -41,8 +41,8 @@ def ops():
 
 
 # 2 x 4096 (the small-batch schedules), 8 x 4096 (the metric's 8-GPU strong-scaling share: balanced schedule),
-# 64 x 2048 (BASELINE config 3: two stream groups; rows 0 / 32 / 63 reach both)
-@pytest.mark.parametrize("B,n,rows", [(2, 4096, (0, 1)), (8, 4096, (0, 7)), (64, 2048, (0, 32, 63))])
+# 64 x 2048 (BASELINE config 3: two stream groups; rows 0 / 32 / 63 reach both), 32 x 4096 (BASELINE config 4's per-GPU share)
+@pytest.mark.parametrize("B,n,rows", [(2, 4096, (0, 1)), (8, 4096, (0, 7)), (64, 2048, (0, 32, 63)), (32, 4096, (0, 31))])
 def test_mll_step_low_noise_vs_oracle(ops, B, n, rows):
     x, F, vol = sde_batch(B, n)
     Kd = ops.fill(ops.cumtrapz(torch.as_tensor(vol).cuda(), torch.as_tensor(x).cuda(), square=True))
