@@ -116,3 +116,31 @@ def test_fuzz_schedules_vs_oracle_and_vendor(ops):
     import fuzz_sched_cases as fz
     worst = fz.run(seed=4, cases=8)
     assert not fz.failures(worst), (fz.failures(worst), worst)
+
+
+def test_refine_alpha_context_improves_the_mean_gradient():
+    """``with gp.refine_alpha():`` reaches the C ABI's VOLT_REFINE_ALPHA through ExactMarginalLogLikelihood: at the noise
+    floor the gradient wrt a (trainable) mean, d mll / d m = alpha / N, gets closer to the fp64 oracle's, and the default
+    (context off) is untouched."""
+    from volt_amd import gp
+    from volt_amd.gp import ExactMarginalLogLikelihood, GaussianLikelihood, MultivariateNormal
+    B, n, raw = 2, 2048, -11.8
+    x, F, vol = sde_batch(B, n)
+    K = vo.volatility_kernel(np.repeat(x[None], B, 0)[..., None], vol[..., None])
+    y = np.log(F[:, 1:])
+    m0 = y.mean(-1, keepdims=True) + 0 * y
+    o = vo.mll_and_grads(K, y, m0, raw)
+    Kd, yd = torch.as_tensor(K).cuda(), torch.as_tensor(y).cuda()
+    errs = {}
+    for on in (False, True):
+        lh = GaussianLikelihood(batch_shape=torch.Size([B])).cuda()
+        lh.raw_noise.data.fill_(raw)
+        mean = torch.as_tensor(m0).float().cuda().requires_grad_(True)
+        with gp.refine_alpha(on):
+            val = ExactMarginalLogLikelihood(lh, None)(MultivariateNormal(mean, Kd), yd)
+            (-val.sum()).backward()
+        gm = -mean.grad.cpu().double().numpy()
+        errs[on] = float(np.abs(gm - o["d_mean"]).max() / np.abs(o["d_mean"]).max())
+        np.testing.assert_allclose(val.detach().cpu().numpy(), o["mll"], rtol=6e-5)
+    assert errs[True] <= 2e-6 and errs[True] < 0.5 * errs[False], errs
+    assert gp.refine_alpha._on is False
