@@ -80,3 +80,29 @@ def test_psd_safe_cholesky_jitter_loop():
         vo.psd_safe_cholesky(-np.eye(3, dtype=np.float32), jitter=1e-4)
     with pytest.raises(FloatingPointError):
         vo.psd_safe_cholesky(np.full((2, 2), np.nan))
+
+
+@pytest.mark.parametrize("raw", [1e-5, -4.0, -9.0])
+def test_closed_form_vs_scipy_logpdf_and_finite_differences(raw):
+    """A third, independent evaluation of row a5 (the restatement of gpytorch's ExactMarginalLogLikelihood stays unpinned:
+    gpytorch is absent): scipy.stats.multivariate_normal.logpdf -- an eigendecomposition path, no Cholesky -- for the value,
+    central differences of it for d/d raw_noise and d/d mean.  What is restated from gpytorch's published behaviour and
+    NOT checkable here: the softplus + 1e-4 noise constraint and the division by N."""
+    from scipy.stats import multivariate_normal
+    n = 96
+    _, _, K, y, mean = _problem(2, n, seed=11)
+    K, y, mean = K[0].astype(np.float64), y[0].astype(np.float64), mean[0].astype(np.float64)
+
+    def f(raw_, m_):
+        s2 = np.log1p(np.exp(raw_)) + 1e-4
+        return multivariate_normal.logpdf(y, mean=m_, cov=K + s2 * np.eye(n), allow_singular=False) / n
+
+    o = vo.mll_and_grads(K, y, mean, raw)
+    assert abs(o["mll"] - f(raw, mean)) < 1e-9 * max(1.0, abs(o["mll"]))
+    h = 1e-5
+    fd_raw = (f(raw + h, mean) - f(raw - h, mean)) / (2 * h)
+    assert abs(o["d_raw"] - fd_raw) < 1e-5 * max(1e-3, abs(fd_raw))
+    for i in (0, n // 2, n - 1):
+        e = np.zeros(n); e[i] = 1e-4
+        fd_m = (f(raw, mean + e) - f(raw, mean - e)) / 2e-4
+        assert abs(o["d_mean"][i] - fd_m) < 1e-5 * max(1e-3, np.abs(o["d_mean"]).max())
