@@ -21,6 +21,9 @@
  *   VOLT_EXTRA_FLAGS       (build time, volt_amd/build.py) extra hipcc flags for same-box A/B builds: scripts/ab_split.sh
  *   VOLT_PLAIN_SPREAD / VOLT_SPLIT_SPREAD   plain / all-split launches of up to this many workgroups run one workgroup
  *                          per CU (320 / 700)
+ *   VOLT_BATCH / _ORDER / _MINB / _MINN   the whole batched step in ONE launch (csrc/batch_step.hip): 0 off, 1 where measured
+ *                          faster (default), 2 wherever it can run, 3 also ahead of the short- / long-series one-launch steps; order of a column's tiles in the list (0); smallest batch
+ *                          and fewest block columns it takes
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
  *                          1 = one column, 2 = two columns (2 from 6 matrices on, else 1)           (read in csrc/chol64.hip)
  *   VOLT_F64_TRTRI_LOOKAHEAD  fp64 inverse: one-row look-ahead on its own stream, 0 / 1 (on up to 4 matrices)
@@ -86,6 +89,17 @@ int volt_tune_small_stamps(long long* stamps);
  * by R(g), kind 9, which owns diagonal block g).  items: up to max_items records of 4 ints {kind | a << 8 | b << 16, slices or b0 | b1 << 8, slab slot, slice
  * counter}; nslabs / ncnt (optional): slab slots and slice counters.  Returns the number of pieces (= workgroups). */
 int volt_long_describe(int n, int first, int emin, int* items, int max_items, int* nslabs, int* ncnt);
+
+/* Host only: the piece list of the one-launch BATCHED step (csrc/batch_sched.h, csrc/batch_step.hip) for B matrices of n
+ * block columns, in grid order: items [max_items][4] int32 {kind | b << 3, row, col, 0}, kind 0 diagonal tile D(k = row),
+ * 1 look-ahead for tile (row+1,row+1), 2 panel tile (row, col), 3 tile (row, col) of the inverse, 4 its diagonal tile.
+ * order: 0 positions in column order with the matrix innermost, 1 matrix-group-major inside a block column.  items may be
+ * NULL (count only).  Returns the number of pieces (= workgroups of the launch), -1 bad argument, -2 max_items too small. */
+int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_items);
+/* The one-launch batched step: while `stamps` (device, 8 int64 per workgroup of the launch = per piece of the list) is set,
+ * every workgroup of the following steps records [0] s_memrealtime (100 MHz) at entry, [1] at exit, [2] XCC_ID << 32 | HW_ID,
+ * two-phase tiles also [3] / [4] entering / leaving the tile pipeline.  NULL switches it off. */
+int volt_tune_batch_stamps(long long* stamps);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,387 @@
+// The whole batched MLL + gradient step (or factorisation) in ONE launch (round 5).
+//   reference: ONE loop body per training step, voltron/train_utils.py:243-254 (loss = -mll(model(x), y); backward()).
+//
+// The launch-per-column schedules of chol.hip give a step of B matrices of n block columns n + 1 launches, each as long as
+// its longest tile and ended by a tail in which most CUs idle; two stream groups hide part of that, a hipGraph capture
+// cannot (one group), and 8 .. 16 matrices at N = 4096 or 64 at N = 2048 are bounded by exactly these boundaries.  Here
+// workgroup w runs piece w of the host's topologically ordered list (batch_sched.h): diagonal tiles, look-ahead tiles,
+// two-phase panel tiles, rows of the triangular inverse -- the tile bodies are the ones every other schedule runs
+// (tiles.h), so the arithmetic, and with it every bit of the result, is the launch-per-column path's.  What is new:
+//   * hand-offs by PROGRESS WORDS per matrix in the caller's scratch (cleared by batch_begin_kernel ahead of the launch):
+//       rowp[i]  = block columns of block row i of L that are complete (P(i,k) stores k + 1 behind its tile)
+//       tcol[j]  = tiles of block column j of X = L^-1 that are complete (TD(j) stores 1, T(i,j) stores i - j + 1)
+//       la[k]    = the look-ahead part of A[k,k] is parked
+//       W_k's first word as before (diag_body)
+//   * tiles CHASE their inputs (common.h): a panel tile (i,k) follows rowp[k] and rowp[i], a tile (i,j) of the inverse
+//     rowp[i] and tcol[j], asking once per 128-wide K segment and only while its inputs are incomplete.  A tile dispatched
+//     a block column early has all but its last K block behind it when that column completes.
+//   * panel and inverse tiles are stored WRITTEN THROUGH (sc1, non-temporal) and published behind the storing waves' own
+//     drain -- no L2-wide write-back per tile (what made per-slice releases slower the more slices there were: chol.hip,
+//     slab_dump).  Look-ahead tiles, diagonal tiles of the inverse and W_k (one per matrix and block column) keep the
+//     release fence.
+// The table (16 bytes per piece) and the progress words live in the caller's workspace (volt_mll_workspace_init_f32 /
+// volt_potrf_workspace_init_f32 copy the table there once); every workgroup checks the table's header against the
+// shape it was launched for and reports a region that does not hold it (info = INT_MIN + 1) instead of following it.
+#include "common.h"
+#include "tiles.h"
+#include "host.h"
+#include "batch_sched.h"
+#include "../../include/volt_hip.h"
+#include "../../include/volt_hip_tune.h"
+#include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+namespace volt {
+
+// clears what a step's hand-offs are made of: the first word of every W block, info, the progress words
+__global__ void batch_begin_kernel(float* __restrict__ Winv, int nflags, int* __restrict__ info, int ninfo,
+                                   int* __restrict__ prog, int nprog) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nflags) reinterpret_cast<int*>(Winv)[(int64_t)i * TS * TS] = 0;
+    if (i < ninfo) info[i] = 0;
+    for (int c = i; c < nprog; c += gridDim.x * blockDim.x) prog[c] = 0;
+}
+
+// thread 0 waits for *p >= want (p may be nullptr), then one agent-scope acquire; a barrier for the rest
+__device__ __forceinline__ bool word_ge(const int* p, int want) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+}
+__device__ __forceinline__ bool wait_word_ge(const int* p, int want) {
+    if (word_ge(p, want)) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (!word_ge(p, want)) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ void batch_wait(const int* p0, int want0, const int* p1, int want1, int* info_b) {
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        if (p0) ok = wait_word_ge(p0, want0);
+        if (p1) ok = wait_word_ge(p1, want1) && ok;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) atomicCAS(info_b, 0, (int)0x80000000);
+    }
+    __syncthreads();
+}
+// behind plain stores: drain, barrier, agent-scope release, the word
+__device__ __forceinline__ void batch_publish_release(int* word, int val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// behind written-through (sc1) stores: every storing wave drains, then the word -- nothing is left in L2 to write back
+__device__ __forceinline__ void batch_publish_wt(int* word, int val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int AUX_WT = AUX_SC1 | 2;            // sc1 + nt: written through at agent scope, streaming
+
+// First diagonal tile straight from the caller's K (+ sigma2 / jitter on the diagonal, identity in the padding) into the
+// pivot image: no prepared copy of block column 0, no launch ahead of the step for it.
+__device__ __forceinline__ void diag0_image(const KSource& src, int b, float* smem) {
+    const float add = (src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter;
+    const float* Kb = src.K + (int64_t)b * src.bsk;
+    for (int e = threadIdx.x; e < TS * TS; e += NT) {
+        const int r = e >> 7, c = e & 127;
+        smem[r * DT + c] = (c <= r) ? input_elem(src, Kb, add, nullptr, 0, true, r, c) : 0.f;
+    }
+}
+
+// AL(c): block c of z = Y'r -- the sum of the z-partials of row c of the inverse, in sum_zpart_kernel's order -- and
+// alpha's partial sums from block column c of Y, apart[b][c][row] = Y[row, block c] . z_c for the rows of block rows
+// 0 .. c (rowpair_dot: the sums y_times_z_kernel forms).  A stream over (c + 1) tiles the workgroups of this launch have
+// just written.
+__device__ __forceinline__ void alpha_item(const float* __restrict__ Y, const TriReduce& red, float* __restrict__ z,
+                                           float* __restrict__ apart, int Np, int b, int c, int chunk) {
+    const int n = Np / TS, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    f32x4 zc = {0.f, 0.f, 0.f, 0.f};
+    for (int jb = 0; jb <= c; ++jb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(red.zpart + ((int64_t)b * n + jb) * Np + c * TS + 4 * l31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zc[e] += v[e];
+    }
+    if (chunk == 0 && wave == 0 && h == 0) *reinterpret_cast<f32x4*>(z + (int64_t)b * Np + c * TS + 4 * l31) = zc;
+    const float* Yc = Y + (int64_t)b * Np * Np + c * TS + 4 * l31 + (int64_t)h * Np;
+    float* dst = apart + ((int64_t)b * n + c) * Np;
+    const int r0 = chunk * BATCH_ALPHA_ROWS;
+    const int r1 = (r0 + BATCH_ALPHA_ROWS < (c + 1) * TS) ? r0 + BATCH_ALPHA_ROWS : (c + 1) * TS;
+    // a wave takes 32 consecutive rows per pass as 16 row pairs (r + 2 u + h), all sixteen loads in flight: the stream is
+    // latency-bound otherwise (four in flight: 280 us per piece)
+    for (int r = r0 + 32 * wave; r < r1; r += 128) {
+        f32x4 y[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) y[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Yc + (int64_t)(r + 2 * u) * Np));
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float lo, hi;
+            rowpair_dot(y[u], zc, lo, hi);
+            if (lane == 0) {
+                dst[r + 2 * u] = lo;
+                dst[r + 2 * u + 1] = hi;
+            }
+        }
+    }
+}
+
+// tuning only (volt_tune_batch_stamps): 8 int64 per workgroup -- s_memrealtime at entry and exit, the hardware id, and for
+// the two-phase tiles the time the pipeline is entered and left
+static long long* g_batch_stamps = nullptr;
+
+template <bool FROMK>
+__global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                           float* __restrict__ Y, int* __restrict__ info, int Np, int B,
+                                                           KSource src, TriReduce red, const int4* __restrict__ tab,
+                                                           int* __restrict__ prog, int pstride, int4 key0, int4 key1,
+                                                           float* __restrict__ zvec, float* __restrict__ apart,
+                                                           long long* __restrict__ stamps) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    const int n = Np / TS;
+    if (stamps && threadIdx.x == 0) {
+        stamps[(int64_t)blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime();
+        stamps[(int64_t)blockIdx.x * 8 + 2] = ((long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |
+                                              (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+    }
+    struct Exit {                                            // every return path leaves its time behind
+        long long* st;
+        __device__ ~Exit() { if (st && threadIdx.x == 0) st[(int64_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
+    } exit_stamp{stamps};
+    {   // the caller's scratch must hold the table this launch was sized for: anything else is reported, never followed
+        const int4 h0 = tab[0], h1 = tab[1];
+        if (h0.x != key0.x || h0.y != key0.y || h0.z != key0.z || h0.w != key0.w || h1.x != key1.x || h1.y != key1.y ||
+            h1.z != key1.z || h1.w != key1.w) {
+            if (blockIdx.x == 0)
+                for (int b = threadIdx.x; b < B; b += NT) info[b] = (int)0x80000001;
+            return;
+        }
+    }
+    const int4 d = tab[BATCH_HDR + blockIdx.x];
+    const int kind = d.x & 7, b = d.x >> 3;
+    int* rowp = prog + (int64_t)b * pstride;
+    int* tcol = rowp + n;
+    int* la = tcol + n;
+    int* info_b = info + b;
+    const bool usek = FROMK && src.K != nullptr;
+
+    if (kind == BK_DIAG) {
+        const int k = d.y;
+        if (k == 0) {
+            if (usek) {
+                diag0_image(src, b, smem);
+                diag_body(A, Winv, info, Np, 0, b, smem, nullptr, true);
+            } else {
+                diag_body(A, Winv, info, Np, 0, b, smem, nullptr, false);
+            }
+            return;
+        }
+        // L[k,k-1] (and with it all of row k) is there; k >= 2: the look-ahead part of A[k,k] is parked
+        batch_wait(rowp + k, k, k >= 2 ? la + k : nullptr, 1, info_b);
+        if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, b, src, smem, true);
+        else update_body<FROMK>(A, Np, 1, 1, 0, 1, true, b, src, smem, true);
+        diag_body(A, Winv, info, Np, k, b, smem, nullptr, true);
+        return;
+    }
+    if (kind == BK_LOOKAHEAD) {
+        const int k = d.y;                                   // A[k+1,k+1] -= sum_{m<k} L[k+1,m] L[k+1,m]^T, chasing row k+1
+        Chase ch;
+        ch.p0 = ch.p1 = rowp + k + 1;
+        bool ok = true;
+        update_body<FROMK, 0, true>(A, Np, k + 1, k + 1, 0, k, true, b, src, smem, false, &ch, &ok);
+        if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);
+        batch_publish_release(la + k + 1, 1);
+        return;
+    }
+    if (kind == BK_TRTRI_DIAG) {
+        const int i = d.y;
+        batch_wait(reinterpret_cast<const int*>(Winv + ((int64_t)b * n + i) * TS * TS), 1, nullptr, 0, info_b);
+        trtri_diag_body(Winv, Y, Np, i, b, red, smem);
+        batch_publish_release(tcol + i, 1);
+        return;
+    }
+    if (kind == BK_ALPHA) {
+        const int c = d.y;
+        if (threadIdx.x <= c) {                              // row c of the inverse is complete: tcol[j] >= c - j + 1, j <= c
+            if (!wait_word_ge(tcol + threadIdx.x, c - (int)threadIdx.x + 1)) atomicCAS(info_b, 0, (int)0x80000000);
+        }
+        if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        alpha_item(Y, red, zvec, apart, Np, b, c, d.z);
+        return;
+    }
+    // ---- the two-phase tiles
+    TriJob jb;
+    int* word;
+    int val;
+    if (kind == BK_PANEL) {
+        const int i = d.y, k = d.z;
+        jb = panel_job<FROMK>(A, Winv, Np, i, k, b, src);
+        jb.t.ch.p0 = rowp + k;                               // X = L[k, 0 ..]
+        jb.t.ch.p1 = rowp + i;                               // Z = L[i, 0 ..]
+        word = rowp + i;
+        val = k + 1;
+    } else {
+        const int i = d.y, j = d.z;
+        jb = trtri_job(A, Winv, Y, Np, i, j, b);
+        jb.t.flag = reinterpret_cast<const int*>(jb.t.W);    // W_i comes from a workgroup of this launch too
+        jb.t.ch.p0 = rowp + i;                               // X = L[i, j ..]: block m is L[i, j + m]
+        jb.t.ch.base0 = j;
+        jb.t.ch.p1 = tcol + j;                               // Z = Y[j, j ..]: block m is tile (j + m, j) of the inverse
+        word = tcol + j;
+        val = i - j + 1;
+    }
+    f32x16 T[4], O[4];
+    ChasePre pre = {0, 0};
+    if (jb.t.n1 > 0) pre = chase_issue(jb.t.ch);             // the polls go out ahead of the input tile's loads: one round trip
+    job_t0(jb, T);
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    const bool ok = tri_tile_run<true>(jb.t, T, O, smem, &pre);
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);   // a hand-off timed out: internal error
+    tri_store_aux<AUX_WT>(O, jb.out, Np);
+    if (jb.i >= 0 && red.rpad) trtri_reduce<true>(O, Np, jb.i, jb.j, jb.b, red, smem);
+    batch_publish_wt(word, val);
+}
+
+}  // namespace volt
+
+using namespace volt;
+
+// Where the one launch replaces the launch-per-column schedules.  (B, n) only: the gate is part of the shape's identity,
+// volt_*_workspace_bytes / _init and the step agree on it.
+bool volt_internal_batch_applies(int B, int n, int has_y) {
+    const Tunables& tn = tunables();
+    (void)has_y;
+    if (tn.batch <= 0 || B < 1 || n < 2 || B > 65535) return false;
+    if (tn.batch >= 2) return true;
+    return B >= tn.batch_minb && n >= tn.batch_minn;
+}
+
+bool volt_internal_batch_first() { return tunables().batch >= 3; }   // tuning: ahead of the short- / long-series steps
+
+static size_t batch_table_bytes(int B, int n, bool has_y) {
+    return ((size_t)(BATCH_HDR + batch_count(B, n, has_y)) * sizeof(BatchItem) + 255) & ~(size_t)255;
+}
+static size_t batch_prog_bytes(int B, int n) { return ((size_t)B * batch_pstride(n) * sizeof(int) + 255) & ~(size_t)255; }
+
+size_t volt_internal_batch_bytes(int B, int n, int has_y) {
+    if (!volt_internal_batch_applies(B, n, has_y)) return 0;
+    return batch_table_bytes(B, n, has_y != 0) + batch_prog_bytes(B, n);
+}
+
+static void batch_keys(int B, int n, bool has_y, int4& k0, int4& k1) {
+    k0 = int4{BATCH_MAGIC, B, n, has_y ? 1 : 0};
+    k1 = int4{tunables().batch_order, (int)batch_count(B, n, has_y), 0, 0};
+}
+
+// The table, built once per (B, n, inverse?, order) in pinned host memory and kept for the life of the library (host
+// memory only, like the balanced schedules' tables); volt_*_workspace_init copies it into the caller's scratch.
+struct BatchTable {
+    int4* items = nullptr;
+    size_t bytes = 0;
+};
+static const BatchTable* get_batch_table(int B, int n, bool has_y) {
+    static std::mutex mu;
+    static std::map<std::array<int, 4>, BatchTable*> cache;
+    const int order = tunables().batch_order;
+    const std::array<int, 4> key{B, n, has_y ? 1 : 0, order};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    std::vector<BatchItem> items;
+    batch_build(B, n, has_y, order, items);
+    BatchTable* bt = new BatchTable;
+    static_assert(sizeof(BatchItem) == sizeof(int4), "items are read as int4");
+    bt->bytes = (BATCH_HDR + items.size()) * sizeof(BatchItem);
+    if ((int64_t)items.size() != batch_count(B, n, has_y) ||
+        hipHostMalloc((void**)&bt->items, bt->bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        delete bt;
+        bt = nullptr;
+    } else {
+        memset(bt->items, 0, BATCH_HDR * sizeof(BatchItem));
+        batch_keys(B, n, has_y, bt->items[0], bt->items[1]);
+        memcpy(bt->items + BATCH_HDR, items.data(), items.size() * sizeof(BatchItem));
+    }
+    cache[key] = bt;
+    return bt;
+}
+
+int volt_internal_batch_install(void* state, size_t bytes, int B, int n, int has_y, void* stream) {
+    if (!state || bytes < volt_internal_batch_bytes(B, n, has_y) || !volt_internal_batch_applies(B, n, has_y)) return 0;
+    const BatchTable* bt = get_batch_table(B, n, has_y != 0);
+    if (!bt) return (int)hipErrorOutOfMemory;
+    hipError_t e = hipMemcpyAsync(state, bt->items, bt->bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+    return e != hipSuccess ? (int)e : 0;
+}
+
+// One step: clear the hand-off words, then the one launch.  K != nullptr: tiles read their input from K (A receives L);
+// K == nullptr: A holds the input (volt_potrf_f32).  Y == nullptr: the factorisation alone.  e0 / e1 (optional): events
+// recorded around the step kernel on `stream` (bench.py's roofline leg).  Returns 1 when the step was enqueued, 0 when
+// the shape is not this schedule's (nothing enqueued), a HIP error otherwise.
+int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
+                             float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
+                             float* z, float* apart, void* state, size_t state_bytes, void* stream, hipEvent_t e0,
+                             hipEvent_t e1) {
+    const int Np = volt_padded_n(N), n = Np / TS;
+    const bool has_y = Y != nullptr;
+    if (!state || !volt_internal_batch_applies(B, n, has_y) || state_bytes < volt_internal_batch_bytes(B, n, has_y)) return 0;
+    if (has_y && (!z || !apart)) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int4* tab = reinterpret_cast<const int4*>(state);
+    int* prog = reinterpret_cast<int*>(reinterpret_cast<char*>(state) + batch_table_bytes(B, n, has_y));
+    const int pstride = batch_pstride(n), nprog = B * pstride, nflags = B * n;
+    int blocks = (std::max(std::max(nflags, B), nprog) + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks * 256 < std::max(nflags, B)) blocks = (std::max(nflags, B) + 255) / 256;
+    hipLaunchKernelGGL(batch_begin_kernel, dim3(blocks), dim3(256), 0, s, Winv, nflags, info, B, prog, nprog);
+    int4 k0, k1;
+    batch_keys(B, n, has_y, k0, k1);
+    const KSource src{K, ldk, bsk, sigma2, jitter, N};
+    const TriReduce red{has_y ? rpad : nullptr, zpart, frob, N};
+    const unsigned grid = (unsigned)batch_count(B, n, has_y);
+    if (e0 && hipEventRecord(e0, s) != hipSuccess) return (int)hipGetLastError();
+    if (K)
+        hipLaunchKernelGGL(batch_step_kernel<true>, dim3(grid), dim3(256), 0, s, A, Winv, Y, info, Np, B, src, red, tab, prog,
+                           pstride, k0, k1, z, apart, g_batch_stamps);
+    else
+        hipLaunchKernelGGL(batch_step_kernel<false>, dim3(grid), dim3(256), 0, s, A, Winv, Y, info, Np, B, src, red, tab, prog,
+                           pstride, k0, k1, z, apart, g_batch_stamps);
+    if (e1 && hipEventRecord(e1, s) != hipSuccess) return (int)hipGetLastError();
+    hipError_t e = hipGetLastError();
+    return e != hipSuccess ? (int)e : 1;
+}
+
+extern "C" {
+
+int volt_tune_batch_stamps(long long* stamps) {
+    g_batch_stamps = stamps;
+    return 0;
+}
+
+// Host only (no GPU): the piece list of the one-launch batched step, in grid order -- items [max_items][4] int32
+// {kind | b << 3, row, col, 0} (batch_sched.h).  Returns the number of pieces, -1 bad argument, -2 max_items too small.
+int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_items) {
+    if (B < 1 || n < 1 || order < 0 || order > 1) return -1;
+    std::vector<BatchItem> it;
+    batch_build(B, n, has_y != 0, order, it);
+    if ((int64_t)it.size() != batch_count(B, n, has_y != 0)) return -1;
+    if (items) {
+        if ((int)it.size() > max_items) return -2;
+        memcpy(items, it.data(), it.size() * sizeof(BatchItem));
+    }
+    return (int)it.size();
+}
+
+}  // extern "C"

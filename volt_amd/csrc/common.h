@@ -291,10 +291,67 @@ __device__ __forceinline__ void chunk_run(const float* cur, float* nxt, Frag<WL>
     VOLT_SB();
 }
 
-template <int WL>
+// ---- chasing tiles (batch_step.hip: the whole batched step in ONE launch) ------------------------------------------
+// A left-looking tile reads K blocks 0 .. k-1 of two block rows that other workgroups of the SAME launch are still
+// producing.  Instead of waiting for all of them before it starts, a chasing tile follows two progress words ("blocks
+// [0, *p - base) of this operand are complete") and asks only at the top of a 128-wide K segment, for the segment whose
+// loads it is about to issue -- so the long products run as far ahead as their inputs allow and what is left on the
+// critical path behind a finished block column is ONE K block, as in a right-looking sweep, with the left-looking
+// traffic.  Every wave polls for itself (the chunk barriers keep the waves of a workgroup within a chunk of each other,
+// and each has seen for itself that what it loads is there); a tile that finds everything complete on entry -- the
+// common case in a large batch -- never polls again.
+constexpr unsigned long long CHASE_LIMIT_TICKS = 300000000ull;   // 3 s of the 100 MHz s_memrealtime counter (WAIT_LIMIT_TICKS below)
+struct Chase {
+    const int* p0 = nullptr;     // progress word of the X operand's source
+    const int* p1 = nullptr;     // ... of the Z operand's
+    int base0 = 0, base1 = 0;    // the word's value when block 0 of this tile's K range is NOT yet there
+};
+__device__ __forceinline__ int chase_poll(const Chase& ch) {
+    const int v0 = __hip_atomic_load(ch.p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.base0;
+    const int v1 = __hip_atomic_load(ch.p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.base1;
+    return __builtin_amdgcn_readfirstlane(v0 < v1 ? v0 : v1);
+}
+// The two polls issued EARLY (their results are not waited for here): a tile puts them ahead of the loads of its input
+// tile, so that one memory round trip covers both; chase_wait_pre then starts from what they brought.
+struct ChasePre { int v0, v1; };
+__device__ __forceinline__ ChasePre chase_issue(const Chase& ch) {
+    ChasePre p;
+    p.v0 = __hip_atomic_load(ch.p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.v1 = __hip_atomic_load(ch.p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return p;
+}
+// leading K blocks of the tile that are complete: >= need on return, or the last value seen after a time-out (ok = false)
+__device__ __forceinline__ int chase_wait(const Chase& ch, int need, bool& ok) {
+    int r = chase_poll(ch);
+    if (r < need) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while ((r = chase_poll(ch)) < need) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > CHASE_LIMIT_TICKS) {
+                ok = false;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return r;
+}
+__device__ __forceinline__ int chase_wait_pre(const Chase& ch, const ChasePre& pre, int need, bool& ok) {
+    const int a = pre.v0 - ch.base0, b = pre.v1 - ch.base1;
+    const int r = __builtin_amdgcn_readfirstlane(a < b ? a : b);
+    if (r < need) return chase_wait(ch, need, ok);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return r;
+}
+
+template <int WL, bool CHASE = false>
 __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                               int64_t ldb, int nchunks, f32x16 (&acc)[4], float* smem) {
+                                               int64_t ldb, int nchunks, f32x16 (&acc)[4], float* smem,
+                                               const Chase* ch = nullptr, bool* ch_ok = nullptr) {
     if (nchunks <= 0) return;
+    int ready = 0;                             // CHASE: leading K blocks known complete
+    if constexpr (CHASE) ready = chase_wait(*ch, 1, *ch_ok);
     StageRegs s0, s1;
     const StageAddr sa = stage_addr(A, lda, B, ldb);
     stage_load_buf(s0, sa, 0);                 // (nchunks >= 4: chunks 1 and 2 exist)
@@ -312,6 +369,10 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
     P[3] = zero16c();
     int c = 0;
     for (; c + SEG_CHUNKS < nchunks; c += SEG_CHUNKS) {        // every segment but the last: all loads / stores / reads exist
+        if constexpr (CHASE) {                 // this segment requests the next block's chunks
+            const int need = (c >> 2) + 2;
+            if (ready < need) ready = chase_wait(*ch, need, *ch_ok);
+        }
         chunk_run<WL, true, true, true, SEG_FIRST>(b0, b1, F0, F1, P, acc, s0, sa, (c + 3) * BK);
         chunk_run<WL, true, true, true>(b1, b0, F0, F1, P, acc, s1, sa, (c + 4) * BK);
         chunk_run<WL, true, true, true>(b0, b1, F0, F1, P, acc, s0, sa, (c + 5) * BK);
@@ -342,6 +403,7 @@ struct TriTile {
     const float* W;                    // [128][128] row-major, lower triangular
     const int* flag;                   // nullptr, or W's ready flag
     int want;                          // 0: ready = the flag word is non-zero;  else: ready = the word equals `want`
+    Chase ch;                          // tri_tile_run<true> only: the progress words of X's and Z's sources
 };
 
 // One per-lane byte offset per operand (row t >> 3, 16-byte column t & 7); the row group p (32 rows further down) and
@@ -509,8 +571,11 @@ __device__ __forceinline__ void flag_publish(int* flag) {
     }
 }
 
-// T holds T0 on entry; O (zeroed here) holds the product on exit.  Returns false (thread 0) if the flag timed out.
-__device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f32x16 (&O)[4], float* smem) {
+// T holds T0 on entry; O (zeroed here) holds the product on exit.  Returns false if a wait timed out (the W flag: in
+// thread 0;  CHASE: in every lane of the wave that gave up).
+template <bool CHASE = false>
+__device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f32x16 (&O)[4], float* smem,
+                                             const ChasePre* pre = nullptr) {
     const int tid = threadIdx.x;
     const int srow = tid >> 3, scq = (tid & 7) * 4;
     TriSrc ts;
@@ -525,6 +590,10 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     ts.n1 = t.n1;
     ts.nall = t.n1 + 4;
     bool ok = true;
+    int ready = 0;                                   // CHASE: leading K blocks known complete
+    if constexpr (CHASE) {
+        if (t.n1 > 0) ready = pre ? chase_wait_pre(t.ch, *pre, 1, ok) : chase_wait(t.ch, 1, ok);
+    }
     if (t.flag && t.n1 == 0) {                       // no phase 1 to hide behind: W is the first thing needed
         ok = flag_wait_one_lane(t.flag, t.want);
         __syncthreads();
@@ -549,13 +618,17 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
         frag_load<1>(F0, b0, 0);
         O[3] = zero16c();
         for (; c + SEG_CHUNKS < t.n1; c += SEG_CHUNKS) {          // every segment but the last: its prefetches are phase-1 chunks too
+            if constexpr (CHASE) {                                // this segment requests the next block's chunks
+                const int need = (c >> 2) + 2;
+                if (ready < need) ready = chase_wait(t.ch, need, ok);
+            }
             tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, O, T, s0, ts);
             tri_chunk_p1<true, 1, 1>(b1, b0, c + 1, F0, F1, O, T, s1, ts);
             tri_chunk_p1<true, 1, 1>(b0, b1, c + 2, F0, F1, O, T, s0, ts);
             tri_chunk_p1<true, 1, 1, SEG_LAST>(b1, b0, c + 3, F0, F1, O, T, s1, ts);
         }
         // the last segment of phase 1: the W chunks (n1 .. n1+3) come into view
-        if (t.flag) ok = flag_wait_one_lane(t.flag, t.want);      // barriers below order the acquire
+        if (t.flag) ok = flag_wait_one_lane(t.flag, t.want) && ok;      // barriers below order the acquire
         tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, O, T, s0, ts);
         tri_chunk_p1<true, 1, 2>(b1, b0, c + 1, F0, F1, O, T, s1, ts);
         tri_chunk_p1<true, 1, 2>(b0, b1, c + 2, F0, F1, O, T, s0, ts);
@@ -637,6 +710,23 @@ __device__ __forceinline__ float wave_sum_f(float x) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(xi, 32));
     const float r3 = __int_as_float(__builtin_amdgcn_readlane(xi, 48));
     return (r0 + r1) + (r2 + r3);
+}
+
+// alpha = Y z, one 128-column block of Y at a time: lane l of a half-wave holds columns 4 (l % 32) .. + 3 of the block
+// for ITS row (lanes 0..31 one row, lanes 32..63 another) and the matching four entries of z; returns the two rows' dot
+// products (wave-uniform).  The ONE definition of this sum: the launch-per-column tail (mll.hip, y_times_z_kernel) and
+// the one-launch batched step (batch_step.hip, alpha items) add the same partials in the same order, so alpha agrees
+// bit for bit between the schedules.
+__device__ __forceinline__ void rowpair_dot(const f32x4& y, const f32x4& z, float& lo, float& hi) {
+    // explicit fma / mul: the contraction must not depend on what the compiler makes of the call site
+    float p = __builtin_fmaf(y[0], z[0], y[1] * z[1]) + __builtin_fmaf(y[2], z[2], y[3] * z[3]);
+    p = dpp_add<0xB1>(p);
+    p = dpp_add<0x4E>(p);
+    p = dpp_add<0x141>(p);
+    p = dpp_add<0x140>(p);                  // every lane of a 16-lane row holds the row's sum
+    const int pi = __float_as_int(p);
+    lo = __int_as_float(__builtin_amdgcn_readlane(pi, 0)) + __int_as_float(__builtin_amdgcn_readlane(pi, 16));
+    hi = __int_as_float(__builtin_amdgcn_readlane(pi, 32)) + __int_as_float(__builtin_amdgcn_readlane(pi, 48));
 }
 
 }  // namespace volt

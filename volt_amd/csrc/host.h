@@ -1,0 +1,27 @@
+// Host-side internals shared by the translation units of libvolt_hip.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// Schedule parameters: compiled-in defaults (measured on MI355X).  A deployment reads NO environment:
+// only a process started with VOLT_TUNE=1 (the experiment scripts) may override them through the VOLT_* variables listed in
+// include/volt_hip_tune.h -- read ONCE, here and in chol64.hip's tune_int, nowhere else.
+struct Tunables {
+    int groups = 2;                  // stream groups of a large batch (2 >= 4 > 8 with one launch per block column)
+    int splitk_target = 512, splitk_minl = 2, splitk_maxs = 8, splitk_groups = 2, splitk_maxb = 22;
+    int sched = 1, sched_minb = 3, sched_maxb = 31, sched_maxb_potrf = 64;
+    int sched_g = 256, sched_s = 4, sched_groups = 2, sched_kmin = -1;
+    float sched_frac = 0.6f;
+    int small_nmax = 8, small_maxwg = 1150;    // the one-launch step: block columns it takes, and workgroups at most
+    int plain_spread = 320, split_spread = 700;   // plain / all-split launches of up to this many workgroups run one workgroup per CU
+    int long_split = 1;                      // long series: the spine split in two workgroups (substitution | rank-32 updates + diagonal block)
+    int long_xcd = 0;                        // long series: spines on one XCD, their hand-offs through its L2 (long_sched.h)
+    int long_on = 1, long_first = 0, long_emin = 1, long_pad = 1, long_nmin = 2;   // one long series in one launch: on/off, last slice's blocks (0: 3 up to 24 block columns, 4 above), shortest sliced early part, a CU per workgroup, block columns above which it takes one series
+    int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
+    int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
+    int batch = 1;                             // the whole batched step in one launch (batch_step.hip): 0 off, 1 where measured faster, 2 wherever it can run
+    int batch_order = 0;                       // ... order of a block column's panel tiles in its list: 0 row-major (matrix innermost), 1 matrix-major
+    int batch_minb = 8, batch_minn = 16;       // ... smallest batch / fewest block columns it takes
+};
+const Tunables& tunables();                    // chol.hip: read once per process (VOLT_TUNE=1 only)

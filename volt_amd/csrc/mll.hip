@@ -28,41 +28,47 @@ __global__ void sum_zpart_kernel(const float* __restrict__ zpart, float* __restr
     z[(int64_t)b * Np + c] = a;
 }
 
-// R3: alpha = Y z, Y upper triangular: alpha[j] = sum_{c >= j} Y[j][c] z[c].  Pure HBM stream over the
-// upper half of Y: a wave owns one row at a time, lanes read float4 (1 KiB contiguous per wave and
-// pass), z comes from L1/L2; 4 rows are kept in flight per wave for memory-level parallelism.
-// grid = (Np/16) * B workgroups of 4 waves; a workgroup covers 16 consecutive rows.
+// R3: alpha = Y z, Y upper triangular: alpha[j] = sum_{c >= j} Y[j][c] z[c].  Pure HBM stream over the upper half of Y.
+// A wave owns four rows (two at a time, one per half-wave: 512 contiguous bytes per row and 128-column block) and adds
+// the blocks' dot products in ascending block order -- rowpair_dot (common.h) defines the sum, and the one-launch batched
+// step's alpha items (batch_step.hip) produce the very same partials.  grid = (Np/16) * B workgroups of 4 waves.
 __global__ __launch_bounds__(256) void y_times_z_kernel(const float* __restrict__ Y, const float* __restrict__ z,
                                                         float* __restrict__ alpha, int Np, int B) {
     int rb, b;
     decode_tile_batch(Np / 16, B, rb, b);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j0 = rb * 16 + wave * 4;                       // this wave's 4 rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+    const int j0 = rb * 16 + wave * 4;                       // this wave's 4 rows: j0 + h, j0 + 2 + h
     const float* Yb = Y + (int64_t)b * Np * Np;
     const float* zb = z + (int64_t)b * Np;
-    const int cstart = (j0 / TS) * TS;                       // tiles left of the diagonal tile are not stored
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = cstart + lane * 4; c < Np; c += 256) {
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(zb + c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const f32x4 y = *reinterpret_cast<const f32x4*>(Yb + (int64_t)(j0 + r) * Np + c);
-            acc[r] += (y[0] * zv[0] + y[1] * zv[1]) + (y[2] * zv[2] + y[3] * zv[3]);
-        }
+    const int n = Np / TS;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                     // rows j0, j0 + 1, j0 + 2, j0 + 3 (wave-uniform)
+    const float* y0 = Yb + (int64_t)(j0 + h) * Np + 4 * l31;
+    const float* y1 = Yb + (int64_t)(j0 + 2 + h) * Np + 4 * l31;
+    for (int c = j0 / TS; c < n; ++c) {                      // tiles left of the diagonal tile are not stored
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(zb + c * TS + 4 * l31);
+        const f32x4 ya = *reinterpret_cast<const f32x4*>(y0 + c * TS);
+        const f32x4 yb = *reinterpret_cast<const f32x4*>(y1 + c * TS);
+        float lo, hi;
+        rowpair_dot(ya, zv, lo, hi);
+        acc[0] += lo;
+        acc[1] += hi;
+        rowpair_dot(yb, zv, lo, hi);
+        acc[2] += lo;
+        acc[3] += hi;
     }
+    if (lane == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float tot = wave_sum_f(acc[r]);
-        if (lane == 0) alpha[(int64_t)b * Np + j0 + r] = tot;
+        for (int r = 0; r < 4; ++r) alpha[(int64_t)b * Np + j0 + r] = acc[r];
     }
 }
 
 // R4: scalars.  out[b, 0..7] = mll, dmll/dsigma2, quad, logdet, trinv, aa, sigma2-used, 0
 __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restrict__ A, const float* __restrict__ z,
-                                                          const float* __restrict__ alpha_pad,
+                                                          float* __restrict__ alpha_pad,
                                                           const float* __restrict__ frob, const float* __restrict__ sigma2,
                                                           float jitter, float* __restrict__ out,
-                                                          float* __restrict__ alpha_out, int N, int Np, int want_grad) {
+                                                          float* __restrict__ alpha_out, int N, int Np, int want_grad,
+                                                          const float* __restrict__ apart = nullptr) {
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = Np / TS;
@@ -84,11 +90,20 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
         q += zi * zi;
         ld += log((double)Ab[(int64_t)i * Np + i]);
         if (want_grad) {
-            const float al = alpha_pad[(int64_t)b * Np + i];
+            float al;
+            if (apart) {                        // the one-launch batched step: alpha's partial sums per block column of Y,
+                al = 0.f;                       // [B,n,Np], added in ascending block order (as y_times_z_kernel does)
+                for (int c = i / TS; c < n; ++c) al += apart[((int64_t)b * n + c) * Np + i];
+                alpha_pad[(int64_t)b * Np + i] = al;
+            } else {
+                al = alpha_pad[(int64_t)b * Np + i];
+            }
             aa += (double)al * al;
             alpha_out[(int64_t)b * N + i] = al;
         }
     }
+    if (want_grad && apart)
+        for (int i = N + tid; i < Np; i += 256) alpha_pad[(int64_t)b * Np + i] = 0.f;
     if (want_grad) {
         const int nt = n * (n + 1) / 2;
         for (int i = tid; i < nt; i += 256) tr += frob[(int64_t)b * nt + i];
@@ -196,6 +211,8 @@ struct MllWs {
     void* lng;               // state of the one-launch step for one long series (chol.hip), lng_bytes long
     size_t lng_bytes;
     float* eslab;            // ... and the slabs of its early-part slices
+    void* batch;             // table + progress words of the one-launch batched step (batch_step.hip), batch_bytes long
+    size_t batch_bytes;
     size_t bytes;
 };
 
@@ -217,6 +234,13 @@ int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const floa
                             float jitter, float* A, float* Winv, float* Y, int* info, float* rpad, float* zpart,
                             float* frob, float* z, float* apad, float* apart, float* eslab, float* out, float* alpha,
                             void* state, int B, int N, void* stream);
+size_t volt_internal_batch_bytes(int B, int n, int has_y);   // batch_step.hip
+bool volt_internal_batch_first();
+int volt_internal_batch_install(void* state, size_t bytes, int B, int n, int has_y, void* stream);
+int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
+                             float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
+                             float* z, float* apart, void* state, size_t state_bytes, void* stream, hipEvent_t e0,
+                             hipEvent_t e1);
 namespace volt {
 
 static MllWs carve(void* base, int B, int N, int want_grad) {
@@ -259,7 +283,9 @@ static MllWs carve(void* base, int B, int N, int want_grad) {
     w.lng_bytes = want_grad ? volt_internal_long_bytes(B, (int)n) : 0;
     w.lng = w.lng_bytes ? take(w.lng_bytes / sizeof(float)) : nullptr;
     w.eslab = w.lng_bytes ? take(volt_internal_long_slab_floats(B, (int)n)) : nullptr;
-    w.apart = (w.small_bytes || w.lng_bytes) ? take((size_t)B * n * Np) : nullptr;   // alpha's partial sums, per row of the inverse
+    w.batch_bytes = volt_internal_batch_bytes(B, (int)n, want_grad);
+    w.apart = (w.small_bytes || w.lng_bytes || (want_grad && w.batch_bytes)) ? take((size_t)B * n * Np) : nullptr;   // alpha's partial sums, per row of the inverse
+    w.batch = w.batch_bytes ? take(w.batch_bytes / sizeof(float)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -314,6 +340,16 @@ void mll_tail(void* vctx, int b0, int Bg, hipStream_t s) {
                        c.sigma2 ? c.sigma2 + b0 : nullptr, c.jitter, c.out + (int64_t)b0 * 8,
                        c.alpha ? c.alpha + (int64_t)b0 * c.N : nullptr, c.N, Np, c.want_grad);
 }
+// what is left behind the one-launch batched step (batch_step.hip): with the inverse, z and alpha's partial sums came out
+// of the launch itself -- the scalars alone; without, the forward solve for z as above
+void batch_tail(TailCtx& c, int B, hipStream_t s) {
+    if (!c.want_grad) {
+        mll_tail(&c, 0, B, s);
+        return;
+    }
+    hipLaunchKernelGGL(mll_scalars_kernel, dim3(B), dim3(256), 0, s, c.w.A, c.w.z, c.w.apad, c.w.frob, c.sigma2, c.jitter, c.out,
+                       c.alpha, c.N, c.Np, 1, c.w.apart);
+}
 }  // namespace
 
 // gpcv.hip continues from the factor and Y = L^-T this step leaves in its workspace
@@ -338,6 +374,10 @@ int volt_mll_workspace_init_f32(void* workspace, int B, int N, int want_grad, vo
     }
     if (w.lng) {
         const int rc = volt_internal_long_install(w.lng, w.lng_bytes, B, n, stream);
+        if (rc) return rc;
+    }
+    if (w.batch) {
+        const int rc = volt_internal_batch_install(w.batch, w.batch_bytes, B, n, want_grad, stream);
         if (rc) return rc;
     }
     if (!w.tab) return 0;
@@ -366,7 +406,19 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
     MllWs w = carve(workspace, B, N, want_grad);
     int rc;
     bool done = false;
-    if (ready && want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
+    if (ready && w.batch && volt_internal_batch_first()) {                          // batches of longer series: the whole step in one launch (batch_step.hip)
+        hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
+        rc = volt_internal_batch_step(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info, w.rpad, w.zpart,
+                                      w.frob, B, N, w.z, w.apart, w.batch, w.batch_bytes, stream, nullptr, nullptr);
+        if (rc == 1) {
+            TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
+            batch_tail(ctx, B, s);
+            done = true;
+        } else if (rc) {
+            return rc > 0 ? rc : -1;
+        }
+    }
+    if (!done && ready && want_grad && w.lng && w.apart && w.eslab) {  // one long series: one launch with sliced early parts (chol.hip)
         rc = volt_internal_long_step(K, ldk, bsk, resid, sigma2, jitter, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob,
                                      w.z, w.apad, w.apart, w.eslab, out, alpha, w.lng, B, N, stream);
         if (rc == 1) done = true;
@@ -377,6 +429,18 @@ int volt_mll_step_f32(const float* K, int64_t ldk, int64_t bsk, const float* res
                                       w.z, w.apad, w.apart, out, alpha, w.small, B, N, stream);
         if (rc == 1) done = true;
         else if (rc) return rc > 0 ? rc : -1;
+    }
+    if (!done && ready && w.batch) {                          // batches of longer series: the whole step in one launch (batch_step.hip)
+        hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
+        rc = volt_internal_batch_step(K, ldk, bsk, sigma2, jitter, w.A, w.Winv, want_grad ? w.Y : nullptr, info, w.rpad, w.zpart,
+                                      w.frob, B, N, w.z, w.apart, w.batch, w.batch_bytes, stream, nullptr, nullptr);
+        if (rc == 1) {
+            TailCtx ctx{w, sigma2, jitter, out, alpha, N, Np, want_grad};
+            batch_tail(ctx, B, s);
+            done = true;
+        } else if (rc) {
+            return rc > 0 ? rc : -1;
+        }
     }
     if (!done) {
         hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
@@ -417,6 +481,31 @@ int volt_profile_step_f32(const float* K, int64_t ldk, int64_t bsk, const float*
     MllWs w = carve(workspace, B, N, 1);
     hipLaunchKernelGGL(pad_resid_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, resid, w.rpad, N, Np);
     TailCtx ctx{w, sigma2, 0.f, out, alpha, N, Np, 1};
+    if (groups == 0 && w.batch) {
+        // the one-launch batched step (batch_step.hip) is what this shape runs: class 0 = that one launch (factorisation AND
+        // inverse: the whole step's 2 N^3 / 3), class 1 empty
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (int)hipGetLastError();
+        int rc = volt_internal_batch_step(K, ldk, bsk, sigma2, 0.f, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob, B, N, w.z,
+                                          w.apart, w.batch, w.batch_bytes, stream, e0, e1);
+        if (rc == 1) {
+            batch_tail(ctx, B, (hipStream_t)stream);
+            hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            ms_sum_host[0] = ms_union_host[0] = ms;
+            ms_sum_host[1] = ms_union_host[1] = 0.f;
+            launches_host[0] = 1;
+            launches_host[1] = 0;
+            if (per_launch_host) per_launch_host[0] = ms;
+            rc = e != hipSuccess ? (int)e : 0;
+        } else if (rc == 0) {
+            rc = -8;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    }
     // groups > 0 forces that many stream groups and (like the round-2 hook) switches the small-batch schedules off
     return volt_internal_profile(K, ldk, bsk, sigma2, w.A, w.Winv, w.Y, info, w.rpad, w.zpart, w.frob, B, N, groups, stream,
                                  w.sk_slab, w.sk_count, w.sk_rows, w.tab, w.tab_bytes, mll_tail, &ctx, ms_sum_host,
