@@ -18,6 +18,7 @@ dump = args[args.index("--dump") + 1] if "--dump" in args else None
 cmp_ = args[args.index("--cmp") + 1] if "--cmp" in args else None
 nrep = int(args[args.index("--reps-check") + 1]) if "--reps-check" in args else 0
 ref = torch.load(cmp_) if cmp_ else {}
+full = [None]
 out = {}
 
 
@@ -35,6 +36,8 @@ def snapshot(ws, B, n, Np):
     offY = al(nA) + al(B * (Np // 128) * 128 * 128) + 4 * al(B * Np)
     A = torch.tril(flat[:nA].view(B, Np, Np))
     Y = torch.triu(flat[offY: offY + nA].view(B, Np, Np))
+    if "--full" in args and nA * 4 <= (1 << 29):
+        full[0] = (A.cpu().clone(), Y.cpu().clone())
     return tile_sums(A, Np).cpu(), tile_sums(Y, Np).cpu()
 
 
@@ -53,6 +56,9 @@ for sh in shapes:
     torch.cuda.synchronize()
     tA, tY = snapshot(ws, B, n, Np)
     cur = dict(out=o.cpu().clone(), alpha=a.cpu().clone(), info=info.cpu().clone(), tA=tA, tY=tY)
+    if full[0] is not None:
+        cur["A"], cur["Y"] = full[0]
+        full[0] = None
     out[sh] = cur
     msg = f"{sh:>9s}: info {int(info.abs().sum())}"
     if sh in ref:
@@ -61,6 +67,17 @@ for sh in shapes:
         msg += "  bitwise " + ("OK  " if all(eq.values()) else "FAIL " + str(eq))
         if not eq["tA"]: msg += f" L tiles {(rf['tA'] != tA).nonzero()[:5].tolist()}"
         if not eq["tY"]: msg += f" Y tiles {(rf['tY'] != tY).nonzero()[:5].tolist()}"
+        for nm, tk in (("A", "tA"), ("Y", "tY")):
+            if nm in rf and nm in cur and not eq[tk]:
+                d = (rf[nm] != cur[nm])
+                bad = (rf[tk] != cur[tk]).nonzero()
+                # the differing tile that nothing wrong feeds: smallest (row + col) sum is a decent proxy
+                b0, r0, c0 = min(bad.tolist(), key=lambda t: (t[1] + t[2], t[0]))
+                sub = d[b0, r0 * 128:(r0 + 1) * 128, c0 * 128:(c0 + 1) * 128]
+                rows = sub.any(dim=1).nonzero().flatten().tolist(); cols = sub.any(dim=0).nonzero().flatten().tolist()
+                msg += f"\n      {nm} tile {(b0, r0, c0)}: {int(sub.sum())} elements differ; rows {rows[:40]}{'...' if len(rows) > 40 else ''} cols {cols[:40]}{'...' if len(cols) > 40 else ''}"
+                rr, cc = rows[0], cols[0]
+                msg += f" e.g. [{rr},{cc}] ref {rf[nm][b0, r0 * 128 + rr, c0 * 128 + cc].item():.6g} got {cur[nm][b0, r0 * 128 + rr, c0 * 128 + cc].item():.6g}"
         if not eq["out"]: msg += f" out ref {rf['out'][0, :6].tolist()} got {cur['out'][0, :6].tolist()}"
     if nrep:
         bad = 0

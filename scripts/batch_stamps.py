@@ -55,6 +55,11 @@ for k in (2, 3):
     m = kind == k
     if m.any():
         print(f"  {names[k]}: entry->pipeline {np.mean(kb[m] - beg[m]):6.2f} us, pipeline {np.mean(ke[m] - kb[m]):7.2f} us, store+publish {np.mean(end[m] - ke[m]):6.2f} us (means)")
+if s.shape[1] >= 8 and (s[:, 5] > 0).any():
+    t5, t6, t7 = (s[:, 5] - t0) / 100.0, (s[:, 6] - t0) / 100.0, (s[:, 7] - t0) / 100.0
+    for k in (2, 3):
+        m = kind == k
+        print(f"  {names[k]}: entry->item loaded {np.mean(t5[m] - beg[m]):5.2f}, ->pipeline {np.mean(kb[m] - t5[m]):5.2f}; pipeline end->reduced {np.mean(t6[m] - ke[m]):5.2f}, ->tile stored + drained (thread 0) {np.mean(t7[m] - t6[m]):5.2f}, ->exit {np.mean(end[m] - t7[m]):5.2f} us")
 # per CU: how much of the launch had 0 / 1 / 2 workgroups INSIDE a pipeline (two-phase tiles: stamps 3..4; look-ahead: whole piece)
 key = ((xcc * 8 + se) * 2 + sh_) * 16 + cu
 pb = np.where((kind == 2) | (kind == 3), kb, beg); pe = np.where((kind == 2) | (kind == 3), ke, end)

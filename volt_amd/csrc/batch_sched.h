@@ -30,7 +30,7 @@ struct BatchItem {           // 16 bytes, read as one int4 on the device
     int kind_b;              // kind | b << 3
     int row;                 // D: k;  LA: k (the tile is (k+1,k+1));  P: i;  T / TD: i;  AL: c
     int col;                 // P: k;  T: j;  AL: which chunk of BATCH_ALPHA_ROWS rows;  else 0
-    int pad;
+    int pad;                 // the table's check word (batch_step.hip), the same in every piece
 };
 
 constexpr int BATCH_MAGIC = 0x564f4c42;        // "VOLB"

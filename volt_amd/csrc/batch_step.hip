@@ -47,47 +47,58 @@ __global__ void batch_begin_kernel(float* __restrict__ Winv, int nflags, int* __
 }
 
 // thread 0 waits for *p >= want (p may be nullptr), then one agent-scope acquire; a barrier for the rest
-__device__ __forceinline__ bool word_ge(const int* p, int want) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
-}
+template <bool LOCALP>
+__device__ __forceinline__ bool word_ge(const int* p, int want) { return poll_word<LOCALP>(p) >= want; }
+template <bool LOCALP>
 __device__ __forceinline__ bool wait_word_ge(const int* p, int want) {
-    if (word_ge(p, want)) return true;
+    if (word_ge<LOCALP>(p, want)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
-    while (!word_ge(p, want)) {
+    while (!word_ge<LOCALP>(p, want)) {
         __builtin_amdgcn_s_sleep(2);
         if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
     }
     return true;
 }
+template <bool LOCALP>
 __device__ __forceinline__ void batch_wait(const int* p0, int want0, const int* p1, int want1, int* info_b) {
     if (threadIdx.x == 0) {
         bool ok = true;
-        if (p0) ok = wait_word_ge(p0, want0);
-        if (p1) ok = wait_word_ge(p1, want1) && ok;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (p0) ok = wait_word_ge<LOCALP>(p0, want0);
+        if (p1) ok = wait_word_ge<LOCALP>(p1, want1) && ok;
+        acquire_unless_local<LOCALP>();
         if (!ok) atomicCAS(info_b, 0, (int)0x80000000);
     }
     __syncthreads();
 }
-// behind plain stores: drain, barrier, agent-scope release, the word
+// behind plain stores: drain, barrier, agent-scope release, the word.  LOCALP (readers on this XCD): the drain alone -- the
+// stores are in this L2 -- and a plain store of the word, which keeps its line there for the polls
+template <bool LOCALP>
 __device__ __forceinline__ void batch_publish_release(int* word, int val) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (LOCALP) {
+            *reinterpret_cast<volatile int*>(word) = val;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 // behind written-through (sc1) stores: every storing wave drains, then the word -- nothing is left in L2 to write back
+template <bool LOCALP>
 __device__ __forceinline__ void batch_publish_wt(int* word, int val) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        if constexpr (LOCALP) *reinterpret_cast<volatile int*>(word) = val;
+        else __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
-constexpr int AUX_WT = AUX_SC1 | 2;            // sc1 + nt: written through at agent scope, streaming
+constexpr int AUX_WT = AUX_SC1;                // sc1: written through at agent scope (never nt on a hand-off: MI355X_MICROARCH.md)
 
 // First diagonal tile straight from the caller's K (+ sigma2 / jitter on the diagonal, identity in the padding) into the
 // pivot image: no prepared copy of block column 0, no launch ahead of the step for it.
@@ -123,7 +134,7 @@ __device__ __forceinline__ void alpha_item(const float* __restrict__ Y, const Tr
     for (int r = r0 + 32 * wave; r < r1; r += 128) {
         f32x4 y[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) y[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Yc + (int64_t)(r + 2 * u) * Np));
+        for (int u = 0; u < 16; ++u) y[u] = *reinterpret_cast<const f32x4*>(Yc + (int64_t)(r + 2 * u) * Np);
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             float lo, hi;
@@ -140,11 +151,14 @@ __device__ __forceinline__ void alpha_item(const float* __restrict__ Y, const Tr
 // the two-phase tiles the time the pipeline is entered and left
 static long long* g_batch_stamps = nullptr;
 
-template <bool FROMK>
+// LOCAL: the batch is a multiple of 8, so every piece of a matrix runs on ONE XCD (piece w on XCD w % 8, matrix w % 8 mod
+// 8) and that XCD's L2 is where its tiles are handed on: plain (non-temporal) stores, acknowledged by the L2, instead of
+// write-through to memory -- the word of a tile follows its stores after ~1 us instead of ~10.
+template <bool FROMK, bool LOCAL>
 __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                            float* __restrict__ Y, int* __restrict__ info, int Np, int B,
                                                            KSource src, TriReduce red, const int4* __restrict__ tab,
-                                                           int* __restrict__ prog, int pstride, int4 key0, int4 key1,
+                                                           int* __restrict__ prog, int pstride, int check,
                                                            float* __restrict__ zvec, float* __restrict__ apart,
                                                            long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
@@ -159,15 +173,15 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
         __device__ ~Exit() { if (st && threadIdx.x == 0) st[(int64_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
     } exit_stamp{stamps};
     {   // the caller's scratch must hold the table this launch was sized for: anything else is reported, never followed
-        const int4 h0 = tab[0], h1 = tab[1];
-        if (h0.x != key0.x || h0.y != key0.y || h0.z != key0.z || h0.w != key0.w || h1.x != key1.x || h1.y != key1.y ||
-            h1.z != key1.z || h1.w != key1.w) {
+        const int4 h0 = tab[0];
+        if (h0.x != BATCH_MAGIC || h0.y != B || h0.z != n || h0.w != check) {
             if (blockIdx.x == 0)
                 for (int b = threadIdx.x; b < B; b += NT) info[b] = (int)0x80000001;
             return;
         }
     }
     const int4 d = tab[BATCH_HDR + blockIdx.x];
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     const int kind = d.x & 7, b = d.x >> 3;
     int* rowp = prog + (int64_t)b * pstride;
     int* tcol = rowp + n;
@@ -180,17 +194,17 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
         if (k == 0) {
             if (usek) {
                 diag0_image(src, b, smem);
-                diag_body(A, Winv, info, Np, 0, b, smem, nullptr, true);
+                diag_body<false, false, LOCAL>(A, Winv, info, Np, 0, b, smem, nullptr, true);
             } else {
-                diag_body(A, Winv, info, Np, 0, b, smem, nullptr, false);
+                diag_body<false, false, LOCAL>(A, Winv, info, Np, 0, b, smem, nullptr, false);
             }
             return;
         }
         // L[k,k-1] (and with it all of row k) is there; k >= 2: the look-ahead part of A[k,k] is parked
-        batch_wait(rowp + k, k, k >= 2 ? la + k : nullptr, 1, info_b);
+        batch_wait<LOCAL>(rowp + k, k, k >= 2 ? la + k : nullptr, 1, info_b);
         if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, b, src, smem, true);
         else update_body<FROMK>(A, Np, 1, 1, 0, 1, true, b, src, smem, true);
-        diag_body(A, Winv, info, Np, k, b, smem, nullptr, true);
+        diag_body<false, false, LOCAL>(A, Winv, info, Np, k, b, smem, nullptr, true);
         return;
     }
     if (kind == BK_LOOKAHEAD) {
@@ -198,24 +212,24 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
         Chase ch;
         ch.p0 = ch.p1 = rowp + k + 1;
         bool ok = true;
-        update_body<FROMK, 0, true>(A, Np, k + 1, k + 1, 0, k, true, b, src, smem, false, &ch, &ok);
+        update_body<FROMK, 0, true, LOCAL>(A, Np, k + 1, k + 1, 0, k, true, b, src, smem, false, &ch, &ok);
         if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);
-        batch_publish_release(la + k + 1, 1);
+        batch_publish_release<LOCAL>(la + k + 1, 1);
         return;
     }
     if (kind == BK_TRTRI_DIAG) {
         const int i = d.y;
-        batch_wait(reinterpret_cast<const int*>(Winv + ((int64_t)b * n + i) * TS * TS), 1, nullptr, 0, info_b);
+        batch_wait<LOCAL>(reinterpret_cast<const int*>(Winv + ((int64_t)b * n + i) * TS * TS), 1, nullptr, 0, info_b);
         trtri_diag_body(Winv, Y, Np, i, b, red, smem);
-        batch_publish_release(tcol + i, 1);
+        batch_publish_release<LOCAL>(tcol + i, 1);
         return;
     }
     if (kind == BK_ALPHA) {
         const int c = d.y;
         if (threadIdx.x <= c) {                              // row c of the inverse is complete: tcol[j] >= c - j + 1, j <= c
-            if (!wait_word_ge(tcol + threadIdx.x, c - (int)threadIdx.x + 1)) atomicCAS(info_b, 0, (int)0x80000000);
+            if (!wait_word_ge<LOCAL>(tcol + threadIdx.x, c - (int)threadIdx.x + 1)) atomicCAS(info_b, 0, (int)0x80000000);
         }
-        if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x < 64) acquire_unless_local<LOCAL>();
         __syncthreads();
         alpha_item(Y, red, zvec, apart, Np, b, c, d.z);
         return;
@@ -243,15 +257,19 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
     }
     f32x16 T[4], O[4];
     ChasePre pre = {0, 0};
-    if (jb.t.n1 > 0) pre = chase_issue(jb.t.ch);             // the polls go out ahead of the input tile's loads: one round trip
+    if (jb.t.n1 > 0) pre = chase_issue<LOCAL>(jb.t.ch);             // the polls go out ahead of the input tile's loads: one round trip
     job_t0(jb, T);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-    const bool ok = tri_tile_run<true>(jb.t, T, O, smem, &pre);
+    const bool ok = tri_tile_run<true, LOCAL>(jb.t, T, O, smem, &pre);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);   // a hand-off timed out: internal error
-    tri_store_aux<AUX_WT>(O, jb.out, Np);
-    if (jb.i >= 0 && red.rpad) trtri_reduce<true>(O, Np, jb.i, jb.j, jb.b, red, smem);
-    batch_publish_wt(word, val);
+    // the reductions of a tile of the inverse first (they read the accumulators and use LDS behind the tile image), then
+    // the tile: its stores are the last thing before the drain
+    if (jb.i >= 0 && red.rpad) trtri_reduce<!LOCAL>(O, Np, jb.i, jb.j, jb.b, red, smem + TS * WLD);
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    tri_store_lds<LOCAL ? 0 : AUX_WT>(O, jb.out, Np, smem);
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+    batch_publish_wt<LOCAL>(word, val);
 }
 
 }  // namespace volt
@@ -280,9 +298,9 @@ size_t volt_internal_batch_bytes(int B, int n, int has_y) {
     return batch_table_bytes(B, n, has_y != 0) + batch_prog_bytes(B, n);
 }
 
-static void batch_keys(int B, int n, bool has_y, int4& k0, int4& k1) {
-    k0 = int4{BATCH_MAGIC, B, n, has_y ? 1 : 0};
-    k1 = int4{tunables().batch_order, (int)batch_count(B, n, has_y), 0, 0};
+// the word every piece of a table carries: what the table was built for
+static int batch_check_word(int B, int n, bool has_y) {
+    return BATCH_MAGIC ^ (B * 0x01000193) ^ (n << 20) ^ (has_y ? 0x40000000 : 0) ^ (tunables().batch_order << 28);
 }
 
 // The table, built once per (B, n, inverse?, order) in pinned host memory and kept for the life of the library (host
@@ -311,7 +329,8 @@ static const BatchTable* get_batch_table(int B, int n, bool has_y) {
         bt = nullptr;
     } else {
         memset(bt->items, 0, BATCH_HDR * sizeof(BatchItem));
-        batch_keys(B, n, has_y, bt->items[0], bt->items[1]);
+        bt->items[0] = int4{BATCH_MAGIC, B, n, batch_check_word(B, n, has_y)};
+        for (BatchItem& it : items) it.pad = batch_check_word(B, n, has_y);
         memcpy(bt->items + BATCH_HDR, items.data(), items.size() * sizeof(BatchItem));
     }
     cache[key] = bt;
@@ -346,18 +365,20 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
     if (blocks > 256) blocks = 256;
     if (blocks * 256 < std::max(nflags, B)) blocks = (std::max(nflags, B) + 255) / 256;
     hipLaunchKernelGGL(batch_begin_kernel, dim3(blocks), dim3(256), 0, s, Winv, nflags, info, B, prog, nprog);
-    int4 k0, k1;
-    batch_keys(B, n, has_y, k0, k1);
+    const int check = batch_check_word(B, n, has_y);
+    const bool local = (B & 7) == 0 && tunables().batch_local != 0;
     const KSource src{K, ldk, bsk, sigma2, jitter, N};
     const TriReduce red{has_y ? rpad : nullptr, zpart, frob, N};
     const unsigned grid = (unsigned)batch_count(B, n, has_y);
     if (e0 && hipEventRecord(e0, s) != hipSuccess) return (int)hipGetLastError();
-    if (K)
-        hipLaunchKernelGGL(batch_step_kernel<true>, dim3(grid), dim3(256), 0, s, A, Winv, Y, info, Np, B, src, red, tab, prog,
-                           pstride, k0, k1, z, apart, g_batch_stamps);
-    else
-        hipLaunchKernelGGL(batch_step_kernel<false>, dim3(grid), dim3(256), 0, s, A, Winv, Y, info, Np, B, src, red, tab, prog,
-                           pstride, k0, k1, z, apart, g_batch_stamps);
+#define VOLT_BATCH_LAUNCH(FK, LC)                                                                                         \
+    hipLaunchKernelGGL((batch_step_kernel<FK, LC>), dim3(grid), dim3(256), 0, s, A, Winv, Y, info, Np, B, src, red, tab, prog, \
+                       pstride, check, z, apart, g_batch_stamps)
+    if (K && local) VOLT_BATCH_LAUNCH(true, true);
+    else if (K) VOLT_BATCH_LAUNCH(true, false);
+    else if (local) VOLT_BATCH_LAUNCH(false, true);
+    else VOLT_BATCH_LAUNCH(false, false);
+#undef VOLT_BATCH_LAUNCH
     if (e1 && hipEventRecord(e1, s) != hipSuccess) return (int)hipGetLastError();
     hipError_t e = hipGetLastError();
     return e != hipSuccess ? (int)e : 1;

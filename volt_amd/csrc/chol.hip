@@ -1487,6 +1487,7 @@ const Tunables& tunables() {
         geti("VOLT_SPLIT_SPREAD", t.split_spread);
         geti("VOLT_BATCH", t.batch);
         geti("VOLT_BATCH_ORDER", t.batch_order);
+        geti("VOLT_BATCH_LOCAL", t.batch_local);
         geti("VOLT_BATCH_MINB", t.batch_minb);
         geti("VOLT_BATCH_MINN", t.batch_minn);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);

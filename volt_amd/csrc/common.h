@@ -300,33 +300,55 @@ __device__ __forceinline__ void chunk_run(const float* cur, float* nxt, Frag<WL>
 // traffic.  Every wave polls for itself (the chunk barriers keep the waves of a workgroup within a chunk of each other,
 // and each has seen for itself that what it loads is there); a tile that finds everything complete on entry -- the
 // common case in a large batch -- never polls again.
-constexpr unsigned long long CHASE_LIMIT_TICKS = 300000000ull;   // 3 s of the 100 MHz s_memrealtime counter (WAIT_LIMIT_TICKS below)
+#ifndef VOLT_WAIT_TICKS
+#define VOLT_WAIT_TICKS 300000000ull
+#endif
+constexpr unsigned long long CHASE_LIMIT_TICKS = VOLT_WAIT_TICKS;   // 3 s of the 100 MHz s_memrealtime counter (WAIT_LIMIT_TICKS below)
+// A poll of a hand-off word: an sc1 load -- past this CU's L1, served by the XCD's L2 (or by memory when the line was
+// dropped there by a written-through store).
+// LOCALP, the template switch of the waits below: the writer of everything handed on is known to sit on the SAME XCD as the
+// reader (batch_step.hip with a batch that is a multiple of 8) and every address handed on is written ONCE per launch,
+// before anything in the launch reads it.  The XCD's L2 is then the point of coherence and no line of the data can be stale
+// in the reader's L1 (invalidated at kernel start, never filled since), so the waits carry NO acquire fence -- an
+// agent-scope acquire (buffer_inv sc1) costs 1.7 us and more per wave that issues it (MI355X_MICROARCH.md).
+template <bool LOCALP>
+__device__ __forceinline__ int poll_word(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool LOCALP>
+__device__ __forceinline__ void acquire_unless_local() {
+    if constexpr (!LOCALP) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    else asm volatile("" ::: "memory");                      // (the compiler keeps later loads behind the poll all the same)
+}
 struct Chase {
     const int* p0 = nullptr;     // progress word of the X operand's source
     const int* p1 = nullptr;     // ... of the Z operand's
     int base0 = 0, base1 = 0;    // the word's value when block 0 of this tile's K range is NOT yet there
 };
+template <bool LOCALP = false>
 __device__ __forceinline__ int chase_poll(const Chase& ch) {
-    const int v0 = __hip_atomic_load(ch.p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.base0;
-    const int v1 = __hip_atomic_load(ch.p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.base1;
+    const int v0 = poll_word<LOCALP>(ch.p0) - ch.base0;
+    const int v1 = poll_word<LOCALP>(ch.p1) - ch.base1;
     return __builtin_amdgcn_readfirstlane(v0 < v1 ? v0 : v1);
 }
 // The two polls issued EARLY (their results are not waited for here): a tile puts them ahead of the loads of its input
 // tile, so that one memory round trip covers both; chase_wait_pre then starts from what they brought.
 struct ChasePre { int v0, v1; };
+template <bool LOCALP = false>
 __device__ __forceinline__ ChasePre chase_issue(const Chase& ch) {
     ChasePre p;
-    p.v0 = __hip_atomic_load(ch.p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    p.v1 = __hip_atomic_load(ch.p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.v0 = poll_word<LOCALP>(ch.p0);
+    p.v1 = poll_word<LOCALP>(ch.p1);
     return p;
 }
 // leading K blocks of the tile that are complete: >= need on return, or the last value seen after a time-out (ok = false)
+template <bool LOCALP = false>
 __device__ __forceinline__ int chase_wait(const Chase& ch, int need, bool& ok) {
-    int r = chase_poll(ch);
+    int r = chase_poll<LOCALP>(ch);
     if (r < need) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
-        while ((r = chase_poll(ch)) < need) {
+        while ((r = chase_poll<LOCALP>(ch)) < need) {
             __builtin_amdgcn_s_sleep(2);
             if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > CHASE_LIMIT_TICKS) {
                 ok = false;
@@ -334,24 +356,25 @@ __device__ __forceinline__ int chase_wait(const Chase& ch, int need, bool& ok) {
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    acquire_unless_local<LOCALP>();
     return r;
 }
+template <bool LOCALP = false>
 __device__ __forceinline__ int chase_wait_pre(const Chase& ch, const ChasePre& pre, int need, bool& ok) {
     const int a = pre.v0 - ch.base0, b = pre.v1 - ch.base1;
     const int r = __builtin_amdgcn_readfirstlane(a < b ? a : b);
-    if (r < need) return chase_wait(ch, need, ok);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (r < need) return chase_wait<LOCALP>(ch, need, ok);
+    acquire_unless_local<LOCALP>();
     return r;
 }
 
-template <int WL, bool CHASE = false>
+template <int WL, bool CHASE = false, bool LOCALP = false>
 __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                int64_t ldb, int nchunks, f32x16 (&acc)[4], float* smem,
                                                const Chase* ch = nullptr, bool* ch_ok = nullptr) {
     if (nchunks <= 0) return;
     int ready = 0;                             // CHASE: leading K blocks known complete
-    if constexpr (CHASE) ready = chase_wait(*ch, 1, *ch_ok);
+    if constexpr (CHASE) ready = chase_wait<LOCALP>(*ch, 1, *ch_ok);
     StageRegs s0, s1;
     const StageAddr sa = stage_addr(A, lda, B, ldb);
     stage_load_buf(s0, sa, 0);                 // (nchunks >= 4: chunks 1 and 2 exist)
@@ -371,7 +394,7 @@ __device__ __forceinline__ void gemm_nt_128(const float* __restrict__ A, int64_t
     for (; c + SEG_CHUNKS < nchunks; c += SEG_CHUNKS) {        // every segment but the last: all loads / stores / reads exist
         if constexpr (CHASE) {                 // this segment requests the next block's chunks
             const int need = (c >> 2) + 2;
-            if (ready < need) ready = chase_wait(*ch, need, *ch_ok);
+            if (ready < need) ready = chase_wait<LOCALP>(*ch, need, *ch_ok);
         }
         chunk_run<WL, true, true, true, SEG_FIRST>(b0, b1, F0, F1, P, acc, s0, sa, (c + 3) * BK);
         chunk_run<WL, true, true, true>(b1, b0, F0, F1, P, acc, s1, sa, (c + 4) * BK);
@@ -534,18 +557,23 @@ __device__ __forceinline__ void tri_chunk_p2(const float* cur, float* nxt, f32x1
 
 // Hand-off waits are bounded by WALL CLOCK (s_memrealtime: a constant 100 MHz counter), not by an iteration count: a
 // preempted or profiled run spins more often, not longer.  3 s -- only a bug or a wedged device gets there.
-constexpr unsigned long long WAIT_LIMIT_TICKS = 300000000ull;
+#ifndef VOLT_WAIT_TICKS
+#define VOLT_WAIT_TICKS 300000000ull
+#endif
+constexpr unsigned long long WAIT_LIMIT_TICKS = VOLT_WAIT_TICKS;
 // `want` = 0: wait for a non-zero word;  else wait for the word to EQUAL `want` (flags that carry the number of the step
 // they belong to and are never cleared: small_step_kernel in chol.hip).
+template <bool LOCALP = false>
 __device__ __forceinline__ bool flag_is_set(const int* flag, int want) {
-    const int v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int v = poll_word<LOCALP>(flag);
     return want ? v == want : v != 0;
 }
+template <bool LOCALP = false>
 __device__ __forceinline__ bool wait_flag(const int* flag, int want, int sleep) {
-    if (flag_is_set(flag, want)) return true;
+    if (flag_is_set<LOCALP>(flag, want)) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     unsigned spins = 0;
-    while (!flag_is_set(flag, want)) {
+    while (!flag_is_set<LOCALP>(flag, want)) {
         if (sleep == 2) __builtin_amdgcn_s_sleep(2);
         else __builtin_amdgcn_s_sleep(4);
         if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
@@ -553,11 +581,12 @@ __device__ __forceinline__ bool wait_flag(const int* flag, int want, int sleep) 
     return true;
 }
 __device__ __forceinline__ bool wait_nonzero(const int* flag, int sleep) { return wait_flag(flag, 0, sleep); }
+template <bool LOCALP = false>
 __device__ __forceinline__ bool flag_wait_one_lane(const int* flag, int want = 0) {
     bool ok = true;
     if (threadIdx.x == 0) {
-        ok = wait_flag(flag, want, 4);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        ok = wait_flag<LOCALP>(flag, want, 4);
+        acquire_unless_local<LOCALP>();
     }
     return ok;       // meaningful in thread 0 only
 }
@@ -573,7 +602,7 @@ __device__ __forceinline__ void flag_publish(int* flag) {
 
 // T holds T0 on entry; O (zeroed here) holds the product on exit.  Returns false if a wait timed out (the W flag: in
 // thread 0;  CHASE: in every lane of the wave that gave up).
-template <bool CHASE = false>
+template <bool CHASE = false, bool LOCALP = false>
 __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f32x16 (&O)[4], float* smem,
                                              const ChasePre* pre = nullptr) {
     const int tid = threadIdx.x;
@@ -592,10 +621,10 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
     bool ok = true;
     int ready = 0;                                   // CHASE: leading K blocks known complete
     if constexpr (CHASE) {
-        if (t.n1 > 0) ready = pre ? chase_wait_pre(t.ch, *pre, 1, ok) : chase_wait(t.ch, 1, ok);
+        if (t.n1 > 0) ready = pre ? chase_wait_pre<LOCALP>(t.ch, *pre, 1, ok) : chase_wait<LOCALP>(t.ch, 1, ok);
     }
     if (t.flag && t.n1 == 0) {                       // no phase 1 to hide behind: W is the first thing needed
-        ok = flag_wait_one_lane(t.flag, t.want);
+        ok = flag_wait_one_lane<LOCALP>(t.flag, t.want);
         __syncthreads();
     }
     StageRegs s0, s1;
@@ -620,7 +649,7 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
         for (; c + SEG_CHUNKS < t.n1; c += SEG_CHUNKS) {          // every segment but the last: its prefetches are phase-1 chunks too
             if constexpr (CHASE) {                                // this segment requests the next block's chunks
                 const int need = (c >> 2) + 2;
-                if (ready < need) ready = chase_wait(t.ch, need, ok);
+                if (ready < need) ready = chase_wait<LOCALP>(t.ch, need, ok);
             }
             tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, O, T, s0, ts);
             tri_chunk_p1<true, 1, 1>(b1, b0, c + 1, F0, F1, O, T, s1, ts);
@@ -628,7 +657,7 @@ __device__ __forceinline__ bool tri_tile_run(const TriTile& t, f32x16 (&T)[4], f
             tri_chunk_p1<true, 1, 1, SEG_LAST>(b1, b0, c + 3, F0, F1, O, T, s1, ts);
         }
         // the last segment of phase 1: the W chunks (n1 .. n1+3) come into view
-        if (t.flag) ok = flag_wait_one_lane(t.flag, t.want) && ok;      // barriers below order the acquire
+        if (t.flag) ok = flag_wait_one_lane<LOCALP>(t.flag, t.want) && ok;      // barriers below order the acquire
         tri_chunk_p1<true, 1, 1, SEG_FIRST>(b0, b1, c, F0, F1, O, T, s0, ts);
         tri_chunk_p1<true, 1, 2>(b1, b0, c + 1, F0, F1, O, T, s1, ts);
         tri_chunk_p1<true, 1, 2>(b0, b1, c + 2, F0, F1, O, T, s0, ts);

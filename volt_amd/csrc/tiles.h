@@ -34,7 +34,7 @@ __device__ __forceinline__ float input_elem(const KSource& src, const float* Kb,
 // launch (diagonal look-ahead, see factor_step_kernel).  The C tile is loaded NEGATED straight into the accumulators
 // before the K loop (acc = -C + sum, C <- -acc): nothing is held back for an epilogue read-modify-write, and no
 // prefetch registers are carried through the loop.
-template <bool FROMK, int ABL = 0, bool CHASE = false>
+template <bool FROMK, int ABL = 0, bool CHASE = false, bool LOCALP = false>
 __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int rowblk, int colblk, int kb0, int kb1,
                                             bool fromk, int b, const KSource& src, float* smem,
                                             bool to_image = false, const Chase* ch = nullptr, bool* ch_ok = nullptr) {
@@ -59,7 +59,7 @@ __device__ __forceinline__ void update_body(float* __restrict__ A, int Np, int r
                 if (ABL & 1) acc[tm * 2 + tn][q] = 0.f;         // ablation (tuning only): no C load
                 else acc[tm * 2 + tn][q] = -input_elem(src, Kb, add, Ab, Np, usek, rowblk * TS + r, colblk * TS + c);
             }
-    gemm_nt_128<0, CHASE>(Arows, Np, Brows, Np, (kb1 - kb0) * (TS / BK), acc, smem, ch, ch_ok);
+    gemm_nt_128<0, CHASE, LOCALP>(Arows, Np, Brows, Np, (kb1 - kb0) * (TS / BK), acc, smem, ch, ch_ok);
     if (ABL & 2) {                                                 // ablation (tuning only): one store per thread
         float sum = 0.f;
 #pragma unroll
@@ -456,7 +456,9 @@ __device__ __forceinline__ void w_out(__amdgpu_buffer_rsrc_t rs, int i, int j, f
 // inverts sub-block kb-1 also copies the blocks below it, L[kb.., kb-1], out of the image and publishes slab[kb-1] =
 // ready_val behind its own release, so that the tiles below this block are solved by substitution (substitute_tile)
 // while the later pivots are still running, and nothing on the way down waits for the inverse.
-template <bool STAMP = false, bool SLABS = false>
+// LOCALPUB (batch_step.hip, batch a multiple of 8): the readers of W_k sit on this XCD -- the block is handed on through its
+// L2, behind the storing waves' drain alone: no L2-wide write-back (1.7 - 6.5 us on every block column's critical path).
+template <bool STAMP = false, bool SLABS = false, bool LOCALPUB = false>
 __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restrict__ Winv, int* __restrict__ info,
                                           int Np, int k, int b, float* smem, long long* stamps = nullptr,
                                           bool loaded = false, int* ready = nullptr, int ready_val = 0,
@@ -622,9 +624,13 @@ __device__ __forceinline__ void diag_body(float* __restrict__ A, float* __restri
     __syncthreads();
     VOLT_STAMP(12);
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const int bits = __float_as_int(sT[0]);
-        __hip_atomic_store(reinterpret_cast<int*>(W), bits ? bits : 0x7fc00000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (LOCALPUB) {
+            *reinterpret_cast<volatile int*>(W) = bits ? bits : 0x7fc00000;     // a plain store: the line stays in this L2
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(reinterpret_cast<int*>(W), bits ? bits : 0x7fc00000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         // small_step_kernel: the step-numbered flag it waits on instead (W's first word is never cleared there)
         if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -698,6 +704,41 @@ __device__ __forceinline__ void tri_store_aux(const f32x16 (&O)[4], float* __res
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(-O[rb][q]), rs, voff, ((q & 3) + 8 * (q >> 2)) * ld4 + rb * 128, AUX);
+}
+
+// The same tile TRANSPOSED THROUGH LDS into 16-byte stores: the accumulators hold a tile column per lane (64 dword stores
+// per lane, 256 per workgroup -- measured 9.5 us to issue beside a co-resident tile's loads); through the staging area
+// (free once the pipeline has ended) a wave turns its own 32 rows into whole 512-byte rows per half-wave: 16 stores per
+// lane.  A wave reads back only what it wrote, so no barrier -- LDS operations of one wave execute in order.  Uses
+// smem[0, TS * WLD).  Returns with every store of this wave DRAINED (vmcnt = 0).
+// HAZARD (gfx950, found the hard way): a 16-byte store reads its data registers some time AFTER it is issued when the
+// memory pipeline is backed up, and neither the hardware nor the compiler's hazard recognizer keeps a VALU write (or a
+// returning LDS read) of those registers behind it -- a first version that rotated three register sets through the loop
+// stored the constant of an unrelated `v_or_b32 v10, 30, ..` that the scheduler had placed right behind
+// `buffer_store_dwordx4 v[10:13]` (16 wrong elements in one tile of ~1000).  Hence: all sixteen rows are read into registers
+// of their own, then the stores go out back to back with nothing in between, and nothing follows before they have drained.
+template <int AUX>
+__device__ __forceinline__ void tri_store_lds(const f32x16 (&O)[4], float* __restrict__ Out, int64_t ldo, float* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, lh = lane >> 5;
+    float* mine = smem + wave * 32 * WLD;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mine[accrow(q, lane) * WLD + rb * 32 + l31] = -O[rb][q];
+    wave_lds_fence();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Out, 0, 0x7fffffff, 0x00020000);
+    const int voff = (int)((((int64_t)(wave * 32 + lh)) * ldo + 4 * l31) * 4);
+    const int ld8 = (int)(ldo * 8);                          // two rows on, in bytes
+    f32x4 v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const f32x4*>(mine + (2 * it + lh) * WLD + 4 * l31);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    VOLT_SB();
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[it]), rs, voff, it * ld8, AUX);
+    VOLT_SB();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // diagonal tile of row i: Y[i,i] = W_i^T (transposed through LDS so both sides stay coalesced)
