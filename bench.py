@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--with-rollouts", action="store_true", help="run the rollout leg even under --no-aux-legs")
     ap.add_argument("--rollout-samples", type=int, default=10000)
     ap.add_argument("--rollout-horizon", type=int, default=256)
+    ap.add_argument("--profile-only", type=int, default=0, metavar="N",
+                    help="for `rocprofv3 --kernel-trace --stats`: after the set-up run EXACTLY N gradient steps through the "
+                         "roofline hook (each bracketed by HIP events and synchronised), no warm-up, no other leg, and print "
+                         "their mean kernel time: the trace's average duration of the step kernel over the same N launches "
+                         "reproduces roofline.class_ms")
     ap.add_argument("--no-aux-legs", action="store_true",
                     help="skip the ms/Cholesky and forward-only legs (used for the rocprofv3 summaries in profiles/, so "
                          "that every factor_step_kernel<true> launch in the trace is a gradient-step launch)")
@@ -219,6 +224,9 @@ def main():
         return max(per_rank), per_rank, info
 
     step, raw_noise, ws, red = make_step(B)
+    if args.profile_only > 0:
+        profile_only_leg(args.profile_only, K_all[:B], y_all[:B], raw_noise, ws, n, B, dev)
+        return
     dt, dt_ranks, info = timed(step, args.warmup, args.steps)
     bad = int((info != 0).sum().item())
     loss = float(red[0].item()) / (B * world)
@@ -266,29 +274,35 @@ def main():
         names = ["factor_step_kernel<true>", "factor_step_kernel<false>(last trtri row)"]
         flops = kernel_class_flops(B, Np)
         sum_t, un_t, cnt = profile(0)                       # the schedule the timed steps ran in
-        sum_1, un_1, cnt1 = profile(1)                      # lockstep: one stream, whole batch per launch
-        dom = int(np.argmax(un_t))
-        ach = flops[dom] / (un_t[dom] * 1e-3) / 1e12
-        traffic = None
-        try:      # HBM bytes per launch from the PMC passes (scripts/pmc.sh + scripts/pmc_traffic.py), same workload only
-            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pj["config"] == {"n": n, "batch": B}:
-                traffic = round(pj["kernels"][names[dom].split("(")[0]]["bytes_per_launch"])
-        except Exception:
-            traffic = None
-        ngroups = cnt[0] // max(1, cnt1[0])
-        roof = {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
+        sum_1, un_1, cnt1 = profile(1)                      # launch per block column, lockstep: one stream, whole batch per launch
+        one_launch = cnt[0] == 1 and cnt[1] == 0            # the one-launch batched step (csrc/batch_step.hip): factor AND inverse
+        if one_launch:
+            names_t, flops_t = [f"batch_step_kernel<true, {'true' if B % 8 == 0 else 'false'}>"], [flops[0] + flops[1]]
+        else:
+            names_t, flops_t = names, flops
+        dom = 0 if one_launch else int(np.argmax(un_t))
+        ach = flops_t[dom] / (un_t[dom] * 1e-3) / 1e12
+        traffic, traffic_source = pmc_traffic(names_t[dom].split("(")[0], n, B)
+        ngroups = 1 if one_launch else cnt[0] // max(1, cnt1[0])
+        dom1 = int(np.argmax(un_1))
+        roof = {"kernel": names_t[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(cnt[dom]), "avg_launch_ms": round(float(sum_t[dom] / max(1, cnt[dom])), 4),
                 "class_ms": round(float(un_t[dom]), 3),
-                "measured_in": f"the timed schedule ({ngroups} groups of {B // max(1, ngroups)} series on {ngroups} streams): HIP "
-                               "events on each launch's own stream; achieved = algorithmic flops of the class / the UNION of "
-                               "its launch intervals (class_ms); avg_launch_ms = mean duration of one group's launch while the "
-                               "other groups' launches share the GPU (traffic is per whole-batch launch, lockstep PMC passes)",
-                "lockstep": {"class_ms": round(float(un_1[dom]), 3), "launches": int(cnt1[dom]),
-                             "avg_launch_ms": round(float(sum_1[dom] / max(1, cnt1[dom])), 4),
-                             "achieved": round(flops[dom] / (un_1[dom] * 1e-3) / 1e12, 2),
-                             "frac": round(flops[dom] / (un_1[dom] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
+                "measured_in": ("the timed schedule: ONE launch per step (factorisation + inverse + alpha's partial sums of all "
+                                f"{B} series), HIP events around it on its stream; achieved = the step's algorithmic 2 N^3 / 3 flop "
+                                "per series / that launch's duration (class_ms); `bench.py --profile-only N` under rocprofv3 "
+                                "--kernel-trace --stats reproduces it as the kernel's average duration") if one_launch else
+                               (f"the timed schedule ({ngroups} groups of {B // max(1, ngroups)} series on {ngroups} streams): HIP "
+                                "events on each launch's own stream; achieved = algorithmic flops of the class / the UNION of "
+                                "its launch intervals (class_ms); avg_launch_ms = mean duration of one group's launch while the "
+                                "other groups' launches share the GPU (traffic is per whole-batch launch, lockstep PMC passes)"),
+                "lockstep": {"what": "the launch-per-block-column schedule on one stream (round 4's kernel), for comparison",
+                             "kernel": names[dom1], "class_ms": round(float(un_1[dom1]), 3), "launches": int(cnt1[dom1]),
+                             "avg_launch_ms": round(float(sum_1[dom1] / max(1, cnt1[dom1])), 4),
+                             "achieved": round(flops[dom1] / (un_1[dom1] * 1e-3) / 1e12, 2),
+                             "frac": round(flops[dom1] / (un_1[dom1] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}}
+        names, flops = names_t, flops_t
         extra = {"kernel_ms": {nm: round(float(t), 3) for nm, t in zip(names, un_t)},
                  "kernel_tflops": {nm: round(f / (t * 1e-3) / 1e12, 2) for nm, f, t in zip(names, flops, un_t)},
                  "factor_plus_inverse_ms": round(float(un_t.sum()), 3),
@@ -396,8 +410,9 @@ def main():
                               "bound": "mfma", "achieved": round(per_step_series * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12, 2),
                               "peak": FP32_MFMA_PEAK_TF * world, "unit": "TFLOP/s",
                               "frac": round(B * 2 * n ** 3 / 3 / (dt / args.steps) / 1e12 / FP32_MFMA_PEAK_TF, 4)},
-            "schedule": {"groups": (roof or {}).get("launches", 0) // max(1, (roof or {}).get("lockstep", {}).get("launches", 1)),
-                         "streams": "library-internal, forked/joined on the caller's stream"},
+            "schedule": {"step_kernel": (roof or {}).get("kernel"), "launches_per_step": (roof or {}).get("launches", 0),
+                         "streams": "the caller's stream (one launch)" if (roof or {}).get("launches", 0) == 1 else
+                                    "library-internal, forked/joined on the caller's stream"},
             "cpu_baseline": cpu,
             "api_step": api,
             "fp64": f64,
@@ -409,6 +424,51 @@ def main():
     if dist is not None:
         dist.barrier()                       # rank 0 ran the roofline legs: leave together
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel: str, n: int, B: int):
+    """HBM bytes per launch of `kernel` from the PMC passes (scripts/pmc.sh + scripts/pmc_traffic.py write
+    profiles/pmc_traffic.json with the workload and the hash of the library sources they were taken on).  Returned only
+    when workload AND source hash match what is running now -- else (None, why)."""
+    from volt_amd import _lib
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        return None, "no profiles/pmc_traffic.json"
+    if pj.get("config") != {"n": n, "batch": B}:
+        return None, f"profiles/pmc_traffic.json is for {pj.get('config')}"
+    have = _lib.lib().volt_source_hash().decode()
+    if pj.get("source_hash") != have:
+        return None, f"profiles/pmc_traffic.json was taken on sources {pj.get('source_hash')}, running {have}"
+    k = pj.get("kernels", {}).get(kernel)
+    if not k:
+        return None, f"profiles/pmc_traffic.json has no kernel {kernel}"
+    return round(k["bytes_per_launch"]), f"profiles/pmc_traffic.json ({pj.get('date')}, sources {have}, {k['launches_profiled']} launches)"
+
+
+def profile_only_leg(N, K, y, raw_noise, ws, n, B, dev):
+    """--profile-only N: exactly N gradient steps through volt_profile_step_f32, nothing else on the device."""
+    from volt_amd import _lib, ops
+    L = _lib.lib()
+    s2 = (torch.nn.functional.softplus(raw_noise.detach()) + 1e-4).contiguous()
+    inf = torch.empty(B, dtype=torch.int32, device=dev)
+    resid_p = (y - ops.ewma(y, EWMA_K)[..., :-1]).contiguous()
+    torch.cuda.synchronize()
+    ms_sum, ms_un, cnt = (ctypes.c_float * 2)(), (ctypes.c_float * 2)(), (ctypes.c_int * 2)()
+    tot = np.zeros(2)
+    for _ in range(N):
+        _lib.check(L.volt_profile_step_f32(K.data_ptr(), n, n * n, resid_p.data_ptr(), s2.data_ptr(), ws.out.data_ptr(),
+                                           ws.alpha.data_ptr(), ws.ptr, inf.data_ptr(), B, n, 0, _lib.stream_ptr(), ms_sum,
+                                           ms_un, cnt, None), "profile")
+        tot += np.array(list(ms_un))
+    Np = ops.padded_n(n)
+    fl = kernel_class_flops(B, Np)
+    one = cnt[0] == 1 and cnt[1] == 0
+    cls_ms = float(tot[0] / N) if one else float(tot.sum() / N)
+    print(json.dumps({"profile_only": N, "n": n, "batch": B, "launches_per_step": list(cnt), "class_ms": [round(float(t / N), 4) for t in tot],
+                      "step_kernels_ms": round(cls_ms, 4), "achieved_TFLOPs": round(sum(fl) / (cls_ms * 1e-3) / 1e12, 2),
+                      "frac": round(sum(fl) / (cls_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4), "not_pd": int((inf != 0).sum().item()),
+                      "source_hash": L.volt_source_hash().decode()}), flush=True)
 
 
 FP64_MFMA_PEAK_TF = 78.6     # v_mfma_f64_16x16x4_f64, dense (vendor figure; 64 cycles per instruction per SIMD)

@@ -21,9 +21,9 @@
  *   VOLT_EXTRA_FLAGS       (build time, volt_amd/build.py) extra hipcc flags for same-box A/B builds: scripts/ab_split.sh
  *   VOLT_PLAIN_SPREAD / VOLT_SPLIT_SPREAD   plain / all-split launches of up to this many workgroups run one workgroup
  *                          per CU (320 / 700)
- *   VOLT_BATCH / _ORDER / _MINB / _MINN   the whole batched step in ONE launch (csrc/batch_step.hip): 0 off, 1 where measured
- *                          faster (default), 2 wherever it can run, 3 also ahead of the short- / long-series one-launch steps; order of a column's tiles in the list (0); smallest batch
- *                          and fewest block columns it takes
+ *   VOLT_BATCH / _ORDER / _LOCAL   the whole batched step in ONE launch (csrc/batch_step.hip): 0 off, 1 where measured faster
+ *                          (default), 2 wherever it can run, 3 also ahead of the short- / long-series one-launch steps; order of
+ *                          a column's tiles in the list (0); hand-offs through the XCD's L2 when the batch is a multiple of 8 (1)
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
  *                          1 = one column, 2 = two columns (2 from 6 matrices on, else 1)           (read in csrc/chol64.hip)
  *   VOLT_F64_TRTRI_LOOKAHEAD  fp64 inverse: one-row look-ahead on its own stream, 0 / 1 (on up to 4 matrices)

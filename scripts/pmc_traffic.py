@@ -6,8 +6,10 @@ exactly half of the bytes of a wide coalesced streaming read (16 B/lane), so rea
 WRITE_SIZE was calibrated here on fill_kernel (known 4*N^2*B bytes): exact.
 usage: python scripts/pmc_traffic.py gpurun_out/pmc_<tag> <n> <batch> <passes_per_run>
 """
-import csv, glob, json, os, sys
+import csv, datetime, glob, json, os, sys
 from collections import defaultdict
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from volt_amd.build import source_hash
 
 root, n, batch, runs = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 agg = defaultdict(lambda: defaultdict(float))
@@ -17,7 +19,7 @@ for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
         k = row["Kernel_Name"].split("(")[0].replace("volt::", "").replace("void ", "")   # keeps <true>/<false>
         agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
         cnt[k][row["Counter_Name"]] += 1
-out = {"config": {"n": n, "batch": batch}, "source": root, "correction": "read bytes = 2 * FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
+out = {"config": {"n": n, "batch": batch}, "source": root, "source_hash": source_hash(), "date": datetime.date.today().isoformat(), "correction": "read bytes = 2 * FETCH_SIZE KiB (gfx950), write bytes = WRITE_SIZE KiB",
        "kernels": {}}
 for k, a in agg.items():
     if "FETCH_SIZE" not in a or "WRITE_SIZE" not in a:

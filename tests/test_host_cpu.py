@@ -39,10 +39,16 @@ def test_argument_validation_without_a_device():
     assert L.volt_potrf_ws_f32(1, 1, 1, 1, 100, None, 0, 0, None) == -5
     assert L.volt_potrf_k_f32(None, 8, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, 0, None) == -1
     assert L.volt_potrf_k_f32(1, 4, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, 0, None) == -2     # row stride shorter than N
-    assert L.volt_potrf_workspace_bytes(65, 4096) == 0 and L.volt_potrf_workspace_bytes(1, 100) == 0
+    assert L.volt_potrf_workspace_bytes(1, 100) == 0
     assert L.volt_potrf_workspace_bytes(1, 128) == 0 and L.volt_potrf_workspace_bytes(4, 256) == 0   # nothing long enough to cut
     tables = ((33 * 8 * (1 + 4 * 33) + 16) * 16 + 255) // 256 * 256  # the balanced schedule's tables (+ a 16-slot header) live in caller scratch too
-    assert L.volt_potrf_workspace_bytes(8, 4096) == 64 * 33 * 65536 + (33 * 33 * 8 * 4 + 255) // 256 * 256 + tables
+    # round 5: + the one-launch factorisation's piece list (16 B per piece, 16-slot header) and progress words (3 n ints per matrix)
+    pieces = lambda B, n: B * sum(1 + (1 if 1 <= k <= n - 2 else 0) + (n - k - 1) for k in range(n))
+    al = lambda b: (b + 255) // 256 * 256
+    batch = lambda B, n: al((16 + pieces(B, n)) * 16) + al(B * ((3 * n + 31) // 32 * 32) * 4)
+    assert L.volt_potrf_workspace_bytes(8, 4096) == 64 * 33 * 65536 + (33 * 33 * 8 * 4 + 255) // 256 * 256 + tables + batch(8, 32)
+    assert L.volt_potrf_workspace_bytes(65, 4096) == batch(65, 32)        # above 64 matrices: no slabs, the piece list alone
+    assert L.volt_batch_describe(8, 32, 0, 0, None, 0) == pieces(8, 32)
     assert L.volt_potrf_workspace_bytes(64, 4096) > 128 * 33 * 65536
     assert L.volt_mll_workspace_bytes(64, 4096, 1) > L.volt_mll_workspace_bytes(64, 4096, 0) > 0
     # the one-launch step for short series keeps its state and alpha's partial sums in the workspace: there for
@@ -52,7 +58,8 @@ def test_argument_validation_without_a_device():
     assert L.volt_mll_workspace_bytes(8, 399, 1) - L.volt_mll_workspace_bytes(8, 399, 0) > 8 * 512 * 512 * 4   # + Y, partials, state
     assert L.volt_rollout_scratch_bytes(2, 3, 4) == 2 * 3 * 16 * 4
     assert L.volt_mll_workspace_init_f32(None, 8, 4096, 1, None) == -1 and L.volt_potrf_workspace_init_f32(None, 0, 8, 100, None) == -4
-    assert L.volt_potrf_workspace_init_f32(None, 0, 100, 4096, None) == 0          # no scratch for that shape: nothing to do
+    assert L.volt_potrf_workspace_init_f32(None, 0, 100, 256, None) == 0           # no scratch for that shape: nothing to do
+    assert L.volt_potrf_workspace_init_f32(None, 0, 100, 4096, None) == -1         # (100 matrices of N = 4096 have the piece list)
     with pytest.raises(_lib.VoltHipError):
         _lib.check(-3, "x")
 

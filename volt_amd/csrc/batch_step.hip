@@ -226,10 +226,12 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
     }
     if (kind == BK_ALPHA) {
         const int c = d.y;
-        if (threadIdx.x <= c) {                              // row c of the inverse is complete: tcol[j] >= c - j + 1, j <= c
-            if (!wait_word_ge<LOCAL>(tcol + threadIdx.x, c - (int)threadIdx.x + 1)) atomicCAS(info_b, 0, (int)0x80000000);
+        if (threadIdx.x < 64) {                              // row c of the inverse is complete: tcol[j] >= c - j + 1, j <= c
+            bool ok = true;
+            for (int j = 0; j <= c; ++j) ok = wait_word_ge<LOCAL>(tcol + j, c - j + 1) && ok;   // (wave-uniform addresses)
+            if (!ok && threadIdx.x == 0) atomicCAS(info_b, 0, (int)0x80000000);
+            acquire_unless_local<LOCAL>();
         }
-        if (threadIdx.x < 64) acquire_unless_local<LOCAL>();
         __syncthreads();
         alpha_item(Y, red, zvec, apart, Np, b, c, d.z);
         return;
@@ -276,14 +278,27 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
 
 using namespace volt;
 
-// Where the one launch replaces the launch-per-column schedules.  (B, n) only: the gate is part of the shape's identity,
-// volt_*_workspace_bytes / _init and the step agree on it.
+// Where the one launch replaces the launch-per-column schedules: the measured crossovers of profiles/r05/batch_gate_sweep.txt
+// (ms launch-per-column / ms one-launch over B = 2 .. 96, N = 1024 .. 4096, for the gradient step and for the factorisation
+// alone).  (B, n, inverse?) only: the gate is part of the shape's identity -- volt_*_workspace_bytes / _init and the step
+// agree on it.  Short series of few matrices stay with the short-series one-launch step (small_step_kernel), one long series
+// with long_step_kernel: they are tried first (mll.hip).
 bool volt_internal_batch_applies(int B, int n, int has_y) {
     const Tunables& tn = tunables();
-    (void)has_y;
     if (tn.batch <= 0 || B < 1 || n < 2 || B > 65535) return false;
     if (tn.batch >= 2) return true;
-    return B >= tn.batch_minb && n >= tn.batch_minn;
+    if (has_y) {
+        if (n >= 28) return B >= 2;                          // N = 4096: 1.02 - 1.13 x at every batch size
+        if (n >= 20) return B >= 3;                          // N = 3072: 1.0 - 1.15 x (10 .. 16 matrices: a tie)
+        if (n >= 14) return B >= 6;                          // N = 2048: 1.06 - 1.46 x
+        if (n >= 10) return B == 8 || B >= 16;               // N = 1536: 1.06 - 1.38 x (10, 12 matrices: 0.9 - 0.97)
+        if (n >= 8) return B >= 32;                          // N = 1024: 1.0 - 1.24 x
+        return false;
+    }
+    if (n >= 20) return B >= 3;                              // the factorisation alone: 1.03 - 1.35 x
+    if (n >= 14) return B >= 8;
+    if (n >= 10) return B == 8 || B >= 20;
+    return false;
 }
 
 bool volt_internal_batch_first() { return tunables().batch >= 3; }   // tuning: ahead of the short- / long-series steps

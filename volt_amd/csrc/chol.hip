@@ -1451,6 +1451,14 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
 
 using namespace volt;
 
+// batch_step.hip: the whole factorisation in one launch
+size_t volt_internal_batch_bytes(int B, int n, int has_y);
+int volt_internal_batch_install(void* state, size_t bytes, int B, int n, int has_y, void* stream);
+int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const float* sigma2, float jitter, float* A,
+                             float* Winv, float* Y, int* info, const float* rpad, float* zpart, float* frob, int B, int N,
+                             float* z, float* apart, void* state, size_t state_bytes, void* stream, hipEvent_t e0,
+                             hipEvent_t e1);
+
 const Tunables& tunables() {
     static const Tunables tn = [] {
         Tunables t;
@@ -1488,8 +1496,6 @@ const Tunables& tunables() {
         geti("VOLT_BATCH", t.batch);
         geti("VOLT_BATCH_ORDER", t.batch_order);
         geti("VOLT_BATCH_LOCAL", t.batch_local);
-        geti("VOLT_BATCH_MINB", t.batch_minb);
-        geti("VOLT_BATCH_MINN", t.batch_minn);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         return t;
     }();
@@ -2270,10 +2276,16 @@ static size_t potrf_ws_count_bytes(int B, int Np) {
     const size_t n = (size_t)Np / TS;
     return (((n + 1) * (n + 1) * B * sizeof(int)) + 255) & ~(size_t)255;
 }
-size_t volt_potrf_workspace_bytes(int B, int Np) {
+// scratch of the launch-per-column schedules (slabs, counters, balanced tables) ...
+static size_t potrf_ws_sched_bytes(int B, int Np) {
     if (B < 1 || potrf_ws_rows(B) == 0 || Np < TS || Np % TS) return 0;   // more than 64 matrices fill the chip with whole tiles
     if (Np / TS < 3) return 0;               // k <= 1: no product is long enough to be cut (slices are >= 2 K-blocks)
     return potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np) + volt_internal_sched_bytes(B, Np / TS);
+}
+// ... followed by the table + progress words of the one-launch factorisation (volt_potrf_k_f32 only: tiles read from K)
+size_t volt_potrf_workspace_bytes(int B, int Np) {
+    if (B < 1 || Np < TS || Np % TS) return 0;
+    return potrf_ws_sched_bytes(B, Np) + volt_internal_batch_bytes(B, Np / TS, 0);
 }
 
 int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void* stream) {
@@ -2283,7 +2295,12 @@ int volt_potrf_workspace_init_f32(void* ws, size_t ws_bytes, int B, int Np, void
     if (!need) return 0;
     if (!ws || ((uintptr_t)ws & 255)) return -1;
     if (ws_bytes < need) return -2;
-    const size_t tb = volt_internal_sched_bytes(B, Np / TS);
+    const size_t bb = volt_internal_batch_bytes(B, Np / TS, 0);
+    if (bb) {
+        const int rc = volt_internal_batch_install(reinterpret_cast<char*>(ws) + potrf_ws_sched_bytes(B, Np), bb, B, Np / TS, 0, stream);
+        if (rc) return rc;
+    }
+    const size_t tb = potrf_ws_sched_bytes(B, Np) ? volt_internal_sched_bytes(B, Np / TS) : 0;
     if (!tb) return 0;
     return sched_install(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np) + potrf_ws_count_bytes(B, Np), tb, B, Np / TS,
                          false, potrf_ws_rows(B), (hipStream_t)stream);
@@ -2301,7 +2318,7 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
     if (ws) {
         if (((uintptr_t)ws & 255) != 0) return -6;
         if (ws_bytes < need) return -7;
-        if (need) {                                              // K-slices and the balanced schedule
+        if (potrf_ws_sched_bytes(B, Np)) {                       // K-slices and the balanced schedule
             sk.slab = reinterpret_cast<float*>(ws);
             sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
             sk.cap = potrf_ws_rows(B);
@@ -2339,7 +2356,16 @@ int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
     if (ws) {
         if (((uintptr_t)ws & 255) != 0) return -11;
         if (ws_bytes < need) return -12;
-        if (need) {
+        // the whole factorisation in one launch (batch_step.hip), on the caller's word that the init ran on this scratch
+        const size_t bb = volt_internal_batch_bytes(B, n, 0);
+        if (bb && (ws_flags & VOLT_WS_INITIALISED)) {
+            const int rc = volt_internal_batch_step(K, ldk, bsk, sigma2, jitter, A, Winv, nullptr, info, nullptr, nullptr, nullptr, B, N,
+                                                    nullptr, nullptr, reinterpret_cast<char*>(ws) + potrf_ws_sched_bytes(B, Np), bb,
+                                                    stream, nullptr, nullptr);
+            if (rc == 1) return 0;
+            if (rc) return rc > 0 ? rc : -13;
+        }
+        if (potrf_ws_sched_bytes(B, Np)) {
             sk.slab = reinterpret_cast<float*>(ws);
             sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
             sk.cap = potrf_ws_rows(B);

@@ -23,6 +23,5 @@ struct Tunables {
     int batch = 1;                             // the whole batched step in one launch (batch_step.hip): 0 off, 1 where measured faster, 2 wherever it can run
     int batch_order = 0;                       // ... order of a block column's panel tiles in its list: 0 row-major (matrix innermost), 1 matrix-major
     int batch_local = 1;                       // ... batches that are a multiple of 8 hand their tiles on through the XCD's L2 (0: the agent-scope protocol everywhere)
-    int batch_minb = 8, batch_minn = 16;       // ... smallest batch / fewest block columns it takes
 };
 const Tunables& tunables();                    // chol.hip: read once per process (VOLT_TUNE=1 only)
