@@ -329,13 +329,18 @@ def test_potrf_with_scratch_small_and_late_column_schedules(ops, B, n):
     base = ((ws.data_ptr() + 255) // 256) * 256
     assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base + 4, need, 0, _lib.stream_ptr()) == -6
     assert lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need - 1, 0, _lib.stream_ptr()) == -7
-    # the copy-in + in-place pair (volt_prepare_f32 + volt_potrf_ws_f32) gives bitwise the factor ops.potrf's one call
-    # (volt_potrf_k_f32: tiles read from K by the workgroups that update them) does -- same schedule, same arithmetic
+    # the copy-in + in-place pair (volt_prepare_f32 + volt_potrf_ws_f32: the launch-per-column schedules with K-slices) against
+    # ops.potrf's one call (volt_potrf_k_f32: tiles read from K; round 5: the whole factorisation in ONE launch for these
+    # shapes, csrc/batch_step.hip, every tile summed in one piece) -- bitwise where both run the same schedule, else the two
+    # fp32 summation orders, each 2e-5 from fp64
     _lib.check(lib.volt_potrf_workspace_init_f32(base, need, B, Np, _lib.stream_ptr()), "ws init")
     _lib.check(lib.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n, _lib.stream_ptr()), "prepare")
     _lib.check(lib.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, base, need, _lib.WS_INITIALISED, _lib.stream_ptr()), "potrf_ws")
     assert int(info.abs().sum()) == 0
-    assert torch.equal(torch.tril(A[:, :n, :n]), L1)
+    if B == 1:
+        assert torch.equal(torch.tril(A[:, :n, :n]), L1)
+    else:
+        assert float((torch.tril(A[:, :n, :n]) - L1).abs().max()) < 6e-5 * float(L1.abs().max())
     assert lib.volt_potrf_k_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), W.data_ptr(), info.data_ptr(), B, n,
                                 base + 4, need, 0, _lib.stream_ptr()) == -11
 
