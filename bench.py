@@ -522,7 +522,7 @@ def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):
     the difference of two runs (t2 vs t1 iterations: construction and the one-off fill cancel).  eager = the loop with
     the factorisation's info check deferred (the default of the batched loop); eager_per_step_check = with the host
     read-back every step, as a literal gpytorch loop does; graph = graph=True (one captured iteration replayed where the
-    step is launch-bound; at this size the loop declines the capture, see `captured`)."""
+    step is launch-bound).  default = no `graph` argument: what a caller of the reference's signature gets."""
     from volt_amd.train_utils import TrainVoltMagpieBatch
     tx = torch.tensor(x, device=dev)
     prices = torch.tensor(F[:B, 1:], device=dev)
@@ -537,19 +537,64 @@ def api_leg(x, F, vol, dev, n, B, raw_ms, t1=6, t2=26):
 
     out = {"workload": f"TrainVoltMagpieBatch iteration, {B} x N={n}, EWMA(k={EWMA_K}) mean, Adam on raw_noise [B]",
            "raw_op_ms_per_step": round(raw_ms, 3), "iterations": [t1, t2]}
-    for mode, kw in (("eager", {}), ("eager_per_step_check", {"defer": False}), ("graph", {"graph": True})):
+    from volt_amd.train_utils import _capture_pays
+    # default = what a drop-in caller gets (no reference call site passes `graph`: captured where the step is launch-bound)
+    for mode, kw in (("default", {}), ("eager", {"graph": False}), ("eager_per_step_check", {"graph": False, "defer": False}),
+                     ("graph", {"graph": True})):
         run(t1, **kw)                                  # warm: allocator, schedule tables, graph pools
         a = min(run(t1, **kw) for _ in range(2))
         b = min(run(t2, **kw) for _ in range(2))
         ms = (b - a) / (t2 - t1) * 1e3
         out[mode] = {"ms_per_step": round(ms, 3), "overhead_vs_raw_op": round(ms / raw_ms - 1.0, 4)}
-    from volt_amd.train_utils import _capture_pays
-    out["graph"]["captured"] = bool(_capture_pays(prices))
-    if not out["graph"]["captured"]:
-        out["graph"]["note"] = ("graph=True is honoured where a step is launch-bound (< 700 tiles per launch); a step that "
-                                "fills the chip runs eagerly with the deferred check (captured it took 25.9 ms: one stream "
-                                "group instead of two)")
+    out["default"]["captured"] = bool(_capture_pays(prices))
+    out["ref_default_1x399_api"] = api_default_leg(dev)
     return out
+
+
+def api_default_leg(dev, n=399, t1=30, t2=230):
+    """The reference's own default size through its own entry point with its own arguments: TrainVoltMagpieModel(train_x,
+    train_y, vol_model, vol_lh, vol_path, train_iters) for ONE series of ntrain = 400 prices (experiments/stocks/
+    ForecastGenerator.py:53-91) -- no `graph` argument, as at every reference call site (voltron/train_utils.py:192).  Per
+    iteration as the difference of two runs; beside it the raw op (ops.mll_step alone, K resident) in a tight loop."""
+    from volt_amd import ops
+    from volt_amd.synthetic import sde_batch
+    from volt_amd.train_utils import TrainVoltMagpieModel, _capture_pays
+    x, F, vol = sde_batch(1, n, seed=2019)
+    tx = torch.tensor(x, device=dev)
+    prices = torch.tensor(F[0], device=dev)
+    v = torch.tensor(vol[0], device=dev)
+
+    def run(iters, **kw):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        TrainVoltMagpieModel(tx, prices[1:], None, None, v, train_iters=iters, k=EWMA_K, **kw)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    res = {}
+    for mode, kw in (("default", {}), ("eager", {"graph": False})):
+        run(t1, **kw)
+        a = min(run(t1, **kw) for _ in range(3))
+        b = min(run(t2, **kw) for _ in range(3))
+        res[mode] = (b - a) / (t2 - t1) * 1e3
+    K = ops.fill(ops.cumtrapz(v[None], tx, square=True))
+    y = torch.log(prices[1:])[None]
+    r = (y - y.mean(-1, keepdim=True)).contiguous()
+    s2 = torch.full((1,), 0.6932, device=dev)
+    ws = ops.MllWorkspace(1, n, True, dev)
+    for _ in range(5):
+        ops.mll_step(K, r, s2, ws)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        ops.mll_step(K, r, s2, ws)
+    e1.record()
+    torch.cuda.synchronize()
+    raw = e0.elapsed_time(e1) / 200
+    return {"workload": f"TrainVoltMagpieModel, 1 x N={n}, reference arguments (no `graph`)", "raw_op_ms_per_step": round(raw, 4),
+            "ms_per_iteration": round(res["default"], 4), "over_raw_op": round(res["default"] / raw, 3),
+            "captured_by_default": bool(_capture_pays(y)), "eager_ms_per_iteration": round(res["eager"], 4),
+            "iterations": [t1, t2]}
 
 
 def configs_leg(make_step, timed, dev, K_all, y_all, n_head, batch_head, steps=50, warmup=5):

@@ -15,7 +15,7 @@ _, F, _ = sde_batch(64, ntrain - 1, seed=7)
 closes = torch.tensor(F).cuda()                                  # [64, 400] prices
 
 
-def one_ticker(train_y, graph=False):
+def one_ticker(train_y, graph=None):
     dt = 1. / 252
     train_x = (torch.arange(train_y.shape[0] - 1) * dt).cuda()
     test_x = (torch.arange(H) * dt).cuda() + train_x[-1] + train_x[1]
@@ -37,10 +37,14 @@ def one_ticker(train_y, graph=False):
 
 one_ticker(closes[0])                                            # warm-up (library load, allocator)
 t = one_ticker(closes[1])
-print("one ticker, one window:", {k_: round(v, 3) for k_, v in t.items()}, "total %.2f s" % sum(t.values()))
+print("one ticker, one window, the reference's arguments (no `graph`: captured where the step is launch-bound):",
+      {k_: round(v, 3) for k_, v in t.items()}, "total %.2f s" % sum(t.values()))
+one_ticker(closes[2], graph=False)
+t = one_ticker(closes[1], graph=False)
+print("  graph=False (every iteration eager):", {k_: round(v, 3) for k_, v in t.items()}, "total %.2f s" % sum(t.values()))
 one_ticker(closes[2], graph=True)
 t = one_ticker(closes[1], graph=True)
-print("  with hipGraph-captured iterations:", {k_: round(v, 3) for k_, v in t.items()}, "total %.2f s" % sum(t.values()))
+print("  graph=True:", {k_: round(v, 3) for k_, v in t.items()}, "total %.2f s" % sum(t.values()))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 out = GenerateStockPredictionsBatch([f"T{i}" for i in range(64)], closes, forecast_horizon=H, train_iters=iters,
                                     nsample=S, ntrain=ntrain - 1, mean="ewma", k=k, ntimes=1, vol_iters=iters)

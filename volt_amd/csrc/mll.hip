@@ -62,13 +62,26 @@ __global__ __launch_bounds__(256) void y_times_z_kernel(const float* __restrict_
     }
 }
 
+// (one-launch batched step) alpha from its partial sums per block column of Y: alpha[i] = sum_{c >= i / 128} apart[b][c][i],
+// added in ascending block order -- the order y_times_z_kernel adds the same partials in, so alpha agrees bit for bit
+// between the schedules.  grid (Np / 256, B).
+__global__ __launch_bounds__(256) void alpha_sum_kernel(const float* __restrict__ apart, float* __restrict__ alpha_pad, int N,
+                                                        int Np) {
+    const int n = Np / TS, b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    float al = 0.f;
+    if (i < N)
+        for (int c = i / TS; c < n; ++c) al += apart[((int64_t)b * n + c) * Np + i];
+    alpha_pad[(int64_t)b * Np + i] = al;
+}
+
 // R4: scalars.  out[b, 0..7] = mll, dmll/dsigma2, quad, logdet, trinv, aa, sigma2-used, 0
 __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restrict__ A, const float* __restrict__ z,
-                                                          float* __restrict__ alpha_pad,
+                                                          const float* __restrict__ alpha_pad,
                                                           const float* __restrict__ frob, const float* __restrict__ sigma2,
                                                           float jitter, float* __restrict__ out,
-                                                          float* __restrict__ alpha_out, int N, int Np, int want_grad,
-                                                          const float* __restrict__ apart = nullptr) {
+                                                          float* __restrict__ alpha_out, int N, int Np, int want_grad) {
     __shared__ double red[256];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = Np / TS;
@@ -90,20 +103,11 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
         q += zi * zi;
         ld += log((double)Ab[(int64_t)i * Np + i]);
         if (want_grad) {
-            float al;
-            if (apart) {                        // the one-launch batched step: alpha's partial sums per block column of Y,
-                al = 0.f;                       // [B,n,Np], added in ascending block order (as y_times_z_kernel does)
-                for (int c = i / TS; c < n; ++c) al += apart[((int64_t)b * n + c) * Np + i];
-                alpha_pad[(int64_t)b * Np + i] = al;
-            } else {
-                al = alpha_pad[(int64_t)b * Np + i];
-            }
+            const float al = alpha_pad[(int64_t)b * Np + i];
             aa += (double)al * al;
             alpha_out[(int64_t)b * N + i] = al;
         }
     }
-    if (want_grad && apart)
-        for (int i = N + tid; i < Np; i += 256) alpha_pad[(int64_t)b * Np + i] = 0.f;
     if (want_grad) {
         const int nt = n * (n + 1) / 2;
         for (int i = tid; i < nt; i += 256) tr += frob[(int64_t)b * nt + i];
@@ -347,8 +351,9 @@ void batch_tail(TailCtx& c, int B, hipStream_t s) {
         mll_tail(&c, 0, B, s);
         return;
     }
+    hipLaunchKernelGGL(alpha_sum_kernel, dim3((c.Np + 255) / 256, B), dim3(256), 0, s, c.w.apart, c.w.apad, c.N, c.Np);
     hipLaunchKernelGGL(mll_scalars_kernel, dim3(B), dim3(256), 0, s, c.w.A, c.w.z, c.w.apad, c.w.frob, c.sigma2, c.jitter, c.out,
-                       c.alpha, c.N, c.Np, 1, c.w.apart);
+                       c.alpha, c.N, c.Np, 1);
 }
 }  // namespace
 

@@ -92,7 +92,7 @@ def _window_pass(train_x, test_x, train_y, nsample, mean, k, gpcv_iters, vol_ite
 
 
 def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample, mean, k, gpcv_iters, vol_iters,
-                      data_iters, theta, vol_fn, generator, save, path_fn, debug=None, graph=False):
+                      data_iters, theta, vol_fn, generator, save, path_fn, debug=None, graph=None):
     """One batched pass per window (series [B,T] prices; the window ending at index e trains on series[:, e-ntrain:e]).
     A numerical failure anywhere in the batched pass (NotPSDError / NanError after the jitter ladders) must not take the
     other series down with it: the window is then redone one series at a time, and a series that still fails gets NaN
@@ -127,7 +127,7 @@ def _forecast_windows(names, series, end_idxs, ntrain, train_x, test_x, nsample,
 
 def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=20, train_iters=400, nsample=1000,
                                   ntrain=400, mean="ewma", save=False, k=300, ntimes=-1, vol_fn=None,
-                                  vol_iters=None, par_dir="./saved-outputs/", generator=None, debug=None, graph=False):
+                                  vol_iters=None, par_dir="./saved-outputs/", generator=None, debug=None, graph=None):
     """closes [B, T] prices for B tickers on a common calendar (device tensor).  Same window schedule,
     model name and file layout as GenerateStockPredictions (GenerateMultiMeanPreds.py:69-83,128); ``mean`` in
     ewma / dewma / tewma takes the Rollouts branch (:110-112), constant / loglinear / linear the "VOLT + standard
@@ -159,7 +159,7 @@ def GenerateStockPredictionsBatch(tickers, closes, dates=None, forecast_horizon=
 
 def GenerateWindPredictionsBatch(stations, data, forecast_horizon=100, ntrain=400, n_test_times=10, nsample=1000, k=400,
                                  theta=0.01, gpcv_iters=200, vol_iters=500, data_iters=0, save=False, vol_fn=None,
-                                 par_dir="./saved-outputs/", generator=None, graph=False):
+                                 par_dir="./saved-outputs/", generator=None, graph=None):
     """The ``--kernel volt --mean ewma`` branch of experiments/weather/GPGenerator.py:20-112 for B stations at once:
     data [B,T] wind speeds (missing = -99 -> 0, then +1 as at :47,55), dt = 1/365 (:38-41), the schedule of test
     windows of :33-34, GPCV 200 / vol model 500 / data model 0 iterations (:64-67,89-92), EWMA(k=400) mean and

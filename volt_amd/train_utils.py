@@ -196,34 +196,41 @@ class _null:
         return False
 
 
+CAPTURE_BELOW_MS = 4.0        # estimated step time under which the per-iteration host work (~0.3 ms of launches, autograd, Adam) is worth removing
+
+
 def _capture_pays(target):
-    """Same gate as the library's one-group rule (csrc/chol.hip, run_factor_groups): fewer than 700 tiles per launch."""
+    """Is an iteration over ``target`` ([.., N] log-prices) launch-bound?  The step is 2 N^3 / 3 flop per series at the
+    ~110 TFLOP/s the MLL step sustains; an eager iteration adds ~0.3 ms of host work (torch glue, autograd, Adam) that a
+    captured one does not pay: 1 x 399 runs 0.50 ms eager / 0.14 captured, 64 x 4096 22.1 / 22.0.  Since round 5 the step
+    of every shape is ONE launch per batch (or a handful), so capturing costs nothing -- the gate is only about whether
+    it buys anything measurable."""
     n = target.shape[-1]
     batch = target.numel() // max(n, 1)
-    return batch * ((n + 127) // 128 + 1) < 700
+    npad = (n + 127) // 128 * 128
+    return batch * 2.0 * npad ** 3 / 3.0 / 110e12 * 1e3 < CAPTURE_BELOW_MS
 
 
-_WARNED_NO_CAPTURE = False
+def _auto_graph(graph, target, distributed=False):
+    """``graph=None`` (the default of every training loop here, as no reference call site passes it --
+    voltron/train_utils.py:15,69,98,192): capture where it pays, on a CUDA device, outside an ongoing capture, single
+    process.  An explicit True / False is honoured."""
+    if graph is not None:
+        return bool(graph)
+    if distributed or not target.is_cuda or torch.cuda.is_current_stream_capturing():
+        return False
+    return _capture_pays(target)
 
 
-def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=False, defer=False, batched=False,
+def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=None, defer=False, batched=False,
                post_backward=None, scale=1.0, agree=None):
     """Adam on -mll(model(train_x), target); a batched model's per-series losses are summed for ONE backward (the
     series are independent and Adam is elementwise, so every series gets its own loop's update)."""
     model.train()
     lh.train()
-    if graph and not _capture_pays(target):
-        # A step whose launches fill the chip is not launch-bound: capturing it buys nothing and costs the second stream
-        # group the library runs such batches in (64 x 4096: 25.9 ms per captured iteration against 22.5 eager).  The
-        # request is honoured where it pays; otherwise the loop runs eagerly with the deferred check -- and says so, once.
-        global _WARNED_NO_CAPTURE
-        if not _WARNED_NO_CAPTURE:
-            _WARNED_NO_CAPTURE = True
-            n_ = target.shape[-1]
-            warnings.warn(f"graph=True declined for {target.numel() // max(n_, 1)} x N={n_}: a step whose launches fill the "
-                          "chip is not launch-bound, and captured it loses the library's second stream group (+14 % at 64 x "
-                          "4096); running eagerly with the deferred info check instead", RuntimeWarning, stacklevel=3)
-        graph, defer = False, True
+    graph = _auto_graph(graph, target)
+    if not graph and defer is None:
+        defer = True
     optimizer = _adam([{'params': params}], lr, graph)
     mll = ExactMarginalLogLikelihood(lh, model)
     last = {}
@@ -242,7 +249,7 @@ def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, gr
 
 
 # ------------------------------------------------------------------------------------------------ (f)4: GPCV
-def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", graph=False):
+def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", graph=None):
     """The fit inside LearnGPCV (train_utils.py:15-58), returning what it builds: (model, likelihood, losses)."""
     from .kernels import BMKernel, FBMKernel
     from .likelihoods import VolatilityGaussianLikelihood
@@ -259,6 +266,7 @@ def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", gra
     model.initialize_variational_parameters(likelihood, train_x, y=yy)
     model.train()
     likelihood.train()
+    graph = bool(graph)                                  # (this entry returns the per-iteration losses: captured only on request)
     optimizer = _adam([{"params": model.parameters()}], LR_GPCV, graph)
     elbo = VariationalELBO(likelihood, model, yy.shape[-1], combine_terms=True)
     losses = []
@@ -280,10 +288,11 @@ def FitGPCV(train_x, train_y, train_iters=1000, printing=False, kernel="bm", gra
     return model, likelihood, losses
 
 
-def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping=False, kernel="bm", graph=False):
+def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping=False, kernel="bm", graph=None):
     """voltron/train_utils.py:15-67: the volatility path of a price series from a variational GP (BM or FBM prior over
     log-vol, ``y | f ~ N(0, exp f)``) fitted to the scaled returns; one HIP ELBO step per iteration.
     train_y [N+1] prices -> pred_scale [N]; train_y [T,N+1] fits T series at once (batched parameters)."""
+    graph = _auto_graph(graph, train_y[..., 1:])         # (only the fitted scale is returned: nothing per-iteration is lost)
     model, likelihood, _ = FitGPCV(train_x, train_y, train_iters=train_iters, printing=printing, kernel=kernel, graph=graph)
     return likelihood(model(train_x), return_gaussian=False).scale.mean(0).detach()      # :60-67
 
@@ -296,7 +305,7 @@ def _vol_model(train_x, vol_path, kernel, batch_shape):
     return BMGP(train_x, vol_path.log(), vol_lh, kernel=kernel).to(train_x.device), vol_lh
 
 
-def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=False):
+def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=None):
     """voltron/train_utils.py:69-95: the Brownian-motion GP over log-vol that supplies pred_vol to Rollouts.  The MLL
     and its gradient wrt the kernel's `vol` and the noise run on the HIP step (K = vol * min(x,x') keeps d mll / d vol
     in closed form, gp._ExactMLL)."""
@@ -305,10 +314,11 @@ def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="b
     return vol_model, vol_lh
 
 
-def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=False):
+def TrainVolModelBatch(train_x, vol_path, train_iters=1000, printing=False, kernel="bm", graph=None):
     """TrainVolModel for T series at once: vol_path [T,N] -> one batched BMGP (per-series kernel parameter and noise)."""
     T = vol_path.shape[0]
     vol_model, vol_lh = _vol_model(train_x, vol_path, kernel, torch.Size([T]))
+    graph = _auto_graph(graph, vol_path)
     _fit_exact(vol_model, vol_lh, train_x, vol_path.log(), list(vol_model.parameters()), LR_VOL, train_iters, printing, graph,
                defer=not graph, batched=True, scale=1.0 / T)
     return vol_model, vol_lh
@@ -322,7 +332,7 @@ def _attach_vol(model, vol_model, vol_lh, dev):
         model.vol_model = vol_model.to(dev)
 
 
-def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, graph=False):
+def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, graph=None):
     """voltron/train_utils.py:98-144: VoltronGP with a log-linear mean; noise, slope and intercept train."""
     dev = train_x.device
     log_y = train_y.log()
@@ -336,7 +346,7 @@ def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=10
 
 
 def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=1000, printing=False, k=25,
-                         theta=0.5, mean_func="ewma", graph=False):
+                         theta=0.5, mean_func="ewma", graph=None):
     """voltron/train_utils.py:192-257: VoltMagpie with the chosen mean; the noise (and a constant / (log)linear mean's
     parameters) train, the vol forecaster rides along frozen."""
     dev = train_x.device
@@ -352,7 +362,7 @@ def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_it
 
 
 def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, printing=False, process_group=None,
-                         shared_noise=False, mean_func="ewma", theta=0.5, graph=False, defer=True, reduce_across_ranks=True):
+                         shared_noise=False, mean_func="ewma", theta=0.5, graph=None, defer=True, reduce_across_ranks=True):
     """B independent series in one batched model (train_y [B,N] raw prices[1:], vol_path [B,N]).  Per-series raw_noise
     by default (each series is its own GP, as in the reference's loop over tickers); ``shared_noise`` ties one
     likelihood across series AND ranks, whose gradient is then all-reduced.  ``mean_func`` as in
@@ -379,6 +389,7 @@ def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, pri
         warnings.warn("TrainVoltMagpieBatch: graph=True is for single-process runs (the all-reduce stays eager); running the "
                       "eager loop with the deferred check", RuntimeWarning, stacklevel=2)
         graph = False
+    graph = _auto_graph(graph, log_y, distributed)
     count = torch.tensor(float(B), device=dev)
 
     def reduce(loss):                                     # the path's one collective: summed loss (and a shared gradient)
