@@ -727,12 +727,17 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256, dist=None, world=1, rank
     issue = None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "rollout_pmc.json")))
+        # the per-sample-step count was measured at ONE shape (it grows with H: a step's work is O(steps so far)): the
+        # figure is emitted only for that shape, and labelled as derived from a stored counter
+        if pj.get("shape") != {"G": G, "S": S, "H": H, "n": n}:
+            raise ValueError("rollout_pmc.json is for another shape")
         per = float(pj["valu_wave_insts_per_sample_step"])
         ach = G * S * H * per / ker_f
         issue = {"kernel": "rollout_bordered_kernel<1,false>", "bound": "valu_issue", "achieved": round(ach / 1e12, 3),
                  "peak": round(VALU_WAVE_INSTS_PER_S / 1e12, 3), "unit": "T wave-instructions/s",
                  "frac": round(ach / VALU_WAVE_INSTS_PER_S, 4), "valu_wave_insts_per_sample_step": per,
-                 "source": "profiles/r04/rollout_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU ...), kernel time live (HIP events)"}
+                 "source": "instruction count per sample-step: a STORED counter (profiles/r04/rollout_pmc.json, rocprofv3 --pmc "
+                           "SQ_INSTS_VALU at this very shape); kernel time: live (HIP events)"}
     except Exception:
         issue = None
     return {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5"

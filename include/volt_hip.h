@@ -149,7 +149,9 @@ int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np
  * rho = u'K^-1u and tau = u'K^-1 r_tr (the host gets them in closed form or from the fp64 factorisation,
  * volt_amd/rollout_engine.py); this launch walks all H horizon steps for every sample path: the sample's bordered
  * factor grown row by row, EWMA-family mean of the appended point (mean_mode 0 ewma / 1 dewma / 2 tewma /
- * 3 meanrevert, EWMA.py), optional mean reversion (:41-42), jitter ladder of psd_safe_cholesky(pred_cov, jitter) (:46).
+ * 3 meanrevert, EWMA.py; 4 = a mean that depends on x alone -- constant, linear, log-linear, as in
+ * experiments/weather/GPGenerator.py:68-82 --: hist_e1 then holds its values at the H test points, [G,H], hist_y is
+ * ignored but must be valid with k = 1), optional mean reversion (:41-42), jitter ladder of psd_safe_cholesky(pred_cov, jitter) (:46).
  * G series x S samples x H steps, H <= VOLT_ROLLOUT_MAX_H.
  *   scratch == NULL  append-only solve: for the volatility kernel the right-hand side prefix and the stored rows
  *                    are step-invariant, so w_s only grows by one entry per step; nothing is stored or re-read.

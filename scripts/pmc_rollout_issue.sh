@@ -26,7 +26,8 @@ a = agg["k"]
 disp = max(n.values()) if n else 0
 per = {c: v / max(1, n[c]) for c, v in a.items()}
 G, S, H = 8, 10000, 256
-out = {"kernel": "rollout_bordered_kernel<1,false>", "workload": f"{G} series x {S} paths x {H} steps, N=4096", "dispatches": disp,
+out = {"kernel": "rollout_bordered_kernel<1,false>", "workload": f"{G} series x {S} paths x {H} steps, N=4096",
+       "shape": {"G": G, "S": S, "H": H, "n": 4096}, "dispatches": disp,
        "per_dispatch": per}
 if "SQ_INSTS_VALU" in per:
     out["valu_wave_insts_per_sample_step"] = per["SQ_INSTS_VALU"] / (G * S * H)

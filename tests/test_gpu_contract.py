@@ -161,6 +161,79 @@ def test_c5_share_rollouts_8x10k_x256_at_4096(ops):
     assert float((tau_f - tau_c).abs().max()) < 1e-6 * float(r_tr.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("mode,name,theta", [(1, "dewma", None), (2, "tewma", None), (3, "meanrevert", None), (0, "ewma", 0.01),
+                                             (3, "meanrevert", 0.01)])
+def test_c5_share_rollouts_other_means_and_theta_at_4096(ops, mode, name, theta):
+    """C5's per-GPU share (8 series x 10,000 paths x 256 steps, N = 4096) for the rest of the EWMA family and with the mean
+    reversion of the wind configuration (theta = 0.01, experiments/weather/GPGenerator.py:76): every path finite and free of
+    jitter, and a handful of paths step by step against the exact conditional with the ORACLE's mean functions on the
+    path's own stacked history (EWMA.py:74-135 restated in oracle/volt_oracle.py; for this kernel the noise-free conditional
+    mean is y_last - m(last) + m(new), rollout_utils.py:36-42)."""
+    from volt_amd import rollout_engine as re_
+    G, n, S, H, k = 8, 4096, 10000, 256, 25
+    x, F, vol = sde_batch(G, n)
+    pv, z = rollout_inputs(vol[:, -1], S, H, seed=3)
+    tx = dev(x)
+    test_x = torch.arange(H, device="cuda") / 252. + tx[-1] + tx[1]
+    logy = torch.log(dev(F[:, 1:]))
+    lat = np.log(F).astype(np.float32).mean(-1) if theta is not None else None        # rollout_utils.py:63
+    mrl = np.log(F[:, 1:]).astype(np.float32).mean(-1)                                # EWMA.py:124
+    samples, info = re_.rollout_series(tx, logy, torch.log(dev(vol)), test_x, dev(pv), dev(z), mode, k,
+                                       latent_mean=None if lat is None else dev(lat), theta=theta, mr_theta=0.5,
+                                       mr_latent=dev(mrl))
+    assert tuple(samples.shape) == (G, S, H) and bool(torch.isfinite(samples).all())
+    assert int((info != 0).sum()) == 0
+    dx = float(x[1] - x[0])
+    out = samples[:, :2].cpu().numpy()
+    tail = 4 * k + 8                                        # three EMA levels deep, clear of the left padding
+    fn = {"ewma": lambda ys, g: vo.ewma_mean(np.zeros(2), np.zeros(3), ys, k),
+          "dewma": lambda ys, g: vo.dewma_mean(np.zeros(2), np.zeros(3), ys, k),
+          "tewma": lambda ys, g: vo.tewma_mean(np.zeros(2), np.zeros(3), ys, k),
+          "meanrevert": lambda ys, g: vo.meanrevert_mean(np.zeros(2), np.zeros(3), ys, k, 0.5, mrl[g])}[name]
+    for g in (0, G - 1):
+        ly = np.log(F[g, 1:]).astype(np.float32)
+        for s_ in range(2):
+            ys = ly[-tail:].copy()
+            for i in range(H):
+                m = fn(ys[-tail:], g)                       # [.., tail + 1]: means at the known points, then at the new one
+                pm = (ys[-1] - m[-2]) + m[-1]
+                if theta is not None:
+                    pm = pm - theta * (pm - lat[g])
+                val = pm + np.sqrt(0.5 * dx * float(pv[g, s_, i]) ** 2) * z[g, s_, i]
+                assert abs(val - out[g, s_, i]) < 1e-3, (name, g, s_, i, val, out[g, s_, i])
+                ys = np.append(ys, np.float32(out[g, s_, i]))
+
+
+@pytest.mark.parametrize("mean_func", ["constant", "loglinear", "linear"])
+def test_rollouts_on_a_mean_that_depends_on_x_alone(ops, mean_func):
+    """The weather driver's default (mean='constant', theta=0.01: experiments/weather/GPGenerator.py:68-82,134) and the stocks
+    driver's constant / loglinear choices (GenerateMultiMeanPreds.py:168-177) call Rollouts on a model whose mean module has
+    parameters but no series state.  The default (bordered) engine takes them as mode 4 -- the mean of an appended point is
+    mean_module(test_x[idx]), history-free -- and must reproduce the dense engine, which walks the reference's statements
+    (rollout_utils.py:6-93) with any mean module, on the same draws."""
+    import copy
+    from volt_amd.rollout_utils import Rollouts
+    from volt_amd.train_utils import TrainVoltMagpieModel
+    n, S, H = 300, 48, 12
+    F, vol = sde_series(n, 5)
+    tx = torch.arange(n, device="cuda") / 365.
+    test_x = torch.arange(H, device="cuda") / 365. + tx[-1] + tx[1]
+    prices = dev(F)
+    model, lh = TrainVoltMagpieModel(tx, prices[1:], None, None, dev(vol), train_iters=15, mean_func=mean_func)
+    model.eval()
+    pv, z = rollout_inputs(vol[-1], S, H, seed=9)
+    res = {}
+    for engine in ("bordered", "dense"):
+        m = copy.deepcopy(model)
+        res[engine] = Rollouts(tx, prices, test_x, m, nsample=S, theta=0.01, pred_vol=dev(pv), z=dev(z), engine=engine)
+        assert tuple(res[engine].shape) == (S, H) and bool(torch.isfinite(res[engine]).all())
+        assert m.train_x.numel() == n + H - 1                            # mutated like the reference (rollout_utils.py:80-86)
+    assert float((res["bordered"] - res["dense"]).abs().max()) < 2e-3
+    m = copy.deepcopy(model)                                             # and it IS the default engine's path, not a fallback
+    from volt_amd import rollout_engine as re_
+    assert re_.rollouts_bordered(tx, prices, test_x, m, dev(pv), dev(z), prices.log().mean(), 0.01) is not None
+
+
 def test_rollouts_factor_route_matches_closed_form(ops):
     """At the reference's default size the engine fed by the fp64 factorisation reproduces the closed-form engine."""
     from volt_amd import rollout_engine as re_

@@ -76,7 +76,7 @@ struct RolloutParams {
     int* info;               // [G,S] 0; +step (1-based) of the first non-positive pivot of L_s (a local jitter was
                              //       applied); -step if the predictive variance stayed <= 0 after the jitter ladder
     int G, S, H, k;
-    int mean_mode;           // 0 ewma, 1 dewma, 2 tewma, 3 meanrevert
+    int mean_mode;           // 0 ewma, 1 dewma, 2 tewma, 3 meanrevert, 4 given: hist_e1 = the mean at the H appended points [G,H]
     int use_theta;
     float theta, mr_theta, jitter;
 };
@@ -246,9 +246,12 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
         wz = wave_sum_f(wz);
 
         // ---- mean of the new point: EWMA family on the stacked series (EWMA.py:20-37) ----------
-        float ma1, e2new;
-        const float mstar = family_mean(p.mean_mode, idx, k, lane, sw, hy, he1, he2, ema_prev, p.mr_theta,
-                                        (p.mean_mode == 3) ? p.mr_latent[g] : 0.f, ma1, e2new);
+        // (mode 4: a mean that is a function of x alone -- constant / linear / log-linear, the weather driver's default,
+        // experiments/weather/GPGenerator.py:68-82 -- is history-free: the host evaluated it at the test points)
+        float ma1 = 0.f, e2new = 0.f;
+        const float mstar = (p.mean_mode == 4) ? p.hist_e1[(size_t)g * H + idx]
+                                               : family_mean(p.mean_mode, idx, k, lane, sw, hy, he1, he2, ema_prev, p.mr_theta,
+                                                             (p.mean_mode == 3) ? p.mr_latent[g] : 0.f, ma1, e2new);
 
         // ---- conditional and draw (rollout_utils.py:36-53) --------------------------------------
         const float v = pv[idx];
@@ -390,8 +393,8 @@ int volt_rollout_bordered_f32(const double* rho, const double* tau, const double
     if (S < 0) return -18;
     if (H < 1 || H > VOLT_ROLLOUT_MAX_H) return -19;
     if (k < 1 || k > 2048) return -20;
-    if (mean_mode < 0 || mean_mode > 3) return -21;
-    if ((mean_mode == 1 || mean_mode == 2) && !hist_e1) return -6;
+    if (mean_mode < 0 || mean_mode > 4) return -21;
+    if ((mean_mode == 1 || mean_mode == 2 || mean_mode == 4) && !hist_e1) return -6;
     if (mean_mode == 2 && !hist_e2) return -7;
     if (mean_mode == 3 && (!ema_prev || !mr_latent)) return -8;
     if (use_theta && !latent) return -10;

@@ -61,16 +61,17 @@ def _family_state(log_y, k, mean_mode, mr_theta=0.5, mr_latent=None):
 MAX_H = 1024         # VOLT_ROLLOUT_MAX_H: a lane owns 4 entries of each of up to four 256-entry chunks of a factor row
 
 
-def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
+def train_block_terms(U, r_tr, solve="factor", jitter=1e-4):
     """rho = u'K^-1 u and tau = u'K^-1 r_tr for the shared train block K = fill(U), in fp64 [G].
 
     u, the covariance between the train points and ANY appended point, is U itself -- k(x*, x_i) = V[min(i, *)] =
     U[i] -- which is also the last column of K.  Hence K^-1 u = e_{N-1} exactly and
-        rho = U[N-1],   tau = r_tr[N-1]                                     (solve="closed", the default).
-    solve="factor" takes the general route the reference takes (rollout_utils.py:35-36: factor the train block,
-    two solves) -- in fp64 on volt_potrf_f64 / volt_trsv_*_f64, because the noise-free block has condition number
-    1e6 (N = 400) .. 1e8 (N = 4096) and an fp32 factor cannot carry it; it is what the tests hold the closed form
-    against, and the route to take should a caller ever need jitter on the train block."""
+        rho = U[N-1],   tau = r_tr[N-1]                                     (solve="closed").
+    solve="factor" -- THE DEFAULT since round 5 -- takes the general route the reference takes (rollout_utils.py:35-36:
+    factor the train block, two solves) -- in fp64 on volt_potrf_f64 / volt_trsv_*_f64, because the noise-free block has
+    condition number 1e6 (N = 400) .. 1e8 (N = 4096) and an fp32 factor cannot carry it.  The closed form is one of the
+    min-structure identities SURVEY 4 reserves for testing: it stays available (and the tests hold the two against each
+    other), but the product path no longer leans on it."""
     U64 = U.double()
     if solve == "closed":
         return U64[:, -1].contiguous(), r_tr[:, -1].double().contiguous()
@@ -82,10 +83,17 @@ def train_block_terms(U, r_tr, solve="closed", jitter=1e-4):
     return (q * q).sum(-1).contiguous(), (q * ztr).sum(-1).contiguous()
 
 
+MODE_GIVEN = 4       # a mean that depends on x alone (constant / linear / log-linear): its values are handed in
+
+
 def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode, k, latent_mean=None, theta=None,
-                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="closed", timing=None, resubstitute=False):
+                   mr_theta=0.5, mr_latent=None, jitter=1e-4, solve="factor", timing=None, resubstitute=False,
+                   given_mean=None):
     """Batched engine entry.  train_x [N]; log_y, log_vol_path [G,N]; test_x [H]; pred_vol, z [G,S,H].
     Returns (samples [G,S,H] on the device, info [G,S]).  `timing` (a dict) receives events bracketing the kernel.
+    ``mean_mode=MODE_GIVEN`` with ``given_mean=(m_train [G,N], m_test [G,H])``: a mean module that is a function of x
+    alone (the weather driver's default constant mean, experiments/weather/GPGenerator.py:68-82; the stocks driver's
+    constant / loglinear choices, GenerateMultiMeanPreds.py:168-177) -- the mean of an appended point is then history-free.
     ``resubstitute``: re-solve every sample's triangular system from its stored rows at every step (H^3/6 * 4 B of HBM
     traffic per path) instead of extending it by one entry -- bitwise the same paths; the cross-check of the default."""
     dev = train_x.device
@@ -104,7 +112,14 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
     # N-1 (K's entries ARE these fp32 prefixes); from there on the kernel adds the increments in fp64.
     acc0 = U[:, -1].double().contiguous()
     # train residuals with the model's mean family
-    m_tr, hist_y, hist_e1, hist_e2, ema_prev, mrl, w = _family_state(log_y, k, mean_mode, mr_theta, mr_latent)
+    if mean_mode == MODE_GIVEN:
+        m_tr, m_te = given_mean
+        m_tr = m_tr.to(f32).expand(G, N)
+        k = 1
+        hist_y, hist_e1, hist_e2, ema_prev, mrl = _tail(log_y.to(f32), 1), m_te.to(f32).expand(G, H).contiguous(), None, None, None
+        w = torch.ones(1, dtype=f32, device=dev)
+    else:
+        m_tr, hist_y, hist_e1, hist_e2, ema_prev, mrl, w = _family_state(log_y, k, mean_mode, mr_theta, mr_latent)
     r_tr = (log_y.to(f32) - m_tr).contiguous()
     # rho = u'K^-1 u and tau = u'K^-1 r_tr enter every sample's Schur complement C_s - rho 11', whose entries are
     # ~dx vol^2 while rho ~ V[N-1]: fp64, and the kernel keeps (CumTrapz sum - rho) in fp64 too.
@@ -136,12 +151,24 @@ def rollout_series(train_x, log_y, log_vol_path, test_x, pred_vol, z, mean_mode,
     return samples, info
 
 
+def _depends_on_x_alone(mm):
+    """Constant / linear / log-linear means (gp.ConstantMean, gp.LinearMean, means.LogLinearMean): parameters and the
+    input, no series state."""
+    from .gp import ConstantMean, LinearMean
+    return isinstance(mm, (ConstantMean, LinearMean))
+
+
 def rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean, theta):
-    """Rollouts(..., engine="bordered"): same inputs / outputs / model mutation as rollout_utils.Rollouts."""
+    """Rollouts(..., engine="bordered"): same inputs / outputs / model mutation as rollout_utils.Rollouts.  Returns None
+    for a mean module this engine has no mode for (neither the EWMA family nor a function of x alone): the caller then
+    runs the dense engine, which takes any mean module -- as it does for horizons beyond MAX_H."""
     mm = model.mean_module
+    given = None
     if type(mm) not in _MODES:
-        raise NotImplementedError(f"bordered rollouts support the EWMA mean family, got {type(mm).__name__}; "
-                                  "use engine='dense'")
+        if not _depends_on_x_alone(mm):
+            return None                                  # the caller falls back to the dense engine
+        with torch.no_grad():                            # rollout_utils.py:31,39: mean_module(train_x), mean_module(test_x)
+            given = (mm(train_x).reshape(1, -1), mm(test_x).reshape(1, -1))
     S, H = pred_vol.shape
     if z is None:
         z = torch.randn(S, H, device=train_x.device)
@@ -151,9 +178,11 @@ def rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean,
     kw = {}
     if isinstance(mm, MeanRevertingEMAMean):
         kw = dict(mr_theta=mm.theta, mr_latent=mm.latent_mean)
+    if given is not None:
+        kw = dict(given_mean=given)
     samples, info = rollout_series(train_x, log_y.unsqueeze(0), model.log_vol_path.unsqueeze(0), test_x,
-                                   pred_vol.unsqueeze(0), z.unsqueeze(0), _MODES[type(mm)], mm.k,
-                                   latent_mean, theta, **kw)
+                                   pred_vol.unsqueeze(0), z.unsqueeze(0), MODE_GIVEN if given is not None else _MODES[type(mm)],
+                                   1 if given is not None else mm.k, latent_mean, theta, **kw)
     if bool((info[0] != 0).any()):
         exhausted = info[0] < 0
         if bool(exhausted.any()):           # psd_safe_cholesky(pred_cov, jitter=1e-4) raises here, rollout_utils.py:46
@@ -169,7 +198,7 @@ def rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean,
         stack_y = torch.cat((log_y.repeat(S, 1), samples[:, :H - 1]), -1)
         stack_vol = torch.cat((model.log_vol_path.repeat(S, 1), pred_vol[:, :H - 1].log()), -1)
         rolling_x = torch.cat((train_x, test_x[:H - 1]))
-        mm.train_y, mm.train_x = stack_y, rolling_x
+        mm.train_y, mm.train_x = stack_y, rolling_x      # (rollout_utils.py:81-82 sets these on ANY mean module)
         model.train_x, model.train_y, model.log_vol_path = rolling_x, stack_y, stack_vol
     return samples.cpu()
 

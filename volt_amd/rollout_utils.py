@@ -153,7 +153,10 @@ def Rollouts(train_x, train_y, test_x, model, nsample=50, method="volt", theta=N
         engine = "dense"                         # the bordered kernel holds <= 1024 appended points per sample
     if engine == "bordered":
         from .rollout_engine import rollouts_bordered
-        return rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean, theta)
+        out = rollouts_bordered(train_x, train_y, test_x, model, pred_vol, z, latent_mean, theta)
+        if out is not None:
+            return out
+        engine = "dense"                         # a mean module the bordered kernel has no mode for: the general route
     if engine != "dense":
         raise ValueError(f"unknown rollout engine {engine!r}")
 
