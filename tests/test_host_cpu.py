@@ -326,12 +326,17 @@ def test_deferred_checks_keep_one_accumulator_per_shape():
     assert gp.deferred_checks._active is None
 
 
-def test_graph_capture_is_declined_where_a_step_fills_the_chip():
-    """train_utils honours graph=True only for launch-bound steps (the library's one-group gate: < 700 tiles per launch)."""
+def test_graph_capture_is_the_default_where_a_step_is_launch_bound():
+    """graph=None (what every reference call site passes: nothing, voltron/train_utils.py:15,69,98,192) captures the
+    iteration where its estimated GPU time is below CAPTURE_BELOW_MS; an explicit True / False is honoured; never on a CPU
+    tensor (there is no CPU path to capture)."""
     import torch
-    from volt_amd.train_utils import _capture_pays
+    from volt_amd.train_utils import _auto_graph, _capture_pays
     assert _capture_pays(torch.empty(1, 4096)) and _capture_pays(torch.empty(4096)) and _capture_pays(torch.empty(64, 399))
-    assert not _capture_pays(torch.empty(64, 4096)) and not _capture_pays(torch.empty(64, 2048))
+    assert _capture_pays(torch.empty(399)) and _capture_pays(torch.empty(64, 2048))
+    assert not _capture_pays(torch.empty(64, 4096)) and not _capture_pays(torch.empty(16, 4096))
+    assert _auto_graph(True, torch.empty(64, 4096)) is True and _auto_graph(False, torch.empty(399)) is False
+    assert _auto_graph(None, torch.empty(399)) is False              # a CPU tensor: nothing to capture
 
 
 def test_reference_driver_imports_resolve():
