@@ -100,6 +100,13 @@ int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_
  * every workgroup of the following steps records [0] s_memrealtime (100 MHz) at entry, [1] at exit, [2] XCC_ID << 32 | HW_ID,
  * two-phase tiles also [3] / [4] entering / leaving the tile pipeline.  NULL switches it off. */
 int volt_tune_batch_stamps(long long* stamps);
+/* Host only: what the library takes the device to be and the schedule gates that follow (csrc/host.h).  out [7] int32:
+ * CUs, XCDs, workgroup slots the balanced schedule plans for, plain / split launches up to this many workgroups run one
+ * per CU, launches below this many workgroups run as one stream group, one-launch steps enabled (bit 0 short series, 1 one
+ * long series, 2 batched).  Every gate was measured on the full MI355X (256 CUs in 8 XCDs); on any other device -- a CPX /
+ * DPX partition, a reduced part -- the slot gates are scaled with the CU count and the one-launch steps are off.
+ * VOLT_TUNE=1 VOLT_FAKE_CUS / VOLT_FAKE_XCCS plan as if for such a device (tests). */
+int volt_topology_describe(int* out);
 
 #ifdef __cplusplus
 }

@@ -84,3 +84,35 @@ def test_bad_arguments():
     assert L.volt_sched_describe(0, 4, 1, 0, 256, 4, C.c_float(0.6), None, 0, None) == -1
     assert L.volt_sched_describe(4, 4, 0, 4, 256, 4, C.c_float(0.6), None, 0, None) == -1     # k == n needs the inverse
     assert L.volt_sched_describe(8, 32, 1, 16, 256, 4, C.c_float(0.6), None, 1, None) == -2
+
+
+def test_topology_guard_scales_the_gates_and_switches_the_one_launch_steps_off():
+    """Every schedule gate was measured on a full MI355X (256 CUs in 8 XCDs).  The library asks the device once
+    (multiprocessor count, hipDeviceAttributeNumberOfXccs); on anything else the slot-count gates scale with the CU count and
+    the one-launch steps -- tuned for the full chip, the batched one relying on one XCD per matrix -- are off, so such a
+    device runs the launch-per-column schedules.  Planned here for a faked 64-CU / 2-XCD device (a CPX-
+    like partition) in a subprocess (the knobs are read once per process); no GPU."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import ctypes as C, json\nfrom volt_amd import _lib\nL = _lib.lib()\no = (C.c_int * 7)()\nL.volt_topology_describe(o)\n"
+            "print(json.dumps({'t': list(o), 'small': L.volt_mll_workspace_bytes(8, 399, 1), 'long': L.volt_mll_workspace_bytes(1, 4096, 1),"
+            " 'b64': L.volt_mll_workspace_bytes(64, 4096, 1), 'p65': L.volt_potrf_workspace_bytes(65, 4096)}))")
+
+    def run(env_extra):
+        env = dict(os.environ)
+        for k in ("VOLT_TUNE", "VOLT_FAKE_CUS", "VOLT_FAKE_XCCS"):
+            env.pop(k, None)
+        env.update(env_extra)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-800:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    full = run({})
+    assert full["t"] == [256, 8, 256, 320, 700, 700, 7]
+    small = run({"VOLT_TUNE": "1", "VOLT_FAKE_CUS": "64", "VOLT_FAKE_XCCS": "2"})
+    assert small["t"] == [64, 2, 64, 80, 175, 175, 0]
+    # no state of a one-launch step is reserved any more: the workspaces shrink to what the launch-per-column path needs
+    assert small["small"] < full["small"] and small["long"] < full["long"] and small["b64"] < full["b64"]
+    assert small["p65"] == 0 and full["p65"] > 0
+    # a fake without VOLT_TUNE=1 is ignored (a deployment reads no environment)
+    assert run({"VOLT_FAKE_CUS": "64"})["t"] == full["t"]

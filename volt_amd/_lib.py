@@ -67,6 +67,7 @@ _TUNE_SIGS = {
     "volt_long_describe": (C.c_int, [_i32, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
     "volt_batch_describe": (C.c_int, [_i32, _i32, _i32, _i32, _ptr, _i32]),
     "volt_tune_batch_stamps": (C.c_int, [_ptr]),
+    "volt_topology_describe": (C.c_int, [_ptr]),
 }
 
 EXPORTS = tuple(_SIGS)                  # every symbol include/volt_hip.h declares

@@ -381,7 +381,7 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
     if (blocks * 256 < std::max(nflags, B)) blocks = (std::max(nflags, B) + 255) / 256;
     hipLaunchKernelGGL(batch_begin_kernel, dim3(blocks), dim3(256), 0, s, Winv, nflags, info, B, prog, nprog);
     const int check = batch_check_word(B, n, has_y);
-    const bool local = (B & 7) == 0 && tunables().batch_local != 0;
+    const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;   // (workgroup w on XCD w % 8)
     const KSource src{K, ldk, bsk, sigma2, jitter, N};
     const TriReduce red{has_y ? rpad : nullptr, zpart, frob, N};
     const unsigned grid = (unsigned)batch_count(B, n, has_y);
@@ -400,6 +400,23 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
 }
 
 extern "C" {
+
+// What the library found the device to be, and the gates that follow from it (host.h): out[0] CUs, [1] XCDs, [2] slots the
+// balanced schedule plans for, [3] / [4] plain / split launches up to this many workgroups run one per CU, [5] launches
+// below this many workgroups run as one stream group, [6] one-launch steps enabled (short series | one long series << 1 |
+// batched << 2).  No GPU needed (a process without a device reports the full-chip defaults).
+int volt_topology_describe(int* out) {
+    if (!out) return -1;
+    const Tunables& tn = tunables();
+    out[0] = tn.cus;
+    out[1] = tn.xccs;
+    out[2] = tn.sched_g;
+    out[3] = tn.plain_spread;
+    out[4] = tn.split_spread;
+    out[5] = tn.group_gate;
+    out[6] = (tn.small_nmax > 0 ? 1 : 0) | (tn.long_on ? 2 : 0) | (tn.batch > 0 ? 4 : 0);
+    return 0;
+}
 
 int volt_tune_batch_stamps(long long* stamps) {
     g_batch_stamps = stamps;

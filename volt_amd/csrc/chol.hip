@@ -1459,12 +1459,8 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
                              float* z, float* apart, void* state, size_t state_bytes, void* stream, hipEvent_t e0,
                              hipEvent_t e1);
 
-const Tunables& tunables() {
-    static const Tunables tn = [] {
-        Tunables t;
-        const char* tune = getenv("VOLT_TUNE");
-        if (!tune || atoi(tune) == 0) return t;              // the frozen defaults
-        auto geti = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
+static Tunables read_env(Tunables t) {                       // VOLT_TUNE=1 processes only
+    auto geti = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
         geti("VOLT_GROUPS", t.groups);
         geti("VOLT_SPLITK_TARGET", t.splitk_target);
         geti("VOLT_SPLITK_MINL", t.splitk_minl);
@@ -1497,11 +1493,52 @@ const Tunables& tunables() {
         geti("VOLT_BATCH_ORDER", t.batch_order);
         geti("VOLT_BATCH_LOCAL", t.batch_local);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
+        geti("VOLT_FAKE_CUS", t.cus);                        // tests: plan as if the device had this many CUs / XCDs
+        geti("VOLT_FAKE_XCCS", t.xccs);
+    return t;
+}
+
+// What the device looks like, and the gates that depend on it (host.h).  A process without a device (the CPU-side tests)
+// keeps the full-chip defaults.
+static void apply_topology(Tunables& t, bool faked) {
+    if (!faked) {
+        int dev = 0, cus = 0, xccs = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+            t.cus = cus;
+            if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, dev) == hipSuccess && xccs > 0) t.xccs = xccs;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (t.cus == 256 && t.xccs == 8) return;
+    const double f = t.cus / 256.0;
+    auto scale = [f](int v, int lo) { const int r = (int)(v * f + 0.5); return r < lo ? lo : r; };
+    t.sched_g = scale(t.sched_g, 8);
+    t.plain_spread = scale(t.plain_spread, 8);
+    t.split_spread = scale(t.split_spread, 16);
+    t.splitk_target = scale(t.splitk_target, 16);
+    t.group_gate = scale(t.group_gate, 16);
+    t.small_nmax = 0;                                        // the one-launch steps: tuned for, and (batched step) placed on, the full chip
+    t.long_on = 0;
+    t.batch = 0;
+}
+
+const Tunables& tunables() {
+    static const Tunables tn = [] {
+        const char* tune0 = getenv("VOLT_TUNE");
+        const bool tuning = tune0 && atoi(tune0) != 0;
+        const bool faked = tuning && (getenv("VOLT_FAKE_CUS") || getenv("VOLT_FAKE_XCCS"));
+        Tunables t = [&] {
+            Tunables t;
+            if (!tuning) return t;                           // the frozen defaults
+            return read_env(t);
+        }();
+        apply_topology(t, faked);
         return t;
     }();
     return tn;
 }
-
 // Optional per-launch timing (bench only): every launch is bracketed by two events on ITS stream; the caller
 // synchronises, and per kernel class gets the summed launch durations and the length of the UNION of the launch
 // intervals (on one stream the two agree; with the batch cut into groups on several streams the launches of a class
@@ -1854,7 +1891,7 @@ static int run_factor_groups(float* A, float* Winv, int* info, int B, int Np, hi
     // Short series: a launch of B (n + 1) tiles that does not fill the 512 workgroup slots gains nothing from sharing the
     // chip with a second group and pays its launches twice (64 x N=399: 0.289 ms/step as one group, 0.387 as two; 64 x
     // 1000: 0.884 / 0.926; 64 x 1400: 1.85 / 1.62; 512 x 399: 1.12 / 1.09)
-    if (force_groups == 0 && (int64_t)B * (n + 1) < 700) G = 1;
+    if (force_groups == 0 && (int64_t)B * (n + 1) < tunables().group_gate) G = 1;
     // Inside a graph capture the groups become branches of the graph, and how the runtime maps them back onto streams at
     // replay is not ours to say: 64 x 4096 replayed at 22.5 ms in some processes and at 34.8 ms in others.  One group is
     // predictable (25.5 ms); captured loops are for the launch-bound sizes, which run as one group anyway.

@@ -16,6 +16,7 @@
 // Used where fp32 cannot carry the conditioning: the rollouts' train-block factor and its rho / tau
 // (volt_amd/rollout_engine.py), and gp.psd_safe_cholesky on fp64 input.
 #include "common.h"
+#include "host.h"
 #include "../../include/volt_hip.h"
 #include "../../include/volt_hip_tune.h"
 #include <mutex>
@@ -720,12 +721,14 @@ static int tune_int(const char* name, int dflt) {
 // workgroups is SPREAD OUT instead -- 16 KB of LDS padding, one workgroup per CU, two rounds -- : the dispatcher otherwise
 // pairs them up, two share one MFMA pipe and the launch lasts as long as the slower pair (8 x 4096 potrf / inverse / MLL
 // step, ms: no spreading 6.38 / 6.05 / 11.7, up to 256 5.93 / 6.05 / 11.5, **up to 512 5.64 / 4.77 / 9.57**; flat beyond).
+// (slot-count gates are for the full chip: scaled with the device's CU count, host.h)
+static int per_chip(int v) { return (int)((int64_t)v * tunables().cus / 256); }
 static unsigned spread64(int workgroups) {
-    static const int lim = tune_int("VOLT_F64_SPREAD", 512);
+    static const int lim = per_chip(tune_int("VOLT_F64_SPREAD", 512));
     return workgroups <= lim ? 16 * 1024 : 0;
 }
 static int trtri64_slices(int i, int B) {                       // row i: i B tiles of 1 .. i K blocks
-    static const int target = tune_int("VOLT_F64_SPLIT_TARGET", 512);
+    static const int target = per_chip(tune_int("VOLT_F64_SPLIT_TARGET", 512));
     int S = target / (i * B);
     if (S > (i + 1) / 2) S = (i + 1) / 2;
     if (S > 16) S = 16;
@@ -876,7 +879,7 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
     // potrf +-2 % and the step 1 - 5 % SLOWER (the third stream competes with the rows of the inverse): depth 2 from B = 6
     static const int look_env = tune_int("VOLT_F64_LOOKAHEAD", -1);
     const int look = look_env >= 0 ? look_env : (B >= 6 ? 2 : 1);
-    static const int target = tune_int("VOLT_F64_SPLIT_TARGET", 512);
+    static const int target = per_chip(tune_int("VOLT_F64_SPLIT_TARGET", 512));
     auto slices = [&](int tiles, int kblocks) {
         int S = tiles > 0 ? target / tiles : 1;
         if (S > kblocks / 2) S = kblocks / 2;                          // a slice is at least two K blocks long

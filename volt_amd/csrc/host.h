@@ -20,8 +20,15 @@ struct Tunables {
     int long_on = 1, long_first = 0, long_emin = 1, long_pad = 1, long_nmin = 2;   // one long series in one launch: on/off, last slice's blocks (0: 3 up to 24 block columns, 4 above), shortest sliced early part, a CU per workgroup, block columns above which it takes one series
     int small_maxb = 40, small_maxb2 = 64;     // ... series at most (three or four block columns / one or two)
     int small_pad_maxb = 40;                   // ... up to this many series with a CU per workgroup (16 KB of LDS padding)
+    // ---- topology (round 5).  Every gate above was measured on a full MI355X: 256 CUs in 8 XCDs.  The device is asked once
+    // (multiprocessor count, hipDeviceAttributeNumberOfXccs); on anything else -- a partitioned (CPX / DPX) or otherwise
+    // reduced device -- the slot-count gates are scaled with the CU count and the one-launch steps, whose tuning AND whose
+    // one-XCD-per-matrix hand-offs assume the full chip, are switched off: such a device runs the launch-per-column schedules.
+    int cus = 256, xccs = 8;
+    int group_gate = 700;                      // launches of fewer workgroups than this run as one stream group
     int batch = 1;                             // the whole batched step in one launch (batch_step.hip): 0 off, 1 where measured faster, 2 wherever it can run
     int batch_order = 0;                       // ... order of a block column's panel tiles in its list: 0 row-major (matrix innermost), 1 matrix-major
     int batch_local = 1;                       // ... batches that are a multiple of 8 hand their tiles on through the XCD's L2 (0: the agent-scope protocol everywhere)
 };
+// (the struct continues: what the device looks like, and what follows from it)
 const Tunables& tunables();                    // chol.hip: read once per process (VOLT_TUNE=1 only)
