@@ -222,15 +222,13 @@ def _auto_graph(graph, target, distributed=False):
     return _capture_pays(target)
 
 
-def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=None, defer=False, batched=False,
+def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=False, defer=False, batched=False,
                post_backward=None, scale=1.0, agree=None):
     """Adam on -mll(model(train_x), target); a batched model's per-series losses are summed for ONE backward (the
     series are independent and Adam is elementwise, so every series gets its own loop's update)."""
     model.train()
     lh.train()
-    graph = _auto_graph(graph, target)
-    if not graph and defer is None:
-        defer = True
+    graph = bool(graph)      # (None is resolved by the public entry points: only THEIR models' steps are known to be capturable)
     optimizer = _adam([{'params': params}], lr, graph)
     mll = ExactMarginalLogLikelihood(lh, model)
     last = {}
@@ -310,7 +308,8 @@ def TrainVolModel(train_x, vol_path, train_iters=1000, printing=False, kernel="b
     and its gradient wrt the kernel's `vol` and the noise run on the HIP step (K = vol * min(x,x') keeps d mll / d vol
     in closed form, gp._ExactMLL)."""
     vol_model, vol_lh = _vol_model(train_x, vol_path, kernel, torch.Size())
-    _fit_exact(vol_model, vol_lh, train_x, vol_path.log(), list(vol_model.parameters()), LR_VOL, train_iters, printing, graph)
+    _fit_exact(vol_model, vol_lh, train_x, vol_path.log(), list(vol_model.parameters()), LR_VOL, train_iters, printing,
+               _auto_graph(graph, vol_path))
     return vol_model, vol_lh
 
 
@@ -341,7 +340,7 @@ def TrainDataModel(train_x, train_y, vol_model, vol_lh, vol_path, train_iters=10
     _set_mean(model, "loglinear", train_x, log_y)
     _attach_vol(model, vol_model, vol_lh, dev)
     params = _train_noise_and_mean(model, lh)
-    _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph)
+    _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, _auto_graph(graph, log_y))
     return model, lh
 
 
@@ -357,7 +356,7 @@ def TrainVoltMagpieModel(train_x, train_y, vol_model, vol_lh, vol_path, train_it
         _set_mean(model, mean_func, train_x, log_y, k, theta)
     _attach_vol(model, vol_model, vol_lh, dev)
     params = _train_noise_and_mean(model, lh)
-    _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph)
+    _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, _auto_graph(graph, log_y))
     return model, lh
 
 
