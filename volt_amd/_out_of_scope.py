@@ -7,6 +7,7 @@ Resolution is lazy (module ``__getattr__``, PEP 562): the name comes from ``base
 importable (the tests' baseline GPs, computing on libvolt_hip.so like everything else), otherwise it is a stand-in that
 raises NotImplementedError when it is CALLED, never when it is imported."""
 import importlib
+import os
 
 WHERE = {
     "MaternGP": "models", "SMGP": "models",
@@ -29,7 +30,15 @@ def _stand_in(name):
 def resolve(name):
     if name not in WHERE:
         raise AttributeError(name)
+    modname = "baselines." + WHERE[name]
     try:
-        return getattr(importlib.import_module("baselines." + WHERE[name]), name)
-    except ImportError:
+        mod = importlib.import_module(modname)
+    except ModuleNotFoundError as e:
+        if e.name not in ("baselines", modname):     # a dependency of OUR baselines is missing: that is an error, not "out of scope"
+            raise
         return _stand_in(name)
+    # only the source tree's own baselines/ (next to volt_amd/) counts: an unrelated installed package of that name does not
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.dirname(os.path.dirname(os.path.abspath(getattr(mod, "__file__", "") or ""))) != here:
+        return _stand_in(name)
+    return getattr(mod, name)

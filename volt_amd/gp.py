@@ -17,6 +17,7 @@ gradient -- runs in libvolt_hip.so through one ``torch.autograd.Function``; ther
 from __future__ import annotations
 
 import math
+import threading
 import warnings
 
 import torch
@@ -397,19 +398,29 @@ class refine_alpha:
     by one step of iterative refinement against K itself (VOLT_REFINE_ALPHA) -- for models whose mean has trainable
     parameters (d mll / d mean = alpha / N; voltron/train_utils.py:213-220) and that train to the noise floor, where any
     fp32 factorisation leaves alpha at cond * eps (the reference's own path included).  Default off: the step then does
-    what the reference's fp32 path does.  Costs one more pass over K and two triangular solves per step."""
-    _on = False
+    what the reference's fp32 path does.  Costs one more pass over K and two triangular solves per step.
+
+    REQUIREMENT: the residual r - K_s alpha is formed against whole rows of the caller's K, so BOTH triangles of every K
+    that passes through an MLL inside the context must hold the symmetric matrix (everywhere else the library reads the
+    lower triangle only); the kernels of this package return full symmetric matrices.  fp32 only (an fp64 step ignores
+    it: its alpha is at cond * eps64 already).  The switch is per THREAD (threading.local) and re-entrant: a context
+    entered on one thread does not change what another thread's steps do."""
+    _tls = threading.local()
 
     def __init__(self, on=True):
         self.on = on
 
+    @staticmethod
+    def active():
+        return bool(getattr(refine_alpha._tls, "on", False))
+
     def __enter__(self):
-        self._prev = refine_alpha._on
-        refine_alpha._on = self.on
+        self._prev = refine_alpha.active()
+        refine_alpha._tls.on = self.on
         return self
 
     def __exit__(self, *exc):
-        refine_alpha._on = self._prev
+        refine_alpha._tls.on = self._prev
         return False
 
 
@@ -433,7 +444,7 @@ class _ExactMLL(torch.autograd.Function):
         noise = noise.to(dt)
         # gpytorch factors through psd_safe_cholesky: plain first, then jitter 1e-6 * 10^i (fp32 default) with a
         # NumericalWarning, then NotPSDError.  Same ladder here; the jitter is added inside the fused step.
-        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0, refine_alpha=refine_alpha._on)
+        out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0, refine_alpha=refine_alpha.active())
         chk = deferred_checks.deferring()
         if chk is not None:
             chk.note(info)
@@ -448,7 +459,7 @@ class _ExactMLL(torch.autograd.Function):
             first = int(info[info != 0][0].item())
             for i in range(3):
                 jitter = (1e-6 if dt == torch.float32 else 1e-8) * (10 ** i)      # gpytorch's defaults per dtype
-                out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter, refine_alpha=refine_alpha._on)
+                out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter, refine_alpha=refine_alpha.active())
                 if not bool((info != 0).any().item()):
                     warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
                     break

@@ -370,6 +370,9 @@ def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, pri
     collectively); ``graph=True`` captures the iteration (single process only: with ranks it falls back to the eager loop
     with a warning).  ``reduce_across_ranks=False`` keeps the fit rank-local even when torch.distributed is up -- no
     collective at all -- for callers whose ranks run DIFFERENT numbers of fits (the sharded forecast drivers).
+    With ``reduce_across_ranks`` EVERY rank of the group must call this with the same ``train_iters``, ``defer`` and ``graph``
+    (each stretch of the loop ends in a collective "replay?" decision, and a rank whose jitter ladder is exhausted raises
+    only after that decision has been taken by all -- see ``agree``): checked once, up front, with an all-gather.
     Returns (model, likelihood, last per-series losses)."""
     from . import distributed as vdist
     B = train_y.shape[0]
@@ -403,6 +406,14 @@ def TrainVoltMagpieBatch(train_x, train_y, vol_path, train_iters=1000, k=25, pri
         flag = torch.tensor([1.0 if bad else 0.0], device=dev)
         vdist._dist().all_reduce(flag, op=vdist._dist().ReduceOp.MAX, group=process_group)
         return bool(flag.item() > 0)
+
+    if distributed:                                       # the loop arguments the collectives depend on must agree
+        mine = torch.tensor([float(train_iters), float(bool(defer)), float(bool(graph))], device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(vdist._dist().get_world_size(process_group))]
+        vdist._dist().all_gather(allv, mine, group=process_group)
+        if any(not torch.equal(v, mine) for v in allv):
+            raise ValueError("TrainVoltMagpieBatch: train_iters / defer / graph differ across the ranks of the group: "
+                             f"{[v.tolist() for v in allv]}")
 
     losses = _fit_exact(model, lh, train_x, log_y, params, LR_DATA, train_iters, printing, graph, defer=defer and not graph,
                         batched=True, post_backward=reduce, agree=agree if distributed else None)
