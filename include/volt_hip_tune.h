@@ -23,7 +23,7 @@
  *                          per CU (320 / 700)
  *   VOLT_BATCH / _ORDER / _LOCAL   the whole batched step in ONE launch (csrc/batch_step.hip): 0 off, 1 where measured faster
  *                          (default), 2 wherever it can run, 3 also ahead of the short- / long-series one-launch steps; order of
- *                          a column's tiles in the list (0); hand-offs through the XCD's L2 when the batch is a multiple of 8 (1)
+ *                          a column's tiles in the list (0; VOLT_BATCH_LAD: look-ahead tiles listed this many columns early, 0: measured no gain); hand-offs through the XCD's L2 when the batch is a multiple of 8 (1)
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
  *                          1 = one column, 2 = two columns (2 from 6 matrices on, else 1)           (read in csrc/chol64.hip)
  *   VOLT_F64_TRTRI_LOOKAHEAD  fp64 inverse: one-row look-ahead on its own stream, 0 / 1 (on up to 4 matrices)
@@ -93,7 +93,8 @@ int volt_long_describe(int n, int first, int emin, int* items, int max_items, in
 /* Host only: the piece list of the one-launch BATCHED step (csrc/batch_sched.h, csrc/batch_step.hip) for B matrices of n
  * block columns, in grid order: items [max_items][4] int32 {kind | b << 3, row, col, 0}, kind 0 diagonal tile D(k = row),
  * 1 look-ahead for tile (row+1,row+1), 2 panel tile (row, col), 3 tile (row, col) of the inverse, 4 its diagonal tile.
- * order: 0 positions in column order with the matrix innermost, 1 matrix-group-major inside a block column.  items may be
+ * order: bit 0: 0 positions in column order with the matrix innermost, 1 matrix-group-major inside a block column; bits
+ * 1.. : how many block columns early the look-ahead tiles are listed (VOLT_BATCH_LAD).  items may be
  * NULL (count only).  Returns the number of pieces (= workgroups of the launch), -1 bad argument, -2 max_items too small. */
 int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_items);
 /* The one-launch batched step: while `stamps` (device, 8 int64 per workgroup of the launch = per piece of the list) is set,

@@ -17,7 +17,9 @@ y = torch.log(torch.tensor(F[:, 1:]).cuda()); r = (y - y.mean(-1, keepdim=True))
 s2 = torch.full((B,), 0.05, device="cuda")
 ws = ops.MllWorkspace(B, n, True, K.device)
 nb = ops.padded_n(n) // 128
-order = int(os.environ.get("VOLT_BATCH_ORDER", "0"))
+lad = int(os.environ.get("VOLT_BATCH_LAD", "0"))
+while lad > 0 and 2 * lad * B > 128: lad -= 1              # batch_step.hip, batch_lad()
+order = int(os.environ.get("VOLT_BATCH_ORDER", "0")) | lad << 1
 cnt = L.volt_batch_describe(B, nb, 1, order, None, 0)
 buf = (C.c_int * (4 * cnt))()
 assert L.volt_batch_describe(B, nb, 1, order, buf, cnt) == cnt

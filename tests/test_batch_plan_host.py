@@ -22,8 +22,10 @@ def plan(B, n, has_y, order=0):
     return np.array(buf).reshape(cnt, 4)
 
 
-@pytest.mark.parametrize("B,n,has_y,order", [(8, 4, 1, 0), (3, 5, 1, 0), (16, 7, 1, 1), (5, 6, 0, 0), (1, 1, 1, 0), (2, 2, 1, 0), (64, 32, 1, 0)])
+@pytest.mark.parametrize("B,n,has_y,order", [(8, 4, 1, 0), (3, 5, 1, 0), (16, 7, 1, 1), (5, 6, 0, 0), (1, 1, 1, 0), (2, 2, 1, 0), (64, 32, 1, 0),
+                                             (8, 9, 1, 2 << 1), (16, 12, 0, 1 << 1), (8, 32, 1, 2 << 1 | 1)])
 def test_list_is_topological_and_complete(B, n, has_y, order):
+    lad = order >> 1                     # look-ahead tiles listed this many block columns early (the one sanctioned forward wait)
     it = plan(B, n, has_y, order)
     kind, b, row, col = it[:, 0] & 7, it[:, 0] >> 3, it[:, 1], it[:, 2]
     pos = {}
@@ -57,7 +59,12 @@ def test_list_is_topological_and_complete(B, n, has_y, order):
             if r >= 2:
                 before((LA, bb, r - 1, 0), (k, bb, r, c))             # the look-ahead part of A[k, k]
         elif k == LA:
-            before((P, bb, r + 1, r - 1), (k, bb, r, c))              # row k+1 up to column k-1
+            if lad == 0:
+                before((P, bb, r + 1, r - 1), (k, bb, r, c))          # row k+1 up to column k-1
+            else:                                                     # listed early: behind D(max(1, k - lad)), and what it
+                before((D, bb, max(1, r - lad), 0), (k, bb, r, c))    # still waits for is at most `lad` block columns on
+                assert pos[(P, bb, r + 1, r - 1)] < pos[(D, bb, min(r + 1, n - 1), 0)]
+            before((k, bb, r, c), (D, bb, r + 1, 0))                  # and ahead of the diagonal tile that needs it
         elif k == P:
             before((D, bb, c, 0), (k, bb, r, c))                      # W_k
             if c >= 1:
@@ -84,4 +91,4 @@ def test_gate_is_a_function_of_the_shape_only():
     grow = lambda B, N: L.volt_mll_workspace_bytes(B, N, 1)
     assert grow(64, 4096) > 64 * (2 * 4096 * 4096 * 4)                # A and Y and more
     assert L.volt_potrf_workspace_bytes(2, 1024) == L.volt_potrf_workspace_bytes(2, 1024)   # deterministic
-    assert L.volt_batch_describe(0, 4, 1, 0, None, 0) == -1 and L.volt_batch_describe(4, 4, 1, 2, None, 0) == -1
+    assert L.volt_batch_describe(0, 4, 1, 0, None, 0) == -1 and L.volt_batch_describe(4, 4, 1, 16, None, 0) == -1

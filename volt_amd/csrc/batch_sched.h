@@ -51,7 +51,15 @@ inline int64_t batch_count(int B, int n, bool has_y) {
 // order: 0 = positions in the order above, matrix innermost;  1 = panel / trtri tiles of a block column matrix-major in
 // groups of 8 matrices (the 8 matrices of a group still alternate, so the XCD mapping holds): a matrix's tiles of one
 // block column are then adjacent in ITS XCD's queue and share its block row k while it is hot
-inline void batch_build(int B, int n, bool has_y, int order, std::vector<BatchItem>& items) {
+// lad: how many block columns EARLY the look-ahead tiles are listed.  LA(k) -- A[k+1,k+1] -= sum_{m<k} L[k+1,m] L[k+1,m]^T, k K
+// blocks on the 2x2-wave core -- feeds D(k+1); listed with column k it starts when D(k) is dispatched and, sharing its CU,
+// needs ~14 us per block: with few matrices per XCD it finishes AFTER W_k and the pivots wait for it (8 x 4096: LA(20) ends
+// 117 us after D(20), stamps of profiles/r05).  Listed lad columns earlier it chases row k+1 from then on and has one block
+// left when column k-1 completes.  It then waits for a piece listed AFTER it (P(k+1,k-1)): allowed because only lad * B
+// workgroups at a time do so -- the caller keeps that far below the number of resident workgroups -- so the pieces they wait
+// for are always dispatched (the dispatch-order argument needs every waiter to wait on a RUNNING piece; here the few
+// forward waiters cannot fill the chip).
+inline void batch_build(int B, int n, bool has_y, int order, std::vector<BatchItem>& items, int lad = 0) {
     auto emit = [&](int kind, int row, int col) {
         for (int b = 0; b < B; ++b) items.push_back({kind | b << 3, row, col, 0});
     };
@@ -75,7 +83,8 @@ inline void batch_build(int B, int n, bool has_y, int order, std::vector<BatchIt
     };
     for (int k = 0; k < n; ++k) {
         emit(BK_DIAG, k, 0);
-        if (k >= 1 && k + 1 < n) emit(BK_LOOKAHEAD, k, 0);
+        for (int kk = 1; kk + 1 < n; ++kk)                   // the look-ahead tiles listed with this column
+            if ((kk - lad > 1 ? kk - lad : 1) == k) emit(BK_LOOKAHEAD, kk, 0);
         // the row the next diagonal tile needs first, for every matrix; then the rest
         if (k + 1 < n) emit(BK_PANEL, k + 1, k);
         emit_run(BK_PANEL, n - k - 2 > 0 ? n - k - 2 : 0, [&](int p) { return k + 2 + p; }, [&](int p) { return k; });

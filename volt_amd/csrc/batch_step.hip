@@ -303,6 +303,14 @@ bool volt_internal_batch_applies(int B, int n, int has_y) {
 
 bool volt_internal_batch_first() { return tunables().batch >= 3; }   // tuning: ahead of the short- / long-series steps
 
+// look-ahead tiles listed this many block columns early (batch_sched.h): only while the forward waiters are a small part of
+// the 512 resident workgroups
+static int batch_lad(int B) {
+    int lad = tunables().batch_lad;
+    while (lad > 0 && 2 * lad * B > 128) --lad;
+    return lad;
+}
+
 static size_t batch_table_bytes(int B, int n, bool has_y) {
     return ((size_t)(BATCH_HDR + batch_count(B, n, has_y)) * sizeof(BatchItem) + 255) & ~(size_t)255;
 }
@@ -315,7 +323,7 @@ size_t volt_internal_batch_bytes(int B, int n, int has_y) {
 
 // the word every piece of a table carries: what the table was built for
 static int batch_check_word(int B, int n, bool has_y) {
-    return BATCH_MAGIC ^ (B * 0x01000193) ^ (n << 20) ^ (has_y ? 0x40000000 : 0) ^ (tunables().batch_order << 28);
+    return BATCH_MAGIC ^ (B * 0x01000193) ^ (n << 20) ^ (has_y ? 0x40000000 : 0) ^ (tunables().batch_order << 28) ^ (batch_lad(B) << 16);
 }
 
 // The table, built once per (B, n, inverse?, order) in pinned host memory and kept for the life of the library (host
@@ -328,12 +336,12 @@ static const BatchTable* get_batch_table(int B, int n, bool has_y) {
     static std::mutex mu;
     static std::map<std::array<int, 4>, BatchTable*> cache;
     const int order = tunables().batch_order;
-    const std::array<int, 4> key{B, n, has_y ? 1 : 0, order};
+    const std::array<int, 4> key{B, n, has_y ? 1 : 0, order * 16 + batch_lad(B)};
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     std::vector<BatchItem> items;
-    batch_build(B, n, has_y, order, items);
+    batch_build(B, n, has_y, order, items, batch_lad(B));
     BatchTable* bt = new BatchTable;
     static_assert(sizeof(BatchItem) == sizeof(int4), "items are read as int4");
     bt->bytes = (BATCH_HDR + items.size()) * sizeof(BatchItem);
@@ -426,9 +434,9 @@ int volt_tune_batch_stamps(long long* stamps) {
 // Host only (no GPU): the piece list of the one-launch batched step, in grid order -- items [max_items][4] int32
 // {kind | b << 3, row, col, 0} (batch_sched.h).  Returns the number of pieces, -1 bad argument, -2 max_items too small.
 int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_items) {
-    if (B < 1 || n < 1 || order < 0 || order > 1) return -1;
+    if (B < 1 || n < 1 || order < 0 || order > 15) return -1;
     std::vector<BatchItem> it;
-    batch_build(B, n, has_y != 0, order, it);
+    batch_build(B, n, has_y != 0, order & 1, it, order >> 1);
     if ((int64_t)it.size() != batch_count(B, n, has_y != 0)) return -1;
     if (items) {
         if ((int)it.size() > max_items) return -2;

@@ -1492,6 +1492,7 @@ static Tunables read_env(Tunables t) {                       // VOLT_TUNE=1 proc
         geti("VOLT_BATCH", t.batch);
         geti("VOLT_BATCH_ORDER", t.batch_order);
         geti("VOLT_BATCH_LOCAL", t.batch_local);
+        geti("VOLT_BATCH_LAD", t.batch_lad);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         geti("VOLT_FAKE_CUS", t.cus);                        // tests: plan as if the device had this many CUs / XCDs
         geti("VOLT_FAKE_XCCS", t.xccs);
