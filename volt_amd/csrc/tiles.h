@@ -904,6 +904,22 @@ __device__ __forceinline__ TriJob trtri_job(const float* __restrict__ A, const f
     return jb;
 }
 
+// Slabs are stored WRITE-THROUGH (sc1): the data goes to memory without a release fence.  A release
+// (buffer_wbl2) writes back every dirty line of the XCD's L2 -- with hundreds of slices arriving per launch, each
+// behind its own release, the split schedule ran SLOWER the more slices there were (B = 8: S = 2 5.1 ms, S = 8 9.0 ms).
+__device__ __forceinline__ void slab_dump(const f32x16 (&acc)[4], float* __restrict__ slab) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)slab, 0, TS * TS * 4, 0x00020000);
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[t4][4 * g + e];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, ((t4 * 4 + g) * NT + (int)threadIdx.x) * 16, 0,
+                                                   16 /* sc1 */);
+        }
+}
 // T0 of a two-phase tile (factor_step_kernel's prologue)
 __device__ __forceinline__ void job_t0(const TriJob& jb, f32x16 (&T)[4]) {
     if (jb.c0 && jb.row_ok && jb.vec_ok) {
