@@ -371,7 +371,7 @@ def main():
     cfgs = None
     if rank == 0 and world == 1 and not args.no_aux_legs and not args.no_configs:
         del ws
-        cfgs = configs_leg(make_step, timed, dev, K_all, y_all, n, args.batch)
+        cfgs = configs_leg(make_step, timed, dev, K_all, y_all, n, args.batch, api_inputs=(x, F, vol))
         ws = ops.MllWorkspace(B, n, True, dev)
 
     # ---- API leg (rank 0, N=1): what a caller of the drop-in surface pays per iteration
@@ -597,7 +597,7 @@ def api_default_leg(dev, n=399, t1=30, t2=230):
             "iterations": [t1, t2]}
 
 
-def configs_leg(make_step, timed, dev, K_all, y_all, n_head, batch_head, steps=50, warmup=5):
+def configs_leg(make_step, timed, dev, K_all, y_all, n_head, batch_head, steps=50, warmup=5, api_inputs=None):
     """Every BASELINE.json configuration beside the metric (and the reference's own default size), driver-run: the
     training-loop body of the headline (EWMA mean -> softplus -> volt_mll_step_f32 -> chain rule -> Adam) through the same
     timing loop, `steps` steps each.  frac = algorithmic 2 N^3 / 3 flop per series / ms_per_step / the fp32 MFMA peak."""
@@ -624,6 +624,35 @@ def configs_leg(make_step, timed, dev, K_all, y_all, n_head, batch_head, steps=5
         out[name] = {"what": what, "batch": Bc, "n": nc, "steps": steps, "ms_per_step": round(ms, 4), "tflops": round(tf, 2),
                      "frac": round(tf / FP32_MFMA_PEAK_TF, 4), "not_pd": int((info != 0).sum().item())}
         del step, ws_, Ks, ys
+        # the same shape through the drop-in surface with the reference's arguments (no `graph`: captured where the step is
+        # launch-bound, volt_amd/train_utils.py) -- per iteration as the difference of two runs
+        try:
+            from volt_amd.train_utils import TrainVoltMagpieBatch, _capture_pays
+            if nc == n_head and Bc <= K_all.shape[0]:
+                xa, Fa, va = api_inputs
+                xa, Fa, va = xa, Fa[:Bc], va[:Bc]
+            else:
+                xa, Fa, va = x, F, vol
+            tx = torch.tensor(xa, device=dev)
+            pr = torch.tensor(Fa[:Bc, 1:], device=dev)
+            vv = torch.tensor(va[:Bc], device=dev)
+
+            def run(iters):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                TrainVoltMagpieBatch(tx, pr, vv, train_iters=iters, k=EWMA_K)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            t1_, t2_ = (10, 60) if ms < 2.0 else (6, 16)
+            run(t1_)
+            a_ = min(run(t1_) for _ in range(2))
+            b_ = min(run(t2_) for _ in range(2))
+            api_ms = (b_ - a_) / (t2_ - t1_) * 1e3
+            out[name]["api_default"] = {"ms_per_iteration": round(api_ms, 4), "captured": bool(_capture_pays(pr)),
+                                        "tflops": round(Bc * 2 * nc ** 3 / 3 / (api_ms * 1e-3) / 1e12, 2),
+                                        "frac": round(Bc * 2 * nc ** 3 / 3 / (api_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+        except Exception as e:                          # never let the extra leg cost the line
+            out[name]["api_default"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
             calls[k][c] += 1
 names = sorted(agg, key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", agg[k].get("GRBM_GUI_ACTIVE", 0)))
 for k in names:
-    if not k.startswith(("potrf", "trtri", "factor_", "diag_trtri", "fill", "prepare", "reduce", "y_times", "trsv", "rollout", "sum_zpart", "mll_", "tune_", "update64", "trsm64", "diag64")):
+    if not k.startswith(("potrf", "trtri", "factor_", "batch_step", "alpha_sum", "diag_trtri", "fill", "prepare", "reduce", "y_times", "trsv", "rollout", "sum_zpart", "mll_", "tune_", "update64", "trsm64", "diag64")):
         continue
     a = agg[k]
     n = max(calls[k].values())

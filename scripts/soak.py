@@ -1,5 +1,6 @@
 """Soak: many repeated steps over shapes that exercise every hand-off protocol (one-launch long / short series, split-K
-tickets, balanced-schedule slabs, two stream groups), checking info == 0 and BITWISE repeatability of every step.
+tickets, balanced-schedule slabs, two stream groups; round 5: the one-launch batched step's progress words in both hand-off
+protocols -- batches that are a multiple of 8 and those that are not), checking info == 0 and BITWISE repeatability of every step.
     python scripts/soak.py [seconds per shape]"""
 import os, sys, time
 import numpy as np, torch
@@ -8,7 +9,7 @@ from volt_amd import ops
 from volt_amd.synthetic import sde_batch
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 15.0
-for B, n in [(1, 4096), (1, 1500), (8, 399), (40, 399), (2, 4096), (8, 4096), (16, 4096), (12, 2900), (64, 2048), (64, 4096)]:
+for B, n in [(1, 4096), (1, 1500), (8, 399), (40, 399), (2, 4096), (8, 4096), (16, 4096), (12, 2900), (3, 3072), (24, 1536), (64, 2048), (64, 4096)]:
     x, F, vol = sde_batch(min(B, 8), n)
     vol = np.tile(vol, (B // min(B, 8) + 1, 1))[:B]; F = np.tile(F, (B // min(B, 8) + 1, 1))[:B]
     K = ops.fill(ops.cumtrapz(torch.tensor(vol).cuda(), torch.tensor(x).cuda(), square=True))
