@@ -62,6 +62,9 @@ if s.shape[1] >= 8 and (s[:, 5] > 0).any():
     for k in (2, 3):
         m = kind == k
         print(f"  {names[k]}: entry->item loaded {np.mean(t5[m] - beg[m]):5.2f}, ->pipeline {np.mean(kb[m] - t5[m]):5.2f}; pipeline end->reduced {np.mean(t6[m] - ke[m]):5.2f}, ->tile stored + drained (thread 0) {np.mean(t7[m] - t6[m]):5.2f}, ->exit {np.mean(end[m] - t7[m]):5.2f} us")
+md = (kind == 0) & (items[:, 1] >= 2)
+if md.any() and (s[md, 3] > 0).all():
+    print(f"  diag (k >= 2): entry->inputs seen {np.mean(kb[md] - beg[md]):7.2f} us, last K block into the image {np.mean(ke[md] - kb[md]):6.2f}, pivots + inverse + publish {np.mean(end[md] - ke[md]):6.2f} (means; alone: ~7 and ~25)")
 # per CU: how much of the launch had 0 / 1 / 2 workgroups INSIDE a pipeline (two-phase tiles: stamps 3..4; look-ahead: whole piece)
 key = ((xcc * 8 + se) * 2 + sh_) * 16 + cu
 pb = np.where((kind == 2) | (kind == 3), kb, beg); pe = np.where((kind == 2) | (kind == 3), ke, end)

@@ -7,14 +7,16 @@ import json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [   # shape, {label: env}
-    # (round 5) the one-launch batched step is the default for the first five; "launch per column" = the round-4 schedules
+    # (round 5) the one-launch batched step is the default for the first eight; "launch per column" = the round-4 schedules
     ("64x4096", {"launch per column, 2 groups": {"VOLT_BATCH": "0"}, "launch per column, 1 group": {"VOLT_BATCH": "0", "VOLT_GROUPS": "1"}}),
     ("64x2048", {"launch per column, 2 groups": {"VOLT_BATCH": "0"}, "launch per column, 4 groups": {"VOLT_BATCH": "0", "VOLT_GROUPS": "4"}}),
     ("32x4096", {"launch per column": {"VOLT_BATCH": "0"}, "launch per column, balanced": {"VOLT_BATCH": "0", "VOLT_SCHED_MAXB": "32"}}),
     ("16x4096", {"launch per column, balanced": {"VOLT_BATCH": "0"}, "launch per column, plain": {"VOLT_BATCH": "0", "VOLT_SCHED": "0"}}),
     ("8x4096", {"launch per column, balanced": {"VOLT_BATCH": "0"}, "launch per column, plain": {"VOLT_BATCH": "0", "VOLT_SCHED": "0"}}),
-    ("4x4096", {"no balanced schedule": {"VOLT_SCHED": "0"}, "one launch (batched step)": {"VOLT_BATCH": "2"}}),
-    ("2x4096", {"balanced schedule from B=2": {"VOLT_SCHED_MINB": "2"}}),
+    ("4x4096", {"launch per column, balanced": {"VOLT_BATCH": "0"}, "two workgroups per CU": {"VOLT_BATCH_SPREAD": "0"}}),
+    ("2x4096", {"launch per column, split-K": {"VOLT_BATCH": "0"}, "two workgroups per CU": {"VOLT_BATCH_SPREAD": "0"}}),
+    ("16x2048", {"launch per column": {"VOLT_BATCH": "0"}, "two workgroups per CU": {"VOLT_BATCH_SPREAD": "0"}}),
+    ("4x2048", {"one launch (batched step)": {"VOLT_BATCH": "2"}}),
     ("1x4096", {"launch per column": {"VOLT_LONG": "0"}, "one-workgroup spine": {"VOLT_LONG_SPLIT": "0"}}),
     ("1x399", {"launch per column": {"VOLT_LONG": "0", "VOLT_SMALL_NMAX": "0"}, "short-series kernel": {"VOLT_LONG": "0"}}),
     ("8x399", {"launch per column": {"VOLT_SMALL_NMAX": "0"}, "batched step": {"VOLT_BATCH": "3"}}),

@@ -191,6 +191,11 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
 
     if (kind == BK_DIAG) {
         const int k = d.y;
+        // The pivot chain is what a block column waits for, and here it shares its CU with a tile that issues MFMAs and LDS
+        // reads from every SIMD: left at the default priority its dependent readlane / FMA chain took 60 - 150 us instead of
+        // the 30 it takes alone (8 x 4096, profiles/r05 stamps).  Raised above the co-resident tile's waves it is issued the
+        // cycle it is ready -- and being a dependent chain it leaves almost every issue slot to the other tile anyway.
+        __builtin_amdgcn_s_setprio(3);
         if (k == 0) {
             if (usek) {
                 diag0_image(src, b, smem);
@@ -202,8 +207,10 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
         }
         // L[k,k-1] (and with it all of row k) is there; k >= 2: the look-ahead part of A[k,k] is parked
         batch_wait<LOCAL>(rowp + k, k, k >= 2 ? la + k : nullptr, 1, info_b);
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
         if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, b, src, smem, true);
         else update_body<FROMK>(A, Np, 1, 1, 0, 1, true, b, src, smem, true);
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
         diag_body<false, false, LOCAL>(A, Winv, info, Np, k, b, smem, nullptr, true);
         return;
     }
@@ -288,16 +295,15 @@ bool volt_internal_batch_applies(int B, int n, int has_y) {
     if (tn.batch <= 0 || B < 1 || n < 2 || B > 65535) return false;
     if (tn.batch >= 2) return true;
     if (has_y) {
-        if (n >= 28) return B >= 2;                          // N = 4096: 1.02 - 1.13 x at every batch size
-        if (n >= 20) return B >= 3;                          // N = 3072: 1.0 - 1.15 x (10 .. 16 matrices: a tie)
-        if (n >= 14) return B >= 6;                          // N = 2048: 1.06 - 1.46 x
-        if (n >= 10) return B == 8 || B >= 16;               // N = 1536: 1.06 - 1.38 x (10, 12 matrices: 0.9 - 0.97)
-        if (n >= 8) return B >= 32;                          // N = 1024: 1.0 - 1.24 x
+        if (n >= 20) return B >= 2;                          // N = 3072, 4096: 1.01 - 1.44 x at every batch size from 2 on
+        if (n >= 10) return B >= 6;                          // N = 1536, 2048: 1.02 - 1.59 x (2 - 4 matrices: 0.90 - 0.99)
+        if (n >= 8) return B >= 20;                          // N = 1024: 1.07 - 1.48 x
         return false;
     }
-    if (n >= 20) return B >= 3;                              // the factorisation alone: 1.03 - 1.35 x
-    if (n >= 14) return B >= 8;
-    if (n >= 10) return B == 8 || B >= 20;
+    if (n >= 28) return B >= 2;                              // the factorisation alone: 1.02 - 1.74 x
+    if (n >= 20) return B >= 3;
+    if (n >= 10) return B >= 8;                              // (10, 12 matrices of N = 1536: a tie)
+    if (n >= 8) return B >= 24;
     return false;
 }
 
@@ -393,9 +399,14 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
     const KSource src{K, ldk, bsk, sigma2, jitter, N};
     const TriReduce red{has_y ? rpad : nullptr, zpart, frob, N};
     const unsigned grid = (unsigned)batch_count(B, n, has_y);
+    // Few matrices: ONE workgroup per CU (16 KB of dynamic LDS padding).  With two, the diagonal tile -- the latency chain a
+    // block column waits for -- shares its CU's LDS and issue slots with a tile in its K loop and takes 80 us instead of 32
+    // (8 x 4096 stamps, profiles/r05); alone on the CU it runs at its own pace, and the tiles lose only the few percent
+    // that a second resident tile adds to the MFMA duty.
+    const unsigned pad = (int64_t)B * (n + 1) <= tunables().batch_spread ? 16 * 1024 : 0;   // (measured crossover: host.h)
     if (e0 && hipEventRecord(e0, s) != hipSuccess) return (int)hipGetLastError();
 #define VOLT_BATCH_LAUNCH(FK, LC)                                                                                         \
-    hipLaunchKernelGGL((batch_step_kernel<FK, LC>), dim3(grid), dim3(256), 0, s, A, Winv, Y, info, Np, B, src, red, tab, prog, \
+    hipLaunchKernelGGL((batch_step_kernel<FK, LC>), dim3(grid), dim3(256), pad, s, A, Winv, Y, info, Np, B, src, red, tab, prog, \
                        pstride, check, z, apart, g_batch_stamps)
     if (K && local) VOLT_BATCH_LAUNCH(true, true);
     else if (K) VOLT_BATCH_LAUNCH(true, false);

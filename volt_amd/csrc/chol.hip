@@ -463,6 +463,7 @@ static Tunables read_env(Tunables t) {                       // VOLT_TUNE=1 proc
         geti("VOLT_BATCH", t.batch);
         geti("VOLT_BATCH_ORDER", t.batch_order);
         geti("VOLT_BATCH_LOCAL", t.batch_local);
+        geti("VOLT_BATCH_SPREAD", t.batch_spread);
         geti("VOLT_BATCH_LAD", t.batch_lad);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         geti("VOLT_FAKE_CUS", t.cus);                        // tests: plan as if the device had this many CUs / XCDs
@@ -491,6 +492,7 @@ static void apply_topology(Tunables& t, bool faked) {
     t.split_spread = scale(t.split_spread, 16);
     t.splitk_target = scale(t.splitk_target, 16);
     t.group_gate = scale(t.group_gate, 16);
+    t.batch_spread = scale(t.batch_spread, 8);
     t.small_nmax = 0;                                        // the one-launch steps: tuned for, and (batched step) placed on, the full chip
     t.long_on = 0;
     t.batch = 0;
