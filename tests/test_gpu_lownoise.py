@@ -143,4 +143,13 @@ def test_refine_alpha_context_improves_the_mean_gradient():
         errs[on] = float(np.abs(gm - o["d_mean"]).max() / np.abs(o["d_mean"]).max())
         np.testing.assert_allclose(val.detach().cpu().numpy(), o["mll"], rtol=6e-5)
     assert errs[True] <= 2e-6 and errs[True] < 0.5 * errs[False], errs
-    assert gp.refine_alpha._on is False
+    assert gp.refine_alpha.active() is False
+    # the switch is per thread: a context held on this thread does not reach another thread's steps
+    import threading
+    seen = []
+    with gp.refine_alpha():
+        t = threading.Thread(target=lambda: seen.append(gp.refine_alpha.active()))
+        t.start()
+        t.join()
+        assert gp.refine_alpha.active() is True
+    assert seen == [False]
