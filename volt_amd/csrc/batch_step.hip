@@ -403,7 +403,8 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
     // block column waits for -- shares its CU's LDS and issue slots with a tile in its K loop and takes 80 us instead of 32
     // (8 x 4096 stamps, profiles/r05); alone on the CU it runs at its own pace, and the tiles lose only the few percent
     // that a second resident tile adds to the MFMA duty.
-    const unsigned pad = (int64_t)B * (n + 1) <= tunables().batch_spread ? 16 * 1024 : 0;   // (measured crossover: host.h)
+    const int spread = tunables().batch_spread + (n < 32 ? 9 * (32 - n) * tunables().cus / 256 : 0);   // (measured crossovers: host.h)
+    const unsigned pad = (int64_t)B * (n + 1) <= spread ? 16 * 1024 : 0;
     if (e0 && hipEventRecord(e0, s) != hipSuccess) return (int)hipGetLastError();
 #define VOLT_BATCH_LAUNCH(FK, LC)                                                                                         \
     hipLaunchKernelGGL((batch_step_kernel<FK, LC>), dim3(grid), dim3(256), pad, s, A, Winv, Y, info, Np, B, src, red, tab, prog, \
