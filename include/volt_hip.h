@@ -121,6 +121,11 @@ int volt_potrf_k_f32(const float* K, int64_t ldk, int64_t bsk, const float* sigm
 int volt_prepare_f64(const double* K, int64_t ldk, int64_t bsk, const double* sigma2, double jitter,
                      double* A, int B, int N, void* stream);
 int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stream);
+/* The same with caller scratch (256-byte aligned, volt_potrf_workspace_bytes_f64(B, Np) bytes -- a few KB of progress words,
+ * 0 where the shape does not use them; nothing to initialise): small batches of long series run the whole factorisation as
+ * ONE launch (csrc/batch64_step.hip) instead of three launches per block column.  ws == NULL is volt_potrf_f64. */
+size_t volt_potrf_workspace_bytes_f64(int B, int Np);
+int volt_potrf_ws_f64(double* A, double* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a5/a6: triangular solves with one right-hand side  (torch.cholesky_solve at
  * rollout_utils.py:36,44; gpytorch inv_quad) ------------------------------------------------

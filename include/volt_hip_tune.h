@@ -101,6 +101,14 @@ int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_
  * every workgroup of the following steps records [0] s_memrealtime (100 MHz) at entry, [1] at exit, [2] XCC_ID << 32 | HW_ID,
  * two-phase tiles also [3] / [4] entering / leaving the tile pipeline.  NULL switches it off. */
 int volt_tune_batch_stamps(long long* stamps);
+/* The fp64 one-launch step (csrc/batch64_step.hip).  Host only: its piece list in grid order, items [max_items][4] int32
+ * {kind, row, col, matrix}: kind 0 diagonal block D(k = row), 1 panel tile (row, col), 2 diagonal tile of the inverse, 3 tile
+ * (row, col) of the inverse.  items may be NULL (count only).  Returns the number of pieces, -1 bad argument, -2 too small. */
+int volt_batch64_describe(int B, int n, int has_y, int* items, int max_items);
+/* ... and its stamps, 8 int64 per workgroup: [0] entry, [1] exit, [2] XCC_ID << 32 | HW_ID, [3] behind the chased product,
+ * [4] behind the wait for W, [5] behind the second product.  VOLT_BATCH64 = 0 / 1 / 2: off / where measured faster / wherever
+ * it can run; VOLT_BATCH64_MAX: tiles per block column, B (n + 1), up to which it runs. */
+int volt_tune_batch64_stamps(long long* stamps);
 /* Host only: what the library takes the device to be and the schedule gates that follow (csrc/host.h).  out [7] int32:
  * CUs, XCDs, workgroup slots the balanced schedule plans for, plain / split launches up to this many workgroups run one
  * per CU, launches below this many workgroups run as one stream group, one-launch steps enabled (bit 0 short series, 1 one

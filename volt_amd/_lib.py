@@ -32,6 +32,8 @@ _SIGS = {
     "volt_potrf_k_f32": (C.c_int, [_ptr, _i64, _i64, _ptr, C.c_float, _ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _i32, _ptr]),
     "volt_prepare_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, _f64, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_potrf_workspace_bytes_f64": (C.c_size_t, [_i32, _i32]),
+    "volt_potrf_ws_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
     "volt_trsv_lower_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_t_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
@@ -67,6 +69,8 @@ _TUNE_SIGS = {
     "volt_long_describe": (C.c_int, [_i32, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
     "volt_batch_describe": (C.c_int, [_i32, _i32, _i32, _i32, _ptr, _i32]),
     "volt_tune_batch_stamps": (C.c_int, [_ptr]),
+    "volt_batch64_describe": (C.c_int, [_i32, _i32, _i32, _ptr, _i32]),
+    "volt_tune_batch64_stamps": (C.c_int, [_ptr]),
     "volt_topology_describe": (C.c_int, [_ptr]),
 }
 

@@ -17,8 +17,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libvolt_hip.so")
-SOURCES = ["fill.hip", "ewma.hip", "chol.hip", "one_launch.hip", "batch_step.hip", "chol64.hip", "trsv.hip", "mll.hip", "mll64.hip", "rollout.hip", "gpcv.hip", "adam.hip"]
-HEADERS = ["common.h", "tiles.h", "host.h", "sched.h", "long_sched.h", "batch_sched.h", os.path.join("..", "..", "include", "volt_hip.h"),
+SOURCES = ["fill.hip", "ewma.hip", "chol.hip", "one_launch.hip", "batch_step.hip", "chol64.hip", "batch64_step.hip", "trsv.hip", "mll.hip", "mll64.hip", "rollout.hip", "gpcv.hip", "adam.hip"]
+HEADERS = ["common.h", "tiles.h", "tiles64.h", "host.h", "sched.h", "long_sched.h", "batch_sched.h", os.path.join("..", "..", "include", "volt_hip.h"),
            os.path.join("..", "..", "include", "volt_hip_tune.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
          "-Wno-unused-function"]

@@ -1,0 +1,310 @@
+// The fp64 factorisation (and the triangular inverse of the gradient step) of a SMALL batch in ONE launch (SURVEY 8 row a6 in
+// fp64; round 5).
+//   reference call sites: psd_safe_cholesky at voltron/rollout_utils.py:35 on the noise-free train block (fp64: condition
+//   1e6 .. 1e8), VoltronGP.py:83; a double-precision model's training step (train_utils.py:243-254 in the caller's dtype).
+//
+// chol64.hip walks a block column as three launches on a chain / bulk multi-stream schedule: 130 us per block column of which
+// the diagonal block is 58 -- the rest is launch boundaries and event hand-offs (1 x 4096: 4.1 ms for 32 columns).  Here, as
+// in batch_step.hip for fp32, workgroup w runs piece w of a topologically ordered list and the pieces hand their tiles on
+// through per-matrix progress words, chasing their inputs one 128-wide K block at a time (common.h, Chase):
+//     D(k)      A[k,k] -= L[k,:k] L[k,:k]^T (chasing row k), the result straight into the LDS image of the diagonal block;
+//               factor + inverse (tiles64.h, diag64_body) -> L[k,k], W_k;                    publishes wdone = k + 1
+//     US(i,k)   A[i,k] -= L[i,:k] L[k,:k]^T (chasing rows i and k), then L[i,k] = (.) W_k^T;  publishes rowp[i] = k + 1
+//     TD(i)     Y[i,i] = W_i^T;                                                              publishes tcol[i] = 1
+//     T(i,j)    S = Y[j, j..i) L[i, j..i)^T (chasing tcol[j] and rowp[i]), Y[j,i] = -S W_i^T; publishes tcol[j] = i - j + 1
+// The list needs no table: per block column k it is D(k), US(k+1 .. n-1, k), then row k-1 of the inverse (TD, T longest
+// first), every position for all B matrices with the matrix innermost, and a workgroup finds its piece from blockIdx alone.
+// Workgroups are dispatched in grid order and every piece waits only for pieces listed before it, so whatever a resident
+// workgroup waits for is resident or finished.  The diagonal block's image takes 133 KB of LDS: ONE workgroup per CU, which is
+// also what the latency chain wants (batch_step.hip: a pivot chain that shares its CU runs 2.5 x slower) -- and why this is
+// the schedule of small batches only; from batch64_max tiles per block column on, chol64.hip's bulk kernels (two per CU) win.
+// No atomics: unlike the K-sliced launches of chol64.hip the result is the same from run to run.
+#include "common.h"
+#include "tiles64.h"
+#include "host.h"
+#include "../../include/volt_hip.h"
+#include "../../include/volt_hip_tune.h"
+#include <algorithm>
+
+namespace volt {
+
+// progress words per matrix (ints): rowp[n] | tcol[n] | wdone, padded to a multiple of 32
+static inline int batch64_pstride(int n) { return (2 * n + 1 + 31) & ~31; }
+static inline int64_t batch64_count(int B, int n, bool has_y) {
+    return (int64_t)B * (n + (int64_t)n * (n - 1) / 2 + (has_y ? (int64_t)n * (n + 1) / 2 : 0));
+}
+
+__global__ void batch64_begin_kernel(int* __restrict__ info, int ninfo, int* __restrict__ prog, int nprog) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ninfo) info[i] = 0;
+    for (int c = i; c < nprog; c += gridDim.x * blockDim.x) prog[c] = 0;
+}
+
+enum Piece64Kind { P64_DIAG = 0, P64_PANEL = 1, P64_TRTRI_DIAG = 2, P64_TRTRI = 3 };
+struct Piece64 { int kind, row, col; };
+// position p of a matrix's list (header comment); scalar work, at most n steps
+__device__ __host__ inline Piece64 batch64_piece(int p, int n, bool has_y) {
+    for (int k = 0; k < n; ++k) {
+        if (p == 0) return {P64_DIAG, k, k};
+        p -= 1;
+        if (p < n - k - 1) return {P64_PANEL, k + 1 + p, k};
+        p -= n - k - 1;
+        if (has_y && k >= 1) {
+            if (p == 0) return {P64_TRTRI_DIAG, k - 1, k - 1};
+            p -= 1;
+            if (p < k - 1) return {P64_TRTRI, k - 1, p};
+            p -= k - 1;
+        }
+    }
+    if (p == 0) return {P64_TRTRI_DIAG, n - 1, n - 1};
+    return {P64_TRTRI, n - 1, p - 1};
+}
+
+// the wave's 64x64 of a 128x128 tile of doubles <-> accumulator layout (VOLT_ACC64_RC).  WT: written through at agent scope
+// (sc1) -- a tile handed to workgroups on other XCDs leaves nothing behind in this L2 for a release to write back
+__device__ __forceinline__ void tile64_load(f64x4 (&v)[16], const double* __restrict__ C, int64_t ld) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_ACC64_RC(mt, nt, q)
+                v[mt * 4 + nt][q] = C[(int64_t)r * ld + c];
+            }
+}
+template <bool WT>
+__device__ __forceinline__ void tile64_store(const f64x4 (&v)[16], double* __restrict__ C, int64_t ld, double sign) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_ACC64_RC(mt, nt, q)
+                const double x = sign * v[mt * 4 + nt][q];
+                if constexpr (WT) __hip_atomic_store(&C[(int64_t)r * ld + c], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else C[(int64_t)r * ld + c] = x;
+            }
+}
+
+// tuning only (volt_tune_batch64_stamps): 8 int64 per workgroup -- s_memrealtime at entry [0] and exit [1], hardware id [2],
+// behind the chased product [3], behind the wait for W [4], behind the second product [5]
+static long long* g_batch64_stamps = nullptr;
+
+// LOCAL: the batch is a multiple of 8 -- every piece of a matrix runs on ONE XCD (workgroup w on XCD w % 8, matrix w % B) and
+// that XCD's L2 is where its tiles are handed on: plain stores and a drain, no fences (common.h, LOCALP).
+template <bool LOCAL>
+__global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ A, double* __restrict__ Winv,
+                                                           double* __restrict__ Y, int* __restrict__ info, int Np, int B,
+                                                           int* __restrict__ prog, int pstride,
+                                                           long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) double sT[];
+    float* smem = reinterpret_cast<float*>(sT);
+    const int n = Np / TS, b = blockIdx.x % B;
+    const Piece64 pc = batch64_piece(blockIdx.x / B, n, Y != nullptr);
+#define VOLT_B64_STAMP(i) \
+    do { if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    VOLT_B64_STAMP(0);
+    if (stamps && threadIdx.x == 0)
+        stamps[(int64_t)blockIdx.x * 8 + 2] = ((long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |
+                                              (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+    struct Exit {
+        long long* st;
+        __device__ ~Exit() { if (st && threadIdx.x == 0) st[(int64_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
+    } exit_stamp{stamps};
+    int* rowp = prog + (int64_t)b * pstride;
+    int* tcol = rowp + n;
+    int* wdone = tcol + n;
+    int* info_b = info + b;
+    double* Ab = A + (int64_t)b * Np * Np;
+    double* Wb = Winv + (int64_t)b * n * TS * TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int CPB = TS / BK64;
+    bool ok = true;
+
+    if (pc.kind == P64_DIAG) {
+        const int k = pc.row;
+        if (k > 0) {
+            // the tile's own input first (it is there from the start), then the chased sum over row k
+            const double* C = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
+            f64x4 cv[16];
+            tile64_load(cv, C, Np);
+            Chase ch;
+            ch.p0 = ch.p1 = rowp + k;
+            f64x4 acc[16];
+            zero_acc64(acc);
+            const double* Lk = Ab + (int64_t)k * TS * Np;
+            gemm64_nt_128<true, LOCAL>(Lk, Np, Lk, Np, k * CPB, acc, smem, &ch, &ok);
+            VOLT_B64_STAMP(3);
+            // the lower triangle of the updated block into the image, zeros above (the staging buffers are free: the loop
+            // ends with a barrier)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        VOLT_ACC64_RC(mt, nt, q)
+                        sT[r * DT64 + c] = (c <= r) ? cv[mt * 4 + nt][q] - acc[mt * 4 + nt][q] : 0.0;
+                    }
+            if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
+        }
+        diag64_body<false>(A, Winv, info, Np, k, b, sT, nullptr, k > 0);
+        batch_publish_release<LOCAL>(wdone, k + 1);
+        return;
+    }
+    if (pc.kind == P64_TRTRI_DIAG) {
+        const int i = pc.row;
+        batch_wait<LOCAL>(wdone, i + 1, nullptr, 0, info_b);
+        trtri64_diag_body(Wb + (int64_t)i * TS * TS, Y + (int64_t)b * Np * Np + (int64_t)i * TS * Np + (int64_t)i * TS, Np, smem);
+        batch_publish_release<LOCAL>(tcol + i, 1);
+        return;
+    }
+    // ---- the two-product tiles: a chased sum, then the product with a diagonal block's inverse
+    const double *X, *Z, *W;
+    double *mid, *out;                      // where the sum waits for W (read back by this workgroup alone), and the result
+    const double* cin = nullptr;            // the tile the sum is subtracted from (panel tiles)
+    Chase ch;
+    int nblk, wneed, *word, val;
+    double sign;
+    if (pc.kind == P64_PANEL) {
+        const int i = pc.row, k = pc.col;
+        X = Ab + (int64_t)i * TS * Np;
+        Z = Ab + (int64_t)k * TS * Np;
+        ch.p0 = rowp + i;
+        ch.p1 = rowp + k;
+        nblk = k;
+        W = Wb + (int64_t)k * TS * TS;
+        wneed = k + 1;
+        mid = out = Ab + (int64_t)i * TS * Np + (int64_t)k * TS;
+        cin = mid;
+        word = rowp + i;
+        val = k + 1;
+        sign = 1.0;
+    } else {
+        const int i = pc.row, j = pc.col;
+        double* Yb = Y + (int64_t)b * Np * Np;
+        X = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;         // tiles (j, j .. i-1) of the inverse: tcol[j] of them are there
+        Z = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;         // L[i, j .. i-1]: block m is there once rowp[i] >= j + m + 1
+        ch.p0 = tcol + j;
+        ch.p1 = rowp + i;
+        ch.base1 = j;
+        nblk = i - j;
+        W = Wb + (int64_t)i * TS * TS;
+        wneed = i + 1;
+        mid = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;       // the unused slot below the diagonal
+        out = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
+        word = tcol + j;
+        val = i - j + 1;
+        sign = -1.0;
+    }
+    if (nblk > 0) {
+        f64x4 cv[16];
+        if (cin) tile64_load(cv, cin, Np);
+        f64x4 acc[16];
+        zero_acc64(acc);
+        gemm64_nt_128<true, LOCAL>(X, Np, Z, Np, nblk * CPB, acc, smem, &ch, &ok);
+        if (cin) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[t][q] = cv[t][q] - acc[t][q];
+        }
+        tile64_store<false>(acc, mid, Np, 1.0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the barrier of the wait below covers the workgroup)
+    }
+    VOLT_B64_STAMP(3);
+    batch_wait<LOCAL>(wdone, wneed, nullptr, 0, info_b);
+    VOLT_B64_STAMP(4);
+    {
+        f64x4 acc[16];
+        zero_acc64(acc);
+        gemm64_nt_128(mid, Np, W, TS, CPB, acc, smem);      // (all of `mid` is read before the loop's closing barrier)
+        VOLT_B64_STAMP(5);
+        if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
+        tile64_store<!LOCAL>(acc, out, Np, sign);
+    }
+    batch_publish_wt<LOCAL>(word, val);
+#undef VOLT_B64_STAMP
+}
+
+}  // namespace volt
+
+using namespace volt;
+
+// Where the one launch replaces chol64.hip's schedules: small batches of long series (one workgroup per CU; measured
+// crossovers in host.h).  (B, n) only, like every gate.
+bool volt_internal_batch64_applies(int B, int n) {
+    const Tunables& tn = tunables();
+    if (tn.batch64 <= 0 || B < 1 || n < 2 || B > 65535) return false;
+    if (tn.batch64 >= 2) return true;
+    return n >= 4 && (int64_t)B * (n + 1) <= tn.batch64_max;
+}
+
+size_t volt_internal_batch64_bytes(int B, int n) {
+    if (!volt_internal_batch64_applies(B, n)) return 0;
+    return ((size_t)B * batch64_pstride(n) * sizeof(int) + 255) & ~(size_t)255;
+}
+
+// Returns 1 when the step was enqueued, 0 when the shape is not this schedule's (nothing enqueued), a HIP error otherwise.
+int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
+                               void* stream) {
+    const int n = Np / TS;
+    if (!state || !volt_internal_batch64_applies(B, n) || state_bytes < volt_internal_batch64_bytes(B, n)) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int* prog = reinterpret_cast<int*>(state);
+    const int pstride = batch64_pstride(n), nprog = B * pstride;
+    int blocks = (std::max(B, nprog) + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks * 256 < B) blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(batch64_begin_kernel, dim3(blocks), dim3(256), 0, s, info, B, prog, nprog);
+    const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;
+    const unsigned grid = (unsigned)batch64_count(B, n, Y != nullptr);
+    hipError_t e;
+    if (local) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, Y, info, Np, B, prog,
+                           pstride, g_batch64_stamps);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, Y, info, Np, B, prog,
+                           pstride, g_batch64_stamps);
+    }
+    e = hipGetLastError();
+    return e != hipSuccess ? (int)e : 1;
+}
+
+extern "C" {
+
+int volt_tune_batch64_stamps(long long* stamps) {
+    g_batch64_stamps = stamps;
+    return 0;
+}
+
+// Host only (no GPU): the piece list of the fp64 one-launch step, in grid order -- items [max_items][4] int32
+// {kind, row, col, matrix} (kinds: 0 D, 1 US, 2 TD, 3 T).  Returns the number of pieces, -1 bad argument, -2 max_items too small.
+int volt_batch64_describe(int B, int n, int has_y, int* items, int max_items) {
+    if (B < 1 || n < 1) return -1;
+    const int64_t cnt = batch64_count(B, n, has_y != 0);
+    if (cnt > 0x7fffffff) return -1;
+    if (items) {
+        if (cnt > max_items) return -2;
+        for (int64_t w = 0; w < cnt; ++w) {
+            const Piece64 pc = batch64_piece((int)(w / B), n, has_y != 0);
+            items[4 * w] = pc.kind;
+            items[4 * w + 1] = pc.row;
+            items[4 * w + 2] = pc.col;
+            items[4 * w + 3] = (int)(w % B);
+        }
+    }
+    return (int)cnt;
+}
+
+}  // extern "C"

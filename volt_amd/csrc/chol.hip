@@ -465,6 +465,8 @@ static Tunables read_env(Tunables t) {                       // VOLT_TUNE=1 proc
         geti("VOLT_BATCH_LOCAL", t.batch_local);
         geti("VOLT_BATCH_SPREAD", t.batch_spread);
         geti("VOLT_BATCH_LAD", t.batch_lad);
+        geti("VOLT_BATCH64", t.batch64);
+        geti("VOLT_BATCH64_MAX", t.batch64_max);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         geti("VOLT_FAKE_CUS", t.cus);                        // tests: plan as if the device had this many CUs / XCDs
         geti("VOLT_FAKE_XCCS", t.xccs);
@@ -496,6 +498,7 @@ static void apply_topology(Tunables& t, bool faked) {
     t.small_nmax = 0;                                        // the one-launch steps: tuned for, and (batched step) placed on, the full chip
     t.long_on = 0;
     t.batch = 0;
+    t.batch64 = 0;
 }
 
 const Tunables& tunables() {

@@ -16,6 +16,7 @@
 // Used where fp32 cannot carry the conditioning: the rollouts' train-block factor and its rho / tau
 // (volt_amd/rollout_engine.py), and gp.psd_safe_cholesky on fp64 input.
 #include "common.h"
+#include "tiles64.h"
 #include "host.h"
 #include "../../include/volt_hip.h"
 #include "../../include/volt_hip_tune.h"
@@ -24,114 +25,6 @@
 
 namespace volt {
 
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-
-constexpr int SLD64 = SLD / 2;          // 18 doubles per LDS row
-constexpr int BK64 = BK / 2;            // 16 doubles of K per chunk
-
-// Fragments of one K step (4 doubles of K) of the staged chunk: lane l supplies A[row = l & 15][k = l >> 4] and
-// B[col = l & 15][k = l >> 4] for the four 16-row / 16-column blocks of the wave's 64x64.
-struct Frag64 { double a[4], b[4]; };
-__device__ __forceinline__ void frag64_load(Frag64& f, const float* __restrict__ buf, int kk) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int l15 = lane & 15, lk = lane >> 4;
-    const int wr = wave >> 1, wc = wave & 1;
-    const double* sA = reinterpret_cast<const double*>(buf);
-    const double* sB = reinterpret_cast<const double*>(buf + TS * SLD);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        f.a[t] = sA[(wr * 64 + t * 16 + l15) * SLD64 + kk * 4 + lk];
-        f.b[t] = sB[(wc * 64 + t * 16 + l15) * SLD64 + kk * 4 + lk];
-    }
-}
-// accumulator register q of lane l of block (mt, nt) is element (row = 16 mt + (l >> 4) + 4 q, col = 16 nt + (l & 15))
-__device__ __forceinline__ void frag64_mma_row(const Frag64& f, int mt, f64x4 (&acc)[16]) {
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-        acc[mt * 4 + nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[mt], f.b[nt], acc[mt * 4 + nt], 0, 0, 0);
-}
-__device__ __forceinline__ void frag64_mma(const Frag64& f, f64x4 (&acc)[16]) {
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) frag64_mma_row(f, mt, acc);
-}
-
-// One chunk (4 K steps of 4 doubles) of the fp64 K loop, same shape as chunk_run (common.h): fragments
-// double-buffered in registers, the order pinned, staging two instructions at a time between groups of four MFMAs.
-template <bool STEADY>
-__device__ __forceinline__ void chunk64_run(const float* cur, float* nxt, bool more_, Frag64& F0, Frag64& F1, f64x4 (&acc)[16],
-                                            StageRegs& s, bool do_st_, bool do_ld_, const StageAddr& sa, int k_ld) {
-    const bool more = STEADY || more_, do_st = STEADY || do_st_, do_ld = STEADY || do_ld_;
-    frag64_load(F1, cur, 1);
-    VOLT_SB();
-    frag64_mma(F0, acc);
-    VOLT_SB();
-    frag64_load(F0, cur, 2);
-    VOLT_SB();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        frag64_mma_row(F1, m, acc);
-        if (do_st) stage_store_piece(s, nxt, m);
-        VOLT_SB();
-    }
-    frag64_load(F1, cur, 3);
-    VOLT_SB();
-    const int so = __builtin_amdgcn_readfirstlane(k_ld * 4);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        frag64_mma_row(F0, m, acc);
-        if (do_ld) stage_load_piece(s, sa, so, m);
-        VOLT_SB();
-    }
-    __syncthreads();
-    if (more) frag64_load(F0, nxt, 0);
-    VOLT_SB();
-    frag64_mma(F1, acc);
-    VOLT_SB();
-}
-
-// acc += A[0:128, 0:16 nchunks] * B[0:128, 0:16 nchunks]^T (doubles; lda / ldb in doubles).  The software pipeline of
-// gemm_nt_128 on the float view of the operands: loads two chunks ahead, double-buffered LDS, one barrier per chunk.
-__device__ __forceinline__ void gemm64_nt_128(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
-                                              int64_t ldb, int nchunks, f64x4 (&acc)[16], float* smem) {
-    if (nchunks <= 0) return;
-    // ONE staging register set, loads one chunk ahead: with two sets (two chunks ahead, as the fp32 loop has it) a wave
-    // needs 242 + 128 registers and a SIMD holds one wave -- nothing covers its barrier and LDS waits, and the 128x128 fp64
-    // core stops at 57 TF/s (74 % of the 77 TF/s the MFMA pipe issues, scripts/ubench/mfma64.hip).  One set fits two.
-    StageRegs s0;
-    const StageAddr sa = stage_addr(reinterpret_cast<const float*>(A), 2 * lda, reinterpret_cast<const float*>(B), 2 * ldb);
-    stage_load_buf(s0, sa, 0);
-    stage_store(s0, smem);
-    if (nchunks > 1) stage_load_buf(s0, sa, BK);
-    __syncthreads();
-    Frag64 F0, F1;
-    frag64_load(F0, smem, 0);
-    float* b0 = smem;
-    float* b1 = smem + STAGE_FLOATS;
-    int c = 0;
-    for (; c + 3 < nchunks; c += 2) {
-        chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 2) * BK);
-        chunk64_run<true>(b1, b0, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
-    }
-    for (; c + 1 < nchunks; c += 2) {
-        chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 2 < nchunks, sa, (c + 2) * BK);
-        chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s0, c + 2 < nchunks, c + 3 < nchunks, sa, (c + 3) * BK);
-    }
-    if (c < nchunks) chunk64_run<false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
-    __syncthreads();
-}
-
-__device__ __forceinline__ void zero_acc64(f64x4 (&acc)[16]) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[i][q] = 0.0;
-}
-
-// (row, col) inside the 128x128 tile of accumulator register q of block (mt, nt) for this lane
-#define VOLT_ACC64_RC(mt, nt, q)                                              \
-    const int r = (wave >> 1) * 64 + (mt) * 16 + (lane >> 4) + 4 * (q);       \
-    const int c = (wave & 1) * 64 + (nt) * 16 + (lane & 15);
 
 // ----------------------------------------------------------------------------- prepare
 // A = tril-tiles(K) + (sigma2 + jitter) I, identity in the padding; tile (ti, tj), tj <= ti.
@@ -221,369 +114,12 @@ __global__ __launch_bounds__(256, 2) void trsm64_kernel(double* __restrict__ A, 
             }
 }
 
-// ----------------------------------------------------------------------------- P2
-// One workgroup per matrix factors the 128x128 diagonal block and inverts it, blocked by 32 in an LDS image (row
-// stride 129 doubles) -- the structure of the fp32 diag_body (chol.hip):
-//   chol32   the 32x32 diagonal sub-block, all 256 threads: thread (ty, tx) keeps the 2x2 cyclic elements
-//            (ty + 16 a, tx + 16 c) in registers; per pivot the owners publish the still unscaled column to a
-//            double-buffered LDS vector (ONE barrier per pivot), everyone applies a_rc -= a_rj a_cj / d_j
-//   inv32    X = L_kk^-1 by forward substitution, one column per lane of one wave, fully unrolled; X replaces L_kk
-//            in the image (the panel solve, the trailing updates and the blocked inverse only ever need X)
-//   panel    L[i,kb] = A[i,kb] X_kb^T and trailing updates A[i,j] -= L[i,kb] L[j,kb]^T: 32x32x32 products on
-//            v_mfma_f64_16x16x4_f64 straight from the image, one wave per block
-//   W = L^-1 blocked: W[i,j] = -X_i sum_{m=j}^{i-1} L[i,m] W[m,j], wave j owns block column j; the W[m,j] it
-//            produced stay in its accumulators and are fed back as MFMA B operands FROM REGISTERS (accumulator
-//            register q of lane l holds row (l >> 4) + 4 q of a 16-row tile: exactly the k index step q wants from
-//            that lane)
-// Round-2 first version (unblocked LDS loops): 650 us per block; this one: see DESIGN 4.8.
-constexpr int DT64 = TS + 1;
-constexpr int DIAG64_LDS_BYTES = (TS * DT64 + 128 + 32) * 8;
-
-// acc[tr*2+tc] (16x16 tile at rows 16 tr, cols 16 tc of a 32x32 block) += sign * A[32x32] * B[32x32]^T, A and B row-major
-// blocks of the image:  C[r][c] = sum_p A[r][p] B[c][p]
-template <bool NEG>
-__device__ __forceinline__ void mm64_nt(f64x4 (&acc)[4], const double* __restrict__ A, const double* __restrict__ B) {
-    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        double a[2], b[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            a[t] = A[(t * 16 + l15) * DT64 + 4 * st + lk];
-            b[t] = B[(t * 16 + l15) * DT64 + 4 * st + lk];
-            if (NEG) a[t] = -a[t];
-        }
-#pragma unroll
-        for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-            for (int tc = 0; tc < 2; ++tc)
-                acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], b[tc], acc[tr * 2 + tc], 0, 0, 0);
-    }
-}
-// acc += A[32x32] (image block, row-major) * Breg, Breg = a 32x32 block held as 4 accumulator tiles [tp*2+tc]
-__device__ __forceinline__ void mm64_lds_reg(f64x4 (&acc)[4], const double* __restrict__ A, const f64x4 (&Breg)[4]) {
-    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double a[2];
-#pragma unroll
-            for (int tr = 0; tr < 2; ++tr) a[tr] = A[(tr * 16 + l15) * DT64 + tp * 16 + 4 * q + lk];
-#pragma unroll
-            for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-                for (int tc = 0; tc < 2; ++tc)
-                    acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], Breg[tp * 2 + tc][q], acc[tr * 2 + tc], 0, 0, 0);
-        }
-}
-// acc += A[32x32] * B[32x32] (both image blocks, row-major):  C[r][c] = sum_p A[r][p] B[p][c]
-__device__ __forceinline__ void mm64_nn(f64x4 (&acc)[4], const double* __restrict__ A, const double* __restrict__ B) {
-    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        double a[2], b[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            a[t] = A[(t * 16 + l15) * DT64 + 4 * st + lk];
-            b[t] = B[(4 * st + lk) * DT64 + t * 16 + l15];
-        }
-#pragma unroll
-        for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-            for (int tc = 0; tc < 2; ++tc)
-                acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], b[tc], acc[tr * 2 + tc], 0, 0, 0);
-    }
-}
-__device__ __forceinline__ void acc64_zero(f64x4 (&acc)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[t][q] = 0.0;
-}
-// element (r, c) of accumulator register q of tile (tr, tc) inside a 32x32 block
-#define VOLT_BLK64_RC(tr, tc, q)                                  \
-    const int r = (tr) * 16 + ((threadIdx.x & 63) >> 4) + 4 * (q); \
-    const int c = (tc) * 16 + (threadIdx.x & 15);
-__device__ __forceinline__ void acc64_load(f64x4 (&acc)[4], const double* __restrict__ C) {
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                VOLT_BLK64_RC(tr, tc, q)
-                acc[tr * 2 + tc][q] = C[r * DT64 + c];
-            }
-}
-__device__ __forceinline__ void acc64_store(const f64x4 (&acc)[4], double* __restrict__ C, double sign) {
-#pragma unroll
-    for (int tr = 0; tr < 2; ++tr)
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                VOLT_BLK64_RC(tr, tc, q)
-                C[r * DT64 + c] = sign * acc[tr * 2 + tc][q];
-            }
-}
-
-// broadcast of a double from one lane: two v_readlane_b32 into an SGPR pair (no LDS round trip, no barrier)
-__device__ __forceinline__ double rl64(double v, int src) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, src);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// c_i = fma(-l, broadcast(l, lane_i), c_i): the SGPR broadcasts (two v_readlane_b32 per double, into FIXED SGPR pairs
-// s[90:95], declared clobbered) and their FMAs pinned together in one asm block.  Left to the compiler every broadcast
-// of a pivot is hoisted to the top and spilled lane by lane through v_writelane (the fp32 block has the same story,
-// chol.hip rl_fma3); a VALU may read a readlane's SGPR two wait states after it -- groups of three cover each other,
-// shorter ones pad with s_nop.
-__device__ __forceinline__ void rl_fma64_3(double& c0, double& c1, double& c2, double l, int lo, int hi, int l0, int l1, int l2) {
-    asm volatile("v_readlane_b32 s90, %4, %6\n\tv_readlane_b32 s91, %5, %6\n\t"
-                 "v_readlane_b32 s92, %4, %7\n\tv_readlane_b32 s93, %5, %7\n\t"
-                 "v_readlane_b32 s94, %4, %8\n\tv_readlane_b32 s95, %5, %8\n\t"
-                 "v_fma_f64 %0, -%3, s[90:91], %0\n\tv_fma_f64 %1, -%3, s[92:93], %1\n\tv_fma_f64 %2, -%3, s[94:95], %2"
-                 : "+v"(c0), "+v"(c1), "+v"(c2)
-                 : "v"(l), "v"(lo), "v"(hi), "i"(l0), "i"(l1), "i"(l2)
-                 : "s90", "s91", "s92", "s93", "s94", "s95");
-}
-__device__ __forceinline__ void rl_fma64_2(double& c0, double& c1, double l, int lo, int hi, int l0, int l1) {
-    asm volatile("v_readlane_b32 s90, %3, %5\n\tv_readlane_b32 s91, %4, %5\n\t"
-                 "v_readlane_b32 s92, %3, %6\n\tv_readlane_b32 s93, %4, %6\n\t"
-                 "v_fma_f64 %0, -%2, s[90:91], %0\n\ts_nop 0\n\tv_fma_f64 %1, -%2, s[92:93], %1"
-                 : "+v"(c0), "+v"(c1)
-                 : "v"(l), "v"(lo), "v"(hi), "i"(l0), "i"(l1)
-                 : "s90", "s91", "s92", "s93");
-}
-__device__ __forceinline__ void rl_fma64_1(double& c0, double l, int lo, int hi, int l0) {
-    asm volatile("v_readlane_b32 s90, %2, %4\n\tv_readlane_b32 s91, %3, %4\n\ts_nop 1\n\t"
-                 "v_fma_f64 %0, -%1, s[90:91], %0"
-                 : "+v"(c0)
-                 : "v"(l), "v"(lo), "v"(hi), "i"(l0)
-                 : "s90", "s91");
-}
-
-// One WAVE factors the 32x32 diagonal sub-block (kb,kb) with one matrix row per lane in registers -- the idiom of the
-// fp32 diagonal block (chol.hip): per pivot the pivot and the column entries travel by v_readlane (SGPR broadcast),
-// so the 32 dependent pivots cost no barrier and no LDS round trip.  Lanes 0..31 hold the rows of the diagonal
-// sub-block; lanes 32..63 the rows of the panel block (prow,kb) below it, which the very same instructions turn into
-// L[prow,kb] = A[prow,kb] L_kk^-T -- no inverse is needed on the way down.  Several waves run this side by side, each
-// with its own copy of the (tiny) diagonal factorisation and its own panel block; the one with `own` writes L_kk and
-// the reciprocal pivots back.  (The first version -- 256 threads, 2x2 cyclic elements each, one barrier per pivot --
-// took 19.7 us per sub-block, 79 of the kernel's 139 us: scripts/tune_diag64.py.)
-__device__ __forceinline__ void pivot_phase64(double* __restrict__ sT, double* __restrict__ rdiag, int kb, int prow, bool own,
-                                              int& bad) {
-    const int lane = threadIdx.x & 63, l31 = lane & 31;
-    const bool up = lane >= 32;
-    double* rowp = up ? sT + (32 * (prow < 0 ? kb : prow) + l31) * DT64 + 32 * kb : sT + (32 * kb + l31) * DT64 + 32 * kb;
-    const bool live = !up || prow >= 0;
-    double a[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) a[c] = live ? rowp[c] : 0.0;
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-        const double d = rl64(a[j], j);                             // pivot: row j of the diagonal half
-        if (!(d > 0.0) && bad == 0) bad = 32 * kb + j + 1;          // wave-uniform
-        double rs = __builtin_amdgcn_rsq(d);                        // 1/sqrt(d): v_rsq_f64 + two Newton steps
-        rs = rs * (1.5 - 0.5 * d * rs * rs);
-        rs = rs * (1.5 - 0.5 * d * rs * rs);
-        const double l = a[j] * rs;                                 // lane r: L[r][j]  (lane j: d rs = sqrt d)
-        a[j] = l;
-        if (own && lane == 0) rdiag[32 * kb + j] = rs;              // 1 / L[j][j] for the inverse
-        // a[r][c] -= L[r][j] L[c][j] for c > j, L[c][j] broadcast from lane c of the diagonal half
-        double lv = l;
-        asm volatile("s_nop 0" : "+v"(lv));                         // a VALU result needs a wait state before v_readlane reads it
-        const unsigned long long lu = __builtin_bit_cast(unsigned long long, lv);
-        const int llo = (int)(unsigned)lu, lhi = (int)(unsigned)(lu >> 32);
-        int c = j + 1;
-#pragma unroll
-        for (; c + 2 < 32; c += 3) rl_fma64_3(a[c], a[c + 1], a[c + 2], lv, llo, lhi, c, c + 1, c + 2);
-        if (c + 1 < 32) rl_fma64_2(a[c], a[c + 1], lv, llo, lhi, c, c + 1);
-        else if (c < 32) rl_fma64_1(a[c], lv, llo, lhi, c);
-    }
-    if (up) {
-        if (prow >= 0) {
-#pragma unroll
-            for (int c = 0; c < 32; ++c) rowp[c] = a[c];
-        }
-    } else if (own) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) rowp[c] = (c <= l31) ? a[c] : 0.0;
-    }
-}
-
-// X = L^-1 for the 32x32 lower block at (32 kb, 32 kb), by lanes 0..31 of ONE wave (one column each, registers);
-// X replaces L in the image.  rdiag holds the reciprocal pivots.  Call with the block complete in LDS; ends WITHOUT a barrier.
-__device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double* __restrict__ rdiag, int kb) {
-    double* D = sT + (32 * kb) * DT64 + 32 * kb;
-    const int c = threadIdx.x & 63;
-    if (c < 32) {
-        double x[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            double acc = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < r; ++m) acc -= D[r * DT64 + m] * x[m];      // x[m] == 0 for m < c
-            x[r] = acc * rdiag[32 * kb + r];
-        }
-        // every lane has read all of L it needs (its own column's rows >= c only use L, never X): write after a wave barrier
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 32; ++r) D[r * DT64 + c] = x[r];
-    }
-}
-
-#define VOLT_STAMP64(i)                                                                \
-    do {                                                                               \
-        if (STAMP && threadIdx.x == 0) stamps[32 * blockIdx.x + (i)] = __builtin_amdgcn_s_memtime();   \
-    } while (0)
+// ----------------------------------------------------------------------------- P2 (tiles64.h: diag64_body)
 template <bool STAMP>
 __global__ __launch_bounds__(256) void diag64_kernel(double* __restrict__ A, double* __restrict__ Winv,
                                                      int* __restrict__ info, int Np, int k, long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) double sT[];
-    VOLT_STAMP64(0);
-    double* colbuf = sT + TS * DT64;       // 128 doubles: the reciprocal pivots
-    const int n = Np / TS, b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
-    double* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
-    double* W = Winv + ((int64_t)b * n + k) * TS * TS;
-    {   // lower triangle in, 8 x 16-byte loads per thread in flight (one load per iteration cost 7 us of latency)
-        constexpr int PER = TS * TS / 2 / NT;                     // 32 double pairs per thread
-#pragma unroll
-        for (int it0 = 0; it0 < PER; it0 += 8) {
-            f64x2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
-                v[u] = f64x2{0.0, 0.0};
-                if (c <= r) v[u] = *reinterpret_cast<const f64x2*>(D + (int64_t)r * Np + c);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
-                sT[r * DT64 + c] = v[u][0];
-                sT[r * DT64 + c + 1] = (c + 1 <= r) ? v[u][1] : 0.0;
-            }
-        }
-    }
-    __syncthreads();
-    VOLT_STAMP64(1);
-    int bad = 0;
-    double* rdiag = colbuf;                // 128 reciprocal pivots
-    // Sub-block column kb: pivot waves w < max(1, 3 - kb) factor (kb,kb) with the panel block (kb+1+w, kb) riding along;
-    // a wave that has no panel block left inverts the previous diagonal sub-block meanwhile (X_kb is only needed for W).
-    for (int kb = 0; kb < 4; ++kb) {
-        const int npw = kb < 3 ? 3 - kb : 1;
-        if (wave < npw) {
-            pivot_phase64(sT, rdiag, kb, kb + 1 + wave <= 3 ? kb + 1 + wave : -1, wave == 0, bad);
-        } else if (kb >= 1 && wave == 3) {
-            inv32_f64(sT, rdiag, kb - 1);
-        }
-        __syncthreads();
-        VOLT_STAMP64(2 + 4 * kb);
-        // L_kk out (zeros above the diagonal)
-        for (int e = tid; e < 32 * 32; e += NT) {
-            const int r = e >> 5, c = e & 31;
-            D[(int64_t)(32 * kb + r) * Np + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
-        }
-        VOLT_STAMP64(3 + 4 * kb);
-        if (kb == 3) break;
-        // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to the 4 waves
-        int cnt = 0;
-        for (int i = kb + 1; i <= 3; ++i)
-            for (int j = kb + 1; j <= i; ++j) {
-                if (wave == (cnt++ & 3)) {
-                    double* C = sT + (32 * i) * DT64 + 32 * j;
-                    f64x4 acc[4];
-                    acc64_load(acc, C);
-                    mm64_nt<true>(acc, sT + (32 * i) * DT64 + 32 * kb, sT + (32 * j) * DT64 + 32 * kb);
-                    acc64_store(acc, C, 1.0);
-                }
-            }
-        __syncthreads();
-        VOLT_STAMP64(5 + 4 * kb);
-    }
-    __syncthreads();                       // the L_33 store above reads the image
-    if (wave == 3) inv32_f64(sT, rdiag, 3);
-    __syncthreads();
-    // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal: 16-byte stores, the
-    // LDS reads of 8 of them in flight at a time
-    {
-        constexpr int PER = TS * TS / 2 / NT;
-#pragma unroll
-        for (int it0 = 0; it0 < PER; it0 += 8) {
-            f64x2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
-                v[u][0] = (c < r) ? sT[r * DT64 + c] : 0.0;
-                v[u][1] = (c + 1 < r) ? sT[r * DT64 + c + 1] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
-                if ((r >> 5) != (c >> 5)) *reinterpret_cast<f64x2*>(D + (int64_t)r * Np + c) = v[u];
-            }
-        }
-    }
-    VOLT_STAMP64(18);
-    // ---- W = L^-1, blocked by 32: wave j < 3 owns block column j (the diagonal blocks of W are the X_kb in place)
-    f64x4 Wr[3][4];
-    if (wave < 3) {
-        const int j = wave;
-#pragma unroll
-        for (int di = 1; di <= 3; ++di) {
-            const int i = j + di;
-            if (i <= 3) {                                                     // wave-uniform
-                f64x4 S[4];
-                acc64_zero(S);
-                mm64_nn(S, sT + (32 * i) * DT64 + 32 * j, sT + (32 * j) * DT64 + 32 * j);            // L[i,j] X_j
-#pragma unroll
-                for (int dm = 1; dm < di; ++dm)
-                    mm64_lds_reg(S, sT + (32 * i) * DT64 + 32 * (j + dm), Wr[dm - 1]);              // L[i,m] W[m,j]
-                f64x4 R[4];
-                acc64_zero(R);
-                mm64_lds_reg(R, sT + (32 * i) * DT64 + 32 * i, S);                                   // X_i S
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Wr[di - 1][t][q] = -R[t][q];
-            }
-        }
-    }
-    __syncthreads();                                                          // every L block has been consumed
-    VOLT_STAMP64(19);
-    if (wave < 3) {
-        const int j = wave;
-#pragma unroll
-        for (int di = 1; di <= 3; ++di) {
-            const int i = j + di;
-            if (i <= 3) acc64_store(Wr[di - 1], sT + (32 * i) * DT64 + 32 * j, 1.0);
-        }
-    }
-    __syncthreads();
-    {
-        constexpr int PER = TS * TS / 2 / NT;
-#pragma unroll
-        for (int it0 = 0; it0 < PER; it0 += 8) {
-            f64x2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
-                v[u][0] = (c <= r) ? sT[r * DT64 + c] : 0.0;
-                v[u][1] = (c + 1 <= r) ? sT[r * DT64 + c + 1] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = tid + (it0 + u) * NT, r = e >> 6, c = (e & 63) * 2;
-                *reinterpret_cast<f64x2*>(W + r * TS + c) = v[u];
-            }
-        }
-    }
-    if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
-    VOLT_STAMP64(20);
+    diag64_body<STAMP>(A, Winv, info, Np, k, blockIdx.x, sT, stamps, false);
 }
 
 // ----------------------------------------------------------------------------- trtri (fp64)
@@ -656,20 +192,7 @@ __global__ __launch_bounds__(256, 2) void trtri64_p2_kernel(const double* __rest
     double* Yb = Y + (int64_t)b * Np * Np;
     const double* W = Winv + ((int64_t)b * n + i) * TS * TS;
     if (j == i) {
-        double* sW = reinterpret_cast<double*>(smem);              // 64 x 129 doubles at a time (66 KB)
-        double* Yd = Yb + (int64_t)i * TS * Np + (int64_t)i * TS;
-        for (int half = 0; half < 2; ++half) {
-            __syncthreads();
-            for (int e = threadIdx.x; e < 64 * TS; e += NT) {
-                const int r = e >> 7, c = e & 127;                 // W row 64 half + r, column c
-                sW[r * (TS + 1) + c] = W[(int64_t)(64 * half + r) * TS + c];
-            }
-            __syncthreads();
-            for (int e = threadIdx.x; e < TS * 64; e += NT) {
-                const int c = e >> 6, r = e & 63;                  // Y row c, column 64 half + r
-                Yd[(int64_t)c * Np + 64 * half + r] = (64 * half + r >= c) ? sW[r * (TS + 1) + c] : 0.0;
-            }
-        }
+        trtri64_diag_body(W, Yb + (int64_t)i * TS * Np + (int64_t)i * TS, Np, smem);
         return;
     }
     const double* S = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;
@@ -771,7 +294,13 @@ static void trtri64_finish(const double* A, const double* Winv, double* Y, int B
 
 // Factorisation (+ optional triangular inverse Y = L^-T, row k-1 riding on a THIRD stream beside block column k: at
 // small batches the latency chain of the factorisation leaves most CUs idle, and the inverse fills them).
-int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream);
+int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream, void* state = nullptr,
+                             size_t state_bytes = 0);
+// batch64_step.hip: the one-launch schedule of small batches (state: the progress words, caller scratch)
+bool volt_internal_batch64_applies(int B, int n);
+size_t volt_internal_batch64_bytes(int B, int n);
+int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
+                               void* stream);
 
 extern "C" {
 
@@ -850,9 +379,20 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
     return volt_internal_factor_f64(A, Winv, info, nullptr, B, Np, stream);
 }
 
+size_t volt_potrf_workspace_bytes_f64(int B, int Np) {
+    if (B <= 0 || Np < TS || Np % TS) return 0;
+    return volt_internal_batch64_bytes(B, Np / TS);
+}
+
+int volt_potrf_ws_f64(double* A, double* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {
+    if (ws && ((uintptr_t)ws & 255)) return -6;
+    return volt_internal_factor_f64(A, Winv, info, nullptr, B, Np, stream, ws, ws_bytes);
+}
+
 }  // extern "C"
 
-int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream) {
+int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream, void* state,
+                             size_t state_bytes) {
     if (!A) return -1;
     if (!Winv) return -2;
     if (!info) return -3;
@@ -861,6 +401,10 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
     if (B == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const int n = Np / TS;
+    if (state) {                                                      // a small batch: the whole schedule as one launch
+        const int rc = volt_internal_batch64_step(A, Winv, info, Y, B, Np, state, state_bytes, stream);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
     hipError_t e = hipMemsetAsync(info, 0, sizeof(int) * (size_t)B, s);
     if (e != hipSuccess) return (int)e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(diag64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,

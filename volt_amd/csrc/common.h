@@ -760,4 +760,58 @@ __device__ __forceinline__ void rowpair_dot(const f32x4& y, const f32x4& z, floa
     hi = __int_as_float(__builtin_amdgcn_readlane(pi, 32)) + __int_as_float(__builtin_amdgcn_readlane(pi, 48));
 }
 
+// ---- hand-offs of the one-launch batched steps (batch_step.hip, batch64_step.hip) ---------------------------------------
+// thread 0 waits for *p >= want (p may be nullptr), then one agent-scope acquire; a barrier for the rest
+template <bool LOCALP>
+__device__ __forceinline__ bool word_ge(const int* p, int want) { return poll_word<LOCALP>(p) >= want; }
+template <bool LOCALP>
+__device__ __forceinline__ bool wait_word_ge(const int* p, int want) {
+    if (word_ge<LOCALP>(p, want)) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while (!word_ge<LOCALP>(p, want)) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 1023u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > WAIT_LIMIT_TICKS) return false;
+    }
+    return true;
+}
+template <bool LOCALP>
+__device__ __forceinline__ void batch_wait(const int* p0, int want0, const int* p1, int want1, int* info_b) {
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        if (p0) ok = wait_word_ge<LOCALP>(p0, want0);
+        if (p1) ok = wait_word_ge<LOCALP>(p1, want1) && ok;
+        acquire_unless_local<LOCALP>();
+        if (!ok) atomicCAS(info_b, 0, (int)0x80000000);
+    }
+    __syncthreads();
+}
+// behind plain stores: drain, barrier, agent-scope release, the word.  LOCALP (readers on this XCD): the drain alone -- the
+// stores are in this L2 -- and a plain store of the word, which keeps its line there for the polls
+template <bool LOCALP>
+__device__ __forceinline__ void batch_publish_release(int* word, int val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if constexpr (LOCALP) {
+            *reinterpret_cast<volatile int*>(word) = val;
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// behind written-through (sc1) stores: every storing wave drains, then the word -- nothing is left in L2 to write back
+template <bool LOCALP>
+__device__ __forceinline__ void batch_publish_wt(int* word, int val) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if constexpr (LOCALP) *reinterpret_cast<volatile int*>(word) = val;
+        else __hip_atomic_store(word, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+
 }  // namespace volt

@@ -8,6 +8,8 @@
 #include "../../include/volt_hip.h"
 #include <math.h>
 
+size_t volt_internal_batch64_bytes(int B, int n);   // batch64_step.hip
+
 namespace volt {
 
 __global__ void pad_resid64_kernel(const double* __restrict__ resid, double* __restrict__ rpad, int N, int Np) {
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(256) void mll_scalars64_kernel(const double* __rest
 
 struct Mll64Ws {
     double *A, *Winv, *Y, *rpad, *z, *scratch, *apad, *frob;
-    size_t bytes;
+    void* prog;                      // progress words of the one-launch schedule (batch64_step.hip), if the shape is its
+    size_t prog_bytes, bytes;
 };
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static Mll64Ws carve64(void* base, int B, int N, int want_grad) {
@@ -115,6 +118,8 @@ static Mll64Ws carve64(void* base, int B, int N, int want_grad) {
     w.apad = take((size_t)B * Np);
     w.Y = want_grad ? take((size_t)B * Np * Np) : nullptr;
     w.frob = want_grad ? take((size_t)B * n) : nullptr;
+    w.prog_bytes = volt_internal_batch64_bytes(B, (int)n);
+    w.prog = w.prog_bytes ? take(w.prog_bytes / sizeof(double)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -123,7 +128,8 @@ static Mll64Ws carve64(void* base, int B, int N, int want_grad) {
 
 using namespace volt;
 
-int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream);   // chol64.hip
+int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream, void* state,
+                             size_t state_bytes);   // chol64.hip
 
 extern "C" {
 
@@ -151,7 +157,7 @@ int volt_mll_step_f64(const double* K, int64_t ldk, int64_t bsk, const double* r
     hipLaunchKernelGGL(pad_resid64_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
     if ((rc = volt_prepare_f64(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
     // factorisation and (gradient step) the triangular inverse in one multi-stream schedule (chol64.hip)
-    if ((rc = volt_internal_factor_f64(w.A, w.Winv, info, want_grad ? w.Y : nullptr, B, Np, stream))) return rc > 0 ? rc : -1;
+    if ((rc = volt_internal_factor_f64(w.A, w.Winv, info, want_grad ? w.Y : nullptr, B, Np, stream, w.prog, w.prog_bytes))) return rc > 0 ? rc : -1;
     if ((rc = volt_trsv_lower_f64(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
     if (want_grad) {
         if ((rc = volt_trsv_lower_t_f64(w.A, w.Winv, w.z, w.apad, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
