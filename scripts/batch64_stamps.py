@@ -1,0 +1,67 @@
+"""Timeline of the fp64 one-launch step from its per-workgroup stamps (volt_tune_batch64_stamps): the latency chain of matrix
+0 column by column (D(k): entry, chased product done, exit; US(k+1,k): sum parked, W seen, product done, exit), per kind the
+mean duration, microseconds per K block of the chased products, the launch's span and slot occupancy.
+    python scripts/batch64_stamps.py 1x4096 [potrf|step]"""
+import os, sys, ctypes as C
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from volt_amd import ops, _lib
+from volt_amd.synthetic import sde_batch
+
+sh = sys.argv[1] if len(sys.argv) > 1 else "1x4096"
+what = sys.argv[2] if len(sys.argv) > 2 else "potrf"
+B, n = map(int, sh.split("x"))
+L = _lib.lib()
+x, F, vol = sde_batch(min(B, 4), n)
+vol = np.tile(vol, (B // min(B, 4) + 1, 1))[:B]; F = np.tile(F, (B // min(B, 4) + 1, 1))[:B]
+K = ops.fill(ops.cumtrapz(torch.tensor(vol).cuda().double(), torch.tensor(x).cuda().double(), square=True))
+y = torch.log(torch.tensor(F[:, 1:]).cuda().double()); r = (y - y.mean(-1, keepdim=True)).contiguous()
+s2 = torch.full((B,), 0.05, device="cuda", dtype=torch.float64)
+nb = ops.padded_n(n) // 128
+has_y = what == "step"
+cnt = L.volt_batch64_describe(B, nb, int(has_y), None, 0)
+buf = (C.c_int * (4 * cnt))()
+assert L.volt_batch64_describe(B, nb, int(has_y), buf, cnt) == cnt
+items = np.array(buf).reshape(cnt, 4)
+ws = ops.MllWorkspace(B, n, True, K.device, torch.float64)
+run = (lambda: ops.mll_step(K, r, s2, ws)) if has_y else (lambda: ops.potrf(K, s2))
+for _ in range(3): run()
+st = torch.zeros(cnt, 8, dtype=torch.int64, device="cuda")
+L.volt_tune_batch64_stamps(C.c_void_p(st.data_ptr()))
+run()
+torch.cuda.synchronize()
+L.volt_tune_batch64_stamps(None)
+s = st.cpu().numpy()
+assert (s[:, 0] > 0).all(), "the shape did not run as one launch"
+t0 = s[:, 0].min()
+T = lambda col: (s[:, col] - t0) / 100.0
+beg, end, t3, t4, t5 = T(0), T(1), T(3), T(4), T(5)
+kind, row, col, mat = items.T
+dur = end - beg
+span = end.max()
+print(f"{sh} {what}: {cnt} pieces, launch span {span:.1f} us, {dur.sum() / span:.1f} slots busy on average")
+names = ["D", "US", "TD", "T"]
+for k in range(4):
+    m = kind == k
+    if m.any(): print(f"  {names[k]:3s} n {m.sum():6d}  mean {dur[m].mean():8.2f} us  max {dur[m].max():8.2f}")
+blocks = np.where(kind == 1, col, np.where(kind == 3, row - col, 0)).astype(float)
+for k in (1, 3):
+    m = (kind == k) & (blocks >= 8)
+    if m.sum() > 4:
+        A_ = np.vstack([blocks[m], np.ones(m.sum())]).T
+        sl, ic = np.linalg.lstsq(A_, dur[m], rcond=None)[0]
+        print(f"  {names[k]}: duration ~ {sl:.2f} us per K block + {ic:.1f} us")
+    m = kind == k
+    if m.any():
+        print(f"  {names[k]}: sum parked -> W seen {np.mean(t4[m] - t3[m]):7.2f} us, second product {np.mean(t5[m] - t4[m]):6.2f} us, store + publish {np.mean(end[m] - t5[m]):6.2f} us (means)")
+print("chain of matrix 0 (us; D: entry, sum done, exit | US(k+1,k): W seen - D exit, product, store + publish | column)")
+prev = 0.0
+for k in range(nb):
+    d = np.where((kind == 0) & (row == k) & (mat == 0))[0][0]
+    line = f"  k {k:2d}  D in {beg[d]:8.1f} sum {(t3[d] if k else beg[d]):8.1f} out {end[d]:8.1f} (diag {end[d] - (t3[d] if k else beg[d]):5.1f})"
+    if k + 1 < nb:
+        u = np.where((kind == 1) & (row == k + 1) & (col == k) & (mat == 0))[0][0]
+        line += f" | US +{t4[u] - end[d]:5.1f} {t5[u] - t4[u]:5.1f} {end[u] - t5[u]:5.1f}"
+        line += f" | column {end[u] - prev:6.1f}"
+        prev = end[u]
+    print(line)

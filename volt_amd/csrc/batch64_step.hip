@@ -62,7 +62,7 @@ __device__ __host__ inline Piece64 batch64_piece(int p, int n, bool has_y) {
 
 // the wave's 64x64 of a 128x128 tile of doubles <-> accumulator layout (VOLT_ACC64_RC).  WT: written through at agent scope
 // (sc1) -- a tile handed to workgroups on other XCDs leaves nothing behind in this L2 for a release to write back
-__device__ __forceinline__ void tile64_load(f64x4 (&v)[16], const double* __restrict__ C, int64_t ld) {
+__device__ __forceinline__ void tile64_load_neg(f64x4 (&v)[16], const double* __restrict__ C, int64_t ld) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -71,7 +71,7 @@ __device__ __forceinline__ void tile64_load(f64x4 (&v)[16], const double* __rest
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 VOLT_ACC64_RC(mt, nt, q)
-                v[mt * 4 + nt][q] = C[(int64_t)r * ld + c];
+                v[mt * 4 + nt][q] = -C[(int64_t)r * ld + c];
             }
 }
 template <bool WT>
@@ -130,14 +130,12 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
         if (k > 0) {
             // the tile's own input first (it is there from the start), then the chased sum over row k
             const double* C = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
-            f64x4 cv[16];
-            tile64_load(cv, C, Np);
+            f64x4 acc[16];
+            tile64_load_neg(acc, C, Np);                  // the sum starts from -A[k,k]: no second copy of the tile in registers
             Chase ch;
             ch.p0 = ch.p1 = rowp + k;
-            f64x4 acc[16];
-            zero_acc64(acc);
             const double* Lk = Ab + (int64_t)k * TS * Np;
-            gemm64_nt_128<true, LOCAL>(Lk, Np, Lk, Np, k * CPB, acc, smem, &ch, &ok);
+            gemm64_nt_128<true, LOCAL, 2>(Lk, Np, Lk, Np, k * CPB, acc, smem, &ch, &ok);
             VOLT_B64_STAMP(3);
             // the lower triangle of the updated block into the image, zeros above (the staging buffers are free: the loop
             // ends with a barrier)
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         VOLT_ACC64_RC(mt, nt, q)
-                        sT[r * DT64 + c] = (c <= r) ? cv[mt * 4 + nt][q] - acc[mt * 4 + nt][q] : 0.0;
+                        sT[r * DT64 + c] = (c <= r) ? -acc[mt * 4 + nt][q] : 0.0;
                     }
             if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
         }
@@ -202,18 +200,11 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
         sign = -1.0;
     }
     if (nblk > 0) {
-        f64x4 cv[16];
-        if (cin) tile64_load(cv, cin, Np);
         f64x4 acc[16];
-        zero_acc64(acc);
-        gemm64_nt_128<true, LOCAL>(X, Np, Z, Np, nblk * CPB, acc, smem, &ch, &ok);
-        if (cin) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[t][q] = cv[t][q] - acc[t][q];
-        }
-        tile64_store<false>(acc, mid, Np, 1.0);
+        if (cin) tile64_load_neg(acc, cin, Np);            // panel tile: the sum starts from -A[i,k] and is stored negated
+        else zero_acc64(acc);
+        gemm64_nt_128<true, LOCAL, 2>(X, Np, Z, Np, nblk * CPB, acc, smem, &ch, &ok);
+        tile64_store<false>(acc, mid, Np, cin ? -1.0 : 1.0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the barrier of the wait below covers the workgroup)
     }
     VOLT_B64_STAMP(3);
@@ -222,7 +213,7 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
     {
         f64x4 acc[16];
         zero_acc64(acc);
-        gemm64_nt_128(mid, Np, W, TS, CPB, acc, smem);      // (all of `mid` is read before the loop's closing barrier)
+        gemm64_nt_128<false, false, 2>(mid, Np, W, TS, CPB, acc, smem);   // (all of `mid` is read before the loop's closing barrier)
         VOLT_B64_STAMP(5);
         if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
         tile64_store<!LOCAL>(acc, out, Np, sign);

@@ -75,7 +75,12 @@ __device__ __forceinline__ void chunk64_run(const float* cur, float* nxt, bool m
 // gemm_nt_128 on the float view of the operands: loads two chunks ahead, double-buffered LDS, one barrier per chunk.
 // CHASE (batch64_step.hip): the operands' 128-wide K blocks are still being produced by other workgroups of the launch; the
 // loop asks the two progress words (common.h, Chase) before it requests a chunk of a block it has not yet seen complete.
-template <bool CHASE = false, bool LOCALP = false>
+// SETS: staging register sets = chunks the global loads run ahead of the LDS stores.
+//   1  (chol64.hip's kernels, two workgroups per CU): with two sets a wave needs 242 + 128 registers and a SIMD holds one wave;
+//      one set fits two, whose barrier and LDS waits cover each other.
+//   2  (batch64_step.hip, ONE workgroup per CU -- the diagonal block's image -- so a wave has the 512 registers anyway): the
+//      loads are two chunks ahead, as in the fp32 loop.
+template <bool CHASE = false, bool LOCALP = false, int SETS = 1>
 __device__ __forceinline__ void gemm64_nt_128(const double* __restrict__ A, int64_t lda, const double* __restrict__ B,
                                               int64_t ldb, int nchunks, f64x4 (&acc)[16], float* smem,
                                               const Chase* ch = nullptr, bool* ch_ok = nullptr) {
@@ -83,38 +88,57 @@ __device__ __forceinline__ void gemm64_nt_128(const double* __restrict__ A, int6
     constexpr int CPB = TS / BK64;             // chunks per 128-wide K block
     int ready = 0;
     if constexpr (CHASE) ready = chase_wait<LOCALP>(*ch, 1, *ch_ok);
-    // chunk j may be requested once block j / CPB is complete (the last chunk clamps: nothing past the range is asked for)
+    // chunk j may be requested once block j / CPB is complete (clamped: nothing past the range is asked for)
     auto ask = [&](int j) {
         if constexpr (CHASE) {
             const int need = (j < nchunks ? j : nchunks - 1) / CPB + 1;
             if (ready < need) ready = chase_wait<LOCALP>(*ch, need, *ch_ok);
         }
     };
-    // ONE staging register set, loads one chunk ahead: with two sets (two chunks ahead, as the fp32 loop has it) a wave
-    // needs 242 + 128 registers and a SIMD holds one wave -- nothing covers its barrier and LDS waits, and the 128x128 fp64
-    // core stops at 57 TF/s (74 % of the 77 TF/s the MFMA pipe issues, scripts/ubench/mfma64.hip).  One set fits two.
-    StageRegs s0;
     const StageAddr sa = stage_addr(reinterpret_cast<const float*>(A), 2 * lda, reinterpret_cast<const float*>(B), 2 * ldb);
-    stage_load_buf(s0, sa, 0);
-    stage_store(s0, smem);
-    if (nchunks > 1) stage_load_buf(s0, sa, BK);
-    __syncthreads();
     Frag64 F0, F1;
-    frag64_load(F0, smem, 0);
     float* b0 = smem;
     float* b1 = smem + STAGE_FLOATS;
     int c = 0;
-    for (; c + 3 < nchunks; c += 2) {
-        ask(c + 3);
-        chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 2) * BK);
-        chunk64_run<true>(b1, b0, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
+    if constexpr (SETS == 1) {
+        StageRegs s0;
+        stage_load_buf(s0, sa, 0);
+        stage_store(s0, smem);
+        if (nchunks > 1) stage_load_buf(s0, sa, BK);
+        __syncthreads();
+        frag64_load(F0, smem, 0);
+        for (; c + 3 < nchunks; c += 2) {
+            ask(c + 3);
+            chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 2) * BK);
+            chunk64_run<true>(b1, b0, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
+        }
+        for (; c + 1 < nchunks; c += 2) {
+            ask(c + 3);
+            chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 2 < nchunks, sa, (c + 2) * BK);
+            chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s0, c + 2 < nchunks, c + 3 < nchunks, sa, (c + 3) * BK);
+        }
+        if (c < nchunks) chunk64_run<false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
+    } else {
+        // chunk c stores the set that holds chunk c + 1 and refills it with chunk c + 3; the sets alternate
+        StageRegs s0, s1;
+        stage_load_buf(s0, sa, 0);
+        stage_store(s0, smem);
+        if (nchunks > 1) stage_load_buf(s0, sa, BK);
+        if (nchunks > 2) stage_load_buf(s1, sa, 2 * BK);
+        __syncthreads();
+        frag64_load(F0, smem, 0);
+        for (; c + 4 < nchunks; c += 2) {
+            ask(c + 4);
+            chunk64_run<true>(b0, b1, true, F0, F1, acc, s0, true, true, sa, (c + 3) * BK);
+            chunk64_run<true>(b1, b0, true, F0, F1, acc, s1, true, true, sa, (c + 4) * BK);
+        }
+        for (; c + 1 < nchunks; c += 2) {
+            ask(c + 4);
+            chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 3 < nchunks, sa, (c + 3) * BK);
+            chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s1, c + 2 < nchunks, c + 4 < nchunks, sa, (c + 4) * BK);
+        }
+        if (c < nchunks) chunk64_run<false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
     }
-    for (; c + 1 < nchunks; c += 2) {
-        ask(c + 3);
-        chunk64_run<false>(b0, b1, true, F0, F1, acc, s0, true, c + 2 < nchunks, sa, (c + 2) * BK);
-        chunk64_run<false>(b1, b0, c + 2 < nchunks, F0, F1, acc, s0, c + 2 < nchunks, c + 3 < nchunks, sa, (c + 3) * BK);
-    }
-    if (c < nchunks) chunk64_run<false>(b0, b1, false, F0, F1, acc, s0, false, false, sa, 0);
     __syncthreads();
 }
 
