@@ -40,8 +40,8 @@ kind, row, col, mat = items.T
 dur = end - beg
 span = end.max()
 print(f"{sh} {what}: {cnt} pieces, launch span {span:.1f} us, {dur.sum() / span:.1f} slots busy on average")
-names = ["D", "US", "TD", "T"]
-for k in range(4):
+names = ["D", "US", "TD", "T", "LA"]
+for k in range(5):
     m = kind == k
     if m.any(): print(f"  {names[k]:3s} n {m.sum():6d}  mean {dur[m].mean():8.2f} us  max {dur[m].max():8.2f}")
 blocks = np.where(kind == 1, col, np.where(kind == 3, row - col, 0)).astype(float)
@@ -51,17 +51,18 @@ for k in (1, 3):
         A_ = np.vstack([blocks[m], np.ones(m.sum())]).T
         sl, ic = np.linalg.lstsq(A_, dur[m], rcond=None)[0]
         print(f"  {names[k]}: duration ~ {sl:.2f} us per K block + {ic:.1f} us")
-    m = kind == k
-    if m.any():
-        print(f"  {names[k]}: sum parked -> W seen {np.mean(t4[m] - t3[m]):7.2f} us, second product {np.mean(t5[m] - t4[m]):6.2f} us, store + publish {np.mean(end[m] - t5[m]):6.2f} us (means)")
-print("chain of matrix 0 (us; D: entry, sum done, exit | US(k+1,k): W seen - D exit, product, store + publish | column)")
-prev = 0.0
-for k in range(nb):
-    d = np.where((kind == 0) & (row == k) & (mat == 0))[0][0]
-    line = f"  k {k:2d}  D in {beg[d]:8.1f} sum {(t3[d] if k else beg[d]):8.1f} out {end[d]:8.1f} (diag {end[d] - (t3[d] if k else beg[d]):5.1f})"
-    if k + 1 < nb:
-        u = np.where((kind == 1) & (row == k + 1) & (col == k) & (mat == 0))[0][0]
-        line += f" | US +{t4[u] - end[d]:5.1f} {t5[u] - t4[u]:5.1f} {end[u] - t5[u]:5.1f}"
-        line += f" | column {end[u] - prev:6.1f}"
-        prev = end[u]
+m = kind == 1
+if m.any(): print(f"  US: sum parked -> last sub-block seen {np.mean(t4[m] - t3[m]):7.2f} us, -> tile complete {np.mean(t5[m] - t4[m]):6.2f} us (means)")
+m = kind == 3
+if m.any(): print(f"  T: sum parked -> W seen {np.mean(t4[m] - t3[m]):7.2f} us, second product {np.mean(t5[m] - t4[m]):6.2f} us, store + publish {np.mean(end[m] - t5[m]):6.2f} us (means)")
+print("chain of matrix 0 (us): D(i) entry | sum parked | last sub-block of D(i-1) seen | tile (i,i-1) + rank-32 done | exit  (column = step between 'seen' times)")
+prev = None
+for i in range(nb):
+    d = np.where((kind == 0) & (row == i) & (mat == 0))[0][0]
+    if i == 0:
+        print(f"  i  0  in {beg[d]:8.1f}                                        out {end[d]:8.1f}")
+        continue
+    line = f"  i {i:2d}  in {beg[d]:8.1f} sum {t3[d]:8.1f} seen {t4[d]:8.1f} done {t5[d]:8.1f} (+{t5[d] - t4[d]:4.1f}) out {end[d]:8.1f}"
+    if prev is not None: line += f" | column {t4[d] - prev:6.1f}"
+    prev = t4[d]
     print(line)

@@ -92,3 +92,73 @@ def test_gate_is_a_function_of_the_shape_only():
     assert grow(64, 4096) > 64 * (2 * 4096 * 4096 * 4)                # A and Y and more
     assert L.volt_potrf_workspace_bytes(2, 1024) == L.volt_potrf_workspace_bytes(2, 1024)   # deterministic
     assert L.volt_batch_describe(0, 4, 1, 0, None, 0) == -1 and L.volt_batch_describe(4, 4, 1, 16, None, 0) == -1
+
+
+# ---- the fp64 one-launch step (csrc/batch64_step.hip): no table, the piece is a function of blockIdx -------------------
+D64, US64, TD64, T64, LA64 = range(5)
+
+
+def plan64(B, n, has_y):
+    from volt_amd import _lib
+    L = _lib.lib()
+    cnt = L.volt_batch64_describe(B, n, has_y, None, 0)
+    assert cnt > 0
+    buf = (C.c_int * (4 * cnt))()
+    assert L.volt_batch64_describe(B, n, has_y, buf, cnt) == cnt
+    assert L.volt_batch64_describe(B, n, has_y, buf, cnt - 1) == -2
+    return np.array(buf).reshape(cnt, 4)
+
+
+@pytest.mark.parametrize("B,n,has_y", [(1, 32, 0), (1, 32, 1), (8, 8, 1), (3, 5, 1), (2, 2, 1), (5, 3, 0), (16, 4, 1), (1, 1, 1)])
+def test_fp64_list_is_topological_and_complete(B, n, has_y):
+    it = plan64(B, n, has_y)
+    kind, row, col, mat = it.T
+    pos = {}
+    for w, key in enumerate(zip(kind.tolist(), mat.tolist(), row.tolist(), col.tolist())):
+        assert key not in pos, f"piece {key} twice"
+        pos[key] = w
+    # the matrix is the innermost index: with a batch that is a multiple of 8 a matrix stays on one XCD
+    assert (mat == np.arange(len(it)) % B).all()
+    for bb in range(B):
+        for i in range(n):
+            assert (D64, bb, i, i) in pos                              # D(i) carries tile (i, i-1) too
+            if 2 <= i <= n - 1:
+                assert (LA64, bb, i, i) in pos
+            for k in range(i - 1):
+                assert (US64, bb, i, k) in pos
+            if has_y:
+                assert (TD64, bb, i, i) in pos
+                for j in range(i):
+                    assert (T64, bb, i, j) in pos
+    assert len(pos) == B * (n + max(0, n - 2) + (n - 1) * (n - 2) // 2 + (n * (n + 1) // 2 if has_y else 0))
+
+    def row_done(bb, i, k):
+        """the piece that publishes rowp[i] = k + 1 (tile (i, k) of L)"""
+        return (D64, bb, i, i) if k == i - 1 else (US64, bb, i, k)
+
+    def before(a, c):
+        assert pos[a] < pos[c], (a, c)
+
+    for (k, bb, r, c), w in pos.items():
+        me = (k, bb, r, c)
+        if k == D64 and r >= 1:
+            before((D64, bb, r - 1, r - 1), me)                        # the sub-blocks of L[r-1, r-1]
+            if r >= 2:
+                before((LA64, bb, r, r), me)
+                before(row_done(bb, r, r - 2), me)                     # the last block the chased sum of tile (r, r-1) reads
+                before(row_done(bb, r - 1, r - 2), me)
+        if k == LA64:
+            before(row_done(bb, r, r - 2), me)
+        if k == US64:
+            before((D64, bb, c, c), me)
+            if c >= 1:
+                before(row_done(bb, r, c - 1), me)
+                before(row_done(bb, c, c - 1), me)
+        if k == TD64:
+            before((D64, bb, r, r), me)
+        if k == T64:                                                   # tile (r, c) of the inverse
+            before((D64, bb, r, r), me)                                # W_r
+            before(row_done(bb, r, r - 1), me)                         # all of row r of L
+            before((TD64, bb, c, c), me)
+            if r - 1 > c:
+                before((T64, bb, r - 1, c), me)

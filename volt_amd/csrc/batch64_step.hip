@@ -7,17 +7,26 @@
 // the diagonal block is 58 -- the rest is launch boundaries and event hand-offs (1 x 4096: 4.1 ms for 32 columns).  Here, as
 // in batch_step.hip for fp32, workgroup w runs piece w of a topologically ordered list and the pieces hand their tiles on
 // through per-matrix progress words, chasing their inputs one 128-wide K block at a time (common.h, Chase):
-//     D(k)      A[k,k] -= L[k,:k] L[k,:k]^T (chasing row k), the result straight into the LDS image of the diagonal block;
-//               factor + inverse (tiles64.h, diag64_body) -> L[k,k], W_k;                    publishes wdone = k + 1
-//     US(i,k)   A[i,k] -= L[i,:k] L[k,:k]^T (chasing rows i and k), then L[i,k] = (.) W_k^T;  publishes rowp[i] = k + 1
+//     D(i)      i >= 1: tile (i,i-1) -- A[i,i-1] -= L[i,:i-1] L[i-1,:i-1]^T chasing rows i and i-1 -- parked in an LDS image and
+//               solved against L[i-1,i-1] 32 COLUMNS AT A TIME while that block is still being factored (its workgroup
+//               publishes every 32-column slice and the slice's inverse as they become final: tiles64.h, diag64_body /
+//               trsm64_step); every finished slice goes into the sum of A[i,i] (rank-32, from the image) which then is
+//               factored + inverted in the same image (diag64_body) -> L[i,i-1], L[i,i], W_i.
+//               Publishes rowp[i] = i, sub[i] = 1 .. 4 (sub-block columns of L[i,i] out), wdone = i + 1
+//     LA(i)     i >= 2: A[i,i] -= sum_{m<i-1} L[i,m] L[i,m]^T, chasing row i, parked in place;        publishes la[i] = 1
+//     US(i,k)   i >= k + 2: A[i,k] -= L[i,:k] L[k,:k]^T (chasing rows i and k) into the image, the same blocked solve;
+//                                                                                            publishes rowp[i] = k + 1
 //     TD(i)     Y[i,i] = W_i^T;                                                              publishes tcol[i] = 1
 //     T(i,j)    S = Y[j, j..i) L[i, j..i)^T (chasing tcol[j] and rowp[i]), Y[j,i] = -S W_i^T; publishes tcol[j] = i - j + 1
-// The list needs no table: per block column k it is D(k), US(k+1 .. n-1, k), then row k-1 of the inverse (TD, T longest
-// first), every position for all B matrices with the matrix innermost, and a workgroup finds its piece from blockIdx alone.
-// Workgroups are dispatched in grid order and every piece waits only for pieces listed before it, so whatever a resident
-// workgroup waits for is resident or finished.  The diagonal block's image takes 133 KB of LDS: ONE workgroup per CU, which is
-// also what the latency chain wants (batch_step.hip: a pivot chain that shares its CU runs 2.5 x slower) -- and why this is
-// the schedule of small batches only; from batch64_max tiles per block column on, chol64.hip's bulk kernels (two per CU) win.
+// What a block column costs on the latency chain is then the diagonal block's pivots (~40 us) plus ONE 32-column step and one
+// rank-32 update (~7 us): the inverse W_k, the write-out and every hand-off of a whole tile are off it.
+// The list needs no table: per block column k it is D(k), LA(k+1), US(k+2 .. n-1, k), then row k-1 of the inverse (TD, T
+// longest first), every position for all B matrices with the matrix innermost, and a workgroup finds its piece from blockIdx
+// alone.  Workgroups are dispatched in grid order and every piece waits only for pieces listed before it, so whatever a
+// resident workgroup waits for is resident or finished.  The diagonal block's image takes 133 KB of LDS: ONE workgroup per CU,
+// which is also what the latency chain wants (batch_step.hip: a pivot chain that shares its CU runs 2.5 x slower) -- and why
+// this is the schedule of small batches only; from batch64_max tiles per block column on, chol64.hip's bulk kernels (two per
+// CU) win.
 // No atomics: unlike the K-sliced launches of chol64.hip the result is the same from run to run.
 #include "common.h"
 #include "tiles64.h"
@@ -28,10 +37,11 @@
 
 namespace volt {
 
-// progress words per matrix (ints): rowp[n] | tcol[n] | wdone, padded to a multiple of 32
-static inline int batch64_pstride(int n) { return (2 * n + 1 + 31) & ~31; }
+// progress words per matrix (ints): rowp[n] | tcol[n] | sub[n] | la[n] | wdone, padded to a multiple of 32
+static inline int batch64_pstride(int n) { return (4 * n + 1 + 31) & ~31; }
 static inline int64_t batch64_count(int B, int n, bool has_y) {
-    return (int64_t)B * (n + (int64_t)n * (n - 1) / 2 + (has_y ? (int64_t)n * (n + 1) / 2 : 0));
+    const int64_t per = n + (n >= 3 ? n - 2 : 0) + (int64_t)(n - 1) * (n - 2) / 2 + (has_y ? (int64_t)n * (n + 1) / 2 : 0);
+    return (int64_t)B * per;
 }
 
 __global__ void batch64_begin_kernel(int* __restrict__ info, int ninfo, int* __restrict__ prog, int nprog) {
@@ -40,15 +50,20 @@ __global__ void batch64_begin_kernel(int* __restrict__ info, int ninfo, int* __r
     for (int c = i; c < nprog; c += gridDim.x * blockDim.x) prog[c] = 0;
 }
 
-enum Piece64Kind { P64_DIAG = 0, P64_PANEL = 1, P64_TRTRI_DIAG = 2, P64_TRTRI = 3 };
+enum Piece64Kind { P64_DIAG = 0, P64_PANEL = 1, P64_TRTRI_DIAG = 2, P64_TRTRI = 3, P64_LOOKAHEAD = 4 };
 struct Piece64 { int kind, row, col; };
 // position p of a matrix's list (header comment); scalar work, at most n steps
 __device__ __host__ inline Piece64 batch64_piece(int p, int n, bool has_y) {
     for (int k = 0; k < n; ++k) {
         if (p == 0) return {P64_DIAG, k, k};
         p -= 1;
-        if (p < n - k - 1) return {P64_PANEL, k + 1 + p, k};
-        p -= n - k - 1;
+        if (k >= 1 && k + 1 < n) {
+            if (p == 0) return {P64_LOOKAHEAD, k + 1, k + 1};
+            p -= 1;
+        }
+        const int nus = n - k - 2 > 0 ? n - k - 2 : 0;
+        if (p < nus) return {P64_PANEL, k + 2 + p, k};
+        p -= nus;
         if (has_y && k >= 1) {
             if (p == 0) return {P64_TRTRI_DIAG, k - 1, k - 1};
             p -= 1;
@@ -89,9 +104,24 @@ __device__ __forceinline__ void tile64_store(const f64x4 (&v)[16], double* __res
                 else C[(int64_t)r * ld + c] = x;
             }
 }
+// -acc into the LDS image (row stride DT64); LOWER: the lower triangle, zeros above it
+template <bool LOWER>
+__device__ __forceinline__ void tile64_to_image(const f64x4 (&v)[16], double* __restrict__ sT) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_ACC64_RC(mt, nt, q)
+                sT[r * DT64 + c] = (!LOWER || c <= r) ? -v[mt * 4 + nt][q] : 0.0;
+            }
+}
 
 // tuning only (volt_tune_batch64_stamps): 8 int64 per workgroup -- s_memrealtime at entry [0] and exit [1], hardware id [2],
-// behind the chased product [3], behind the wait for W [4], behind the second product [5]
+// behind the chased sum [3]; progressive tiles: sub-block 3 of the diagonal block seen [4], the tile complete [5]; tiles of
+// the inverse: W seen [4], second product done [5]
 static long long* g_batch64_stamps = nullptr;
 
 // LOCAL: the batch is a multiple of 8 -- every piece of a matrix runs on ONE XCD (workgroup w on XCD w % 8, matrix w % B) and
@@ -117,41 +147,82 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
     } exit_stamp{stamps};
     int* rowp = prog + (int64_t)b * pstride;
     int* tcol = rowp + n;
-    int* wdone = tcol + n;
+    int* sub = tcol + n;
+    int* la = sub + n;
+    int* wdone = la + n;
     int* info_b = info + b;
     double* Ab = A + (int64_t)b * Np * Np;
     double* Wb = Winv + (int64_t)b * n * TS * TS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     constexpr int CPB = TS / BK64;
     bool ok = true;
 
-    if (pc.kind == P64_DIAG) {
-        const int k = pc.row;
-        if (k > 0) {
-            // the tile's own input first (it is there from the start), then the chased sum over row k
-            const double* C = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
-            f64x4 acc[16];
-            tile64_load_neg(acc, C, Np);                  // the sum starts from -A[k,k]: no second copy of the tile in registers
-            Chase ch;
-            ch.p0 = ch.p1 = rowp + k;
-            const double* Lk = Ab + (int64_t)k * TS * Np;
-            gemm64_nt_128<true, LOCAL, 2>(Lk, Np, Lk, Np, k * CPB, acc, smem, &ch, &ok);
+    if (pc.kind == P64_LOOKAHEAD) {
+        // A[i,i] -= sum_{m < i-1} L[i,m] L[i,m]^T, chasing row i, parked in place: all of the diagonal tile's sum that does not
+        // need block column i-1 -- the tile itself (DIAG below) has the blocked solve of L[i,i-1] in that time
+        const int i = pc.row;
+        double* C = Ab + (int64_t)i * TS * Np + (int64_t)i * TS;
+        f64x4 acc[16];
+        tile64_load_neg(acc, C, Np);
+        Chase ch;
+        ch.p0 = ch.p1 = rowp + i;
+        const double* Li = Ab + (int64_t)i * TS * Np;
+        gemm64_nt_128<true, LOCAL, 2>(Li, Np, Li, Np, (i - 1) * CPB, acc, smem, &ch, &ok);
+        if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
+        tile64_store<!LOCAL>(acc, C, Np, -1.0);
+        batch_publish_wt<LOCAL>(la + i, 1);
+        return;
+    }
+    if (pc.kind == P64_DIAG || pc.kind == P64_PANEL) {
+        // A tile (i,k) below diagonal block k, solved against L_kk 32 columns at a time as block k's sub-blocks are published
+        // (trsm64_step).  DIAG i = k + 1: the tile next to the diagonal, whose row makes the NEXT diagonal block -- the same
+        // workgroup adds its slices' products to that block's sum as they become final and then factors it: between the last
+        // pivot of block k and the first of block k + 1 there is one 32-column step, one rank-32 update and no hand-off.
+        const bool dg = pc.kind == P64_DIAG;
+        const int i = pc.row, k = dg ? i - 1 : pc.col;
+        if (k >= 0) {
+            double* P = Ab + (int64_t)i * TS * Np + (int64_t)k * TS;
+            {
+                f64x4 acc[16];
+                tile64_load_neg(acc, P, Np);
+                if (k > 0) {
+                    Chase ch;
+                    ch.p0 = rowp + i;
+                    ch.p1 = rowp + k;
+                    gemm64_nt_128<true, LOCAL, 2>(Ab + (int64_t)i * TS * Np, Np, Ab + (int64_t)k * TS * Np, Np, k * CPB, acc, smem,
+                                                  &ch, &ok);
+                }
+                tile64_to_image<false>(acc, sT);          // (the staging buffers are free: the loop ends with a barrier)
+            }
             VOLT_B64_STAMP(3);
-            // the lower triangle of the updated block into the image, zeros above (the staging buffers are free: the loop
-            // ends with a barrier)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        VOLT_ACC64_RC(mt, nt, q)
-                        sT[r * DT64 + c] = (c <= r) ? -acc[mt * 4 + nt][q] : 0.0;
-                    }
+            f64x4 accT[16];
+            if (dg) {                                    // the diagonal tile's sum so far: the look-ahead's, or the input itself
+                if (i >= 2) batch_wait<LOCAL>(la + i, 1, nullptr, 0, info_b);
+                tile64_load_neg(accT, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np);
+            }
+            const double* Lkk = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
+            const double* Wk = Wb + (int64_t)k * TS * TS;
+#define VOLT_B64_STEP(KB)                                                       \
+            batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);             \
+            if (KB == 3) VOLT_B64_STAMP(4);                                     \
+            trsm64_step<KB>(sT, Lkk, Np, Wk, P, Np);                            \
+            if (dg) {                                                           \
+                __syncthreads();                                                \
+                syrk64_slice<KB>(accT, sT);                                     \
+            }
+            VOLT_B64_STEP(0)
+            VOLT_B64_STEP(1)
+            VOLT_B64_STEP(2)
+            VOLT_B64_STEP(3)
+#undef VOLT_B64_STEP
             if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
+            batch_publish_release<LOCAL>(rowp + i, k + 1);       // (drain, barrier: the image is free behind it)
+            VOLT_B64_STAMP(5);
+            if (!dg) return;
+            tile64_to_image<true>(accT, sT);
         }
-        diag64_body<false>(A, Winv, info, Np, k, b, sT, nullptr, k > 0);
-        batch_publish_release<LOCAL>(wdone, k + 1);
+        diag64_body<false, LOCAL>(A, Winv, info, Np, i, b, sT, nullptr, k >= 0, sub + i);
+        batch_publish_release<LOCAL>(wdone, i + 1);
         return;
     }
     if (pc.kind == P64_TRTRI_DIAG) {
@@ -161,64 +232,31 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
         batch_publish_release<LOCAL>(tcol + i, 1);
         return;
     }
-    // ---- the two-product tiles: a chased sum, then the product with a diagonal block's inverse
-    const double *X, *Z, *W;
-    double *mid, *out;                      // where the sum waits for W (read back by this workgroup alone), and the result
-    const double* cin = nullptr;            // the tile the sum is subtracted from (panel tiles)
-    Chase ch;
-    int nblk, wneed, *word, val;
-    double sign;
-    if (pc.kind == P64_PANEL) {
-        const int i = pc.row, k = pc.col;
-        X = Ab + (int64_t)i * TS * Np;
-        Z = Ab + (int64_t)k * TS * Np;
-        ch.p0 = rowp + i;
-        ch.p1 = rowp + k;
-        nblk = k;
-        W = Wb + (int64_t)k * TS * TS;
-        wneed = k + 1;
-        mid = out = Ab + (int64_t)i * TS * Np + (int64_t)k * TS;
-        cin = mid;
-        word = rowp + i;
-        val = k + 1;
-        sign = 1.0;
-    } else {
+    // ---- a tile (i,j) of the inverse: a chased sum, then the product with W_i
+    {
         const int i = pc.row, j = pc.col;
         double* Yb = Y + (int64_t)b * Np * Np;
-        X = Yb + (int64_t)j * TS * Np + (int64_t)j * TS;         // tiles (j, j .. i-1) of the inverse: tcol[j] of them are there
-        Z = Ab + (int64_t)i * TS * Np + (int64_t)j * TS;         // L[i, j .. i-1]: block m is there once rowp[i] >= j + m + 1
-        ch.p0 = tcol + j;
-        ch.p1 = rowp + i;
+        Chase ch;
+        ch.p0 = tcol + j;                                        // tiles (j, j .. i-1) of the inverse: tcol[j] of them are there
+        ch.p1 = rowp + i;                                        // L[i, j .. i-1]: block m is there once rowp[i] >= j + m + 1
         ch.base1 = j;
-        nblk = i - j;
-        W = Wb + (int64_t)i * TS * TS;
-        wneed = i + 1;
-        mid = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;       // the unused slot below the diagonal
-        out = Yb + (int64_t)j * TS * Np + (int64_t)i * TS;
-        word = tcol + j;
-        val = i - j + 1;
-        sign = -1.0;
-    }
-    if (nblk > 0) {
-        f64x4 acc[16];
-        if (cin) tile64_load_neg(acc, cin, Np);            // panel tile: the sum starts from -A[i,k] and is stored negated
-        else zero_acc64(acc);
-        gemm64_nt_128<true, LOCAL, 2>(X, Np, Z, Np, nblk * CPB, acc, smem, &ch, &ok);
-        tile64_store<false>(acc, mid, Np, cin ? -1.0 : 1.0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the barrier of the wait below covers the workgroup)
-    }
-    VOLT_B64_STAMP(3);
-    batch_wait<LOCAL>(wdone, wneed, nullptr, 0, info_b);
-    VOLT_B64_STAMP(4);
-    {
+        double* mid = Yb + (int64_t)i * TS * Np + (int64_t)j * TS;       // the unused slot below the diagonal
         f64x4 acc[16];
         zero_acc64(acc);
-        gemm64_nt_128<false, false, 2>(mid, Np, W, TS, CPB, acc, smem);   // (all of `mid` is read before the loop's closing barrier)
+        gemm64_nt_128<true, LOCAL, 2>(Yb + (int64_t)j * TS * Np + (int64_t)j * TS, Np, Ab + (int64_t)i * TS * Np + (int64_t)j * TS, Np,
+                                      (i - j) * CPB, acc, smem, &ch, &ok);
+        tile64_store<false>(acc, mid, Np, 1.0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the barrier of the wait below covers the workgroup)
+        VOLT_B64_STAMP(3);
+        batch_wait<LOCAL>(wdone, i + 1, nullptr, 0, info_b);
+        VOLT_B64_STAMP(4);
+        zero_acc64(acc);
+        gemm64_nt_128<false, false, 2>(mid, Np, Wb + (int64_t)i * TS * TS, TS, CPB, acc, smem);   // (all of `mid` is read before the closing barrier)
         VOLT_B64_STAMP(5);
         if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
-        tile64_store<!LOCAL>(acc, out, Np, sign);
+        tile64_store<!LOCAL>(acc, Yb + (int64_t)j * TS * Np + (int64_t)i * TS, Np, -1.0);
+        batch_publish_wt<LOCAL>(tcol + j, i - j + 1);
     }
-    batch_publish_wt<LOCAL>(word, val);
 #undef VOLT_B64_STAMP
 }
 

@@ -369,15 +369,113 @@ __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double*
     }
 }
 
+// X_kb (the 32x32 inverse of diagonal sub-block kb, in the image) into the diagonal block of W: 8-byte stores, 4 per thread
+__device__ __forceinline__ void x64_out(const double* __restrict__ sT, double* __restrict__ W, int kb) {
+    for (int e = threadIdx.x; e < 32 * 32; e += NT) {
+        const int r = e >> 5, c = e & 31;
+        W[(int64_t)(32 * kb + r) * TS + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
+    }
+}
+
+// ---- the blocked solve  tile <- tile L_kk^-T  in an LDS image, 32 columns at a time (batch64_step.hip) ---------------------
+// B operand of a 32x32x32 product straight from memory into registers: element [c][p] of a row-major block (ld doubles)
+struct Blk64 { double v[8][2]; };
+__device__ __forceinline__ void blk64_load(Blk64& b, const double* __restrict__ B, int64_t ld) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 8; ++st)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b.v[st][t] = B[(int64_t)(t * 16 + l15) * ld + 4 * st + lk];
+}
+// acc += sign * A[32x32] (image block) * B^T, B in registers:  C[r][c] = sum_p A[r][p] B[c][p]
+template <bool NEG>
+__device__ __forceinline__ void mm64_nt_rb(f64x4 (&acc)[4], const double* __restrict__ A, const Blk64& b) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        double a[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            a[t] = A[(t * 16 + l15) * DT64 + 4 * st + lk];
+            if (NEG) a[t] = -a[t];
+        }
+#pragma unroll
+        for (int tr = 0; tr < 2; ++tr)
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+                acc[tr * 2 + tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr], b.v[st][tc], acc[tr * 2 + tc], 0, 0, 0);
+    }
+}
+// Step KB on the 128x128 tile P in the image: column slice KB becomes final, Lt = P[:,KB] X_KB^T, and is taken out of the
+// slices to its right, P[:,j] -= Lt L[j,KB]^T.  Wave w owns rows 32 w .. 32 w + 31 (no barrier inside, none needed between
+// steps).  Lkk: the diagonal block of L in memory (ld doubles), Wk: W_k, whose diagonal 32-blocks are the X_kb.  Then the
+// final slice goes out to `out` (ldo doubles): 16-byte stores.
+template <int KB>
+__device__ __forceinline__ void trsm64_step(double* __restrict__ sT, const double* __restrict__ Lkk, int64_t ld,
+                                            const double* __restrict__ Wk, double* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Blk64 bx, bl[KB < 3 ? 3 - KB : 1];
+    blk64_load(bx, Wk + (int64_t)(32 * KB) * TS + 32 * KB, TS);
+#pragma unroll
+    for (int j = KB + 1; j <= 3; ++j) blk64_load(bl[j - KB - 1], Lkk + (int64_t)(32 * j) * ld + 32 * KB, ld);
+    double* rows = sT + (32 * wave) * DT64;
+    f64x4 acc[4];
+    acc64_zero(acc);
+    mm64_nt_rb<false>(acc, rows + 32 * KB, bx);
+    acc64_store(acc, rows + 32 * KB, 1.0);
+#pragma unroll
+    for (int j = KB + 1; j <= 3; ++j) {
+        f64x4 c[4];
+        acc64_load(c, rows + 32 * j);
+        mm64_nt_rb<true>(c, rows + 32 * KB, bl[j - KB - 1]);
+        acc64_store(c, rows + 32 * j, 1.0);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + (lane >> 4), c = (lane & 15) * 2;
+        f64x2 v;
+        v[0] = rows[r * DT64 + 32 * KB + c];
+        v[1] = rows[r * DT64 + 32 * KB + c + 1];
+        *reinterpret_cast<f64x2*>(out + (int64_t)(32 * wave + r) * ldo + 32 * KB + c) = v;
+    }
+}
+// acc (the wave's 64x64 of a 128x128 tile, gemm64 layout) += Lt[:, slice KB] Lt[:, slice KB]^T from the image
+template <int KB>
+__device__ __forceinline__ void syrk64_slice(f64x4 (&acc)[16], const double* __restrict__ sT) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lk = lane >> 4;
+    const double* ra = sT + ((wave >> 1) * 64 + l15) * DT64 + 32 * KB + lk;
+    const double* rb = sT + ((wave & 1) * 64 + l15) * DT64 + 32 * KB + lk;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        double a[4], bb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a[t] = ra[(16 * t) * DT64 + 4 * st];
+            bb[t] = rb[(16 * t) * DT64 + 4 * st];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt * 4 + nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], bb[nt], acc[mt * 4 + nt], 0, 0, 0);
+    }
+}
+
 #define VOLT_STAMP64(i)                                                                \
     do {                                                                               \
         if (STAMP && threadIdx.x == 0) stamps[32 * b + (i)] = __builtin_amdgcn_s_memtime();   \
     } while (0)
 // The diagonal block of matrix b, block column k.  image_ready: the caller has already put the (lower triangle of the)
 // block into the image sT (batch64_step.hip: the tile's last update lands there instead of in memory).
-template <bool STAMP>
+// sub (batch64_step.hip; LOCALPUB as in common.h): PROGRESSIVE hand-off.  The tiles below this block do not wait for the whole
+// inverse W: they solve against L_kk 32 columns at a time (trsm64_step) and need, for sub-block column kb, the final blocks
+// L[kb..3, kb] and X_kb = L[kb,kb]^-1.  With sub != nullptr those go to memory as soon as they exist -- the column slice
+// behind its pivot phase, X_kb (into the diagonal block of W where it stays) behind the phase that inverts it -- and *sub is
+// raised to kb + 1 when slice kb and X_kb are there; the separate pass that writes the off-diagonal blocks of L is gone.
+template <bool STAMP, bool LOCALPUB = false>
 __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __restrict__ Winv, int* __restrict__ info, int Np,
-                                            int k, int b, double* __restrict__ sT, long long* stamps, bool image_ready) {
+                                            int k, int b, double* __restrict__ sT, long long* stamps, bool image_ready,
+                                            int* sub = nullptr) {
     VOLT_STAMP64(0);
     double* colbuf = sT + TS * DT64;       // 128 doubles: the reciprocal pivots
     const int n = Np / TS, tid = threadIdx.x, wave = tid >> 6;
@@ -417,11 +515,12 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
         }
         __syncthreads();
         VOLT_STAMP64(2 + 4 * kb);
-        // L_kk out (zeros above the diagonal)
-        for (int e = tid; e < 32 * 32; e += NT) {
+        // L_kk out (zeros above the diagonal); progressive: with the blocks below it, which rode along and are final too
+        for (int e = tid; e < (sub ? TS - 32 * kb : 32) * 32; e += NT) {
             const int r = e >> 5, c = e & 31;
             D[(int64_t)(32 * kb + r) * Np + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
         }
+        if (sub && kb >= 1) x64_out(sT, W, kb - 1);          // X_{kb-1}: wave 3 inverted it during this pivot phase
         VOLT_STAMP64(3 + 4 * kb);
         if (kb == 3) break;
         // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to the 4 waves
@@ -436,15 +535,21 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
                     acc64_store(acc, C, 1.0);
                 }
             }
-        __syncthreads();
+        if (sub && kb >= 1) batch_publish_release<LOCALPUB>(sub, kb);       // (drain, barrier, word)
+        else __syncthreads();
         VOLT_STAMP64(5 + 4 * kb);
     }
-    __syncthreads();                       // the L_33 store above reads the image
+    if (sub) batch_publish_release<LOCALPUB>(sub, 3);
+    else __syncthreads();                  // the L_33 store above reads the image
     if (wave == 3) inv32_f64(sT, rdiag, 3);
     __syncthreads();
+    if (sub) {
+        x64_out(sT, W, 3);
+        batch_publish_release<LOCALPUB>(sub, 4);
+    }
     // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal: 16-byte stores, the
     // LDS reads of 8 of them in flight at a time
-    {
+    if (!sub) {
         constexpr int PER = TS * TS / 2 / NT;
 #pragma unroll
         for (int it0 = 0; it0 < PER; it0 += 8) {
