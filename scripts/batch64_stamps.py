@@ -26,12 +26,14 @@ items = np.array(buf).reshape(cnt, 4)
 ws = ops.MllWorkspace(B, n, True, K.device, torch.float64)
 run = (lambda: ops.mll_step(K, r, s2, ws)) if has_y else (lambda: ops.potrf(K, s2))
 for _ in range(3): run()
-st = torch.zeros(cnt, 8, dtype=torch.int64, device="cuda")
+DS = "VOLT_B64_DIAG_STAMPS" in os.environ.get("VOLT_EXTRA_FLAGS", "")
+st = torch.zeros(cnt * 8 + (32 * nb * B if DS else 0), dtype=torch.int64, device="cuda")
 L.volt_tune_batch64_stamps(C.c_void_p(st.data_ptr()))
 run()
 torch.cuda.synchronize()
 L.volt_tune_batch64_stamps(None)
-s = st.cpu().numpy()
+sall = st.cpu().numpy()
+s = sall[:cnt * 8].reshape(cnt, 8)
 assert (s[:, 0] > 0).all(), "the shape did not run as one launch"
 t0 = s[:, 0].min()
 T = lambda col: (s[:, col] - t0) / 100.0
@@ -66,3 +68,11 @@ for i in range(nb):
     if prev is not None: line += f" | column {t4[d] - prev:6.1f}"
     prev = t4[d]
     print(line)
+if DS:
+    ds = sall[cnt * 8:].reshape(nb, B, 32)[:, 0, :]        # matrix 0
+    lab = {0: "entry", 1: "image", 2: "piv0", 3: "out0", 5: "trail0+pub", 6: "piv1", 7: "out1", 9: "trail1+pub", 10: "piv2", 11: "out2",
+           13: "trail2+pub", 14: "piv3", 15: "out3", 18: "pub3+inv3+pub4(+Lout)", 19: "Wcomp", 20: "Wout"}
+    for i in (1, nb // 2, nb - 1):
+        v = ds[i]
+        idx = [j for j in sorted(lab) if v[j] > 0]
+        print(f"diagonal block {i} (us since its entry): " + "  ".join(f"{lab[j]} {(v[j] - v[0]) / 100.0:.1f}" for j in idx))

@@ -23,7 +23,7 @@ names = {1: "load", 18: "L out", 19: "W compute", 20: "W out"}
 for kb in range(4):
     names.update({2 + 4 * kb: f"chol32[{kb}]", 3 + 4 * kb: f"Lkk out + inv32[{kb}]", 4 + 4 * kb: f"panel[{kb}]", 5 + 4 * kb: f"trailing[{kb}]"})
 prev = s[0]
-print("columns are s_memtime ticks / 100 (the counter runs at the ~2.3 GHz shader clock here: 23 ticks/100 = 1 us)")
+print("s_memrealtime (100 MHz): microseconds")
 for i in sorted(names):
     if s[i] == 0: continue
     print(f"{names[i]:26s} {(s[i] - prev) * 0.01:8.2f} us   (t = {(s[i] - s[0]) * 0.01:7.2f})")

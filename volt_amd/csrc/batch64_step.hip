@@ -20,9 +20,9 @@
 //     T(i,j)    S = Y[j, j..i) L[i, j..i)^T (chasing tcol[j] and rowp[i]), Y[j,i] = -S W_i^T; publishes tcol[j] = i - j + 1
 // What a block column costs on the latency chain is then the diagonal block's pivots (~40 us) plus ONE 32-column step and one
 // rank-32 update (~7 us): the inverse W_k, the write-out and every hand-off of a whole tile are off it.
-// The list needs no table: per block column k it is D(k), LA(k+1), US(k+2 .. n-1, k), then row k-1 of the inverse (TD, T
-// longest first), every position for all B matrices with the matrix innermost, and a workgroup finds its piece from blockIdx
-// alone.  Workgroups are dispatched in grid order and every piece waits only for pieces listed before it, so whatever a
+// The list needs no table: D(0), then per block column k: LA(k+1), D(k+1) -- resident, its sums under way, while D(k) is
+// still at its pivots --, US(k+2 .. n-1, k), then row k-1 of the inverse (TD, T longest first); every position for all B
+// matrices with the matrix innermost, and a workgroup finds its piece from blockIdx alone.  Workgroups are dispatched in grid order and every piece waits only for pieces listed before it, so whatever a
 // resident workgroup waits for is resident or finished.  The diagonal block's image takes 133 KB of LDS: ONE workgroup per CU,
 // which is also what the latency chain wants (batch_step.hip: a pivot chain that shares its CU runs 2.5 x slower) -- and why
 // this is the schedule of small batches only; from batch64_max tiles per block column on, chol64.hip's bulk kernels (two per
@@ -54,11 +54,15 @@ enum Piece64Kind { P64_DIAG = 0, P64_PANEL = 1, P64_TRTRI_DIAG = 2, P64_TRTRI = 
 struct Piece64 { int kind, row, col; };
 // position p of a matrix's list (header comment); scalar work, at most n steps
 __device__ __host__ inline Piece64 batch64_piece(int p, int n, bool has_y) {
+    if (p == 0) return {P64_DIAG, 0, 0};
+    p -= 1;
     for (int k = 0; k < n; ++k) {
-        if (p == 0) return {P64_DIAG, k, k};
-        p -= 1;
         if (k >= 1 && k + 1 < n) {
             if (p == 0) return {P64_LOOKAHEAD, k + 1, k + 1};
+            p -= 1;
+        }
+        if (k + 1 < n) {
+            if (p == 0) return {P64_DIAG, k + 1, k + 1};
             p -= 1;
         }
         const int nus = n - k - 2 > 0 ? n - k - 2 : 0;
@@ -221,7 +225,12 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             if (!dg) return;
             tile64_to_image<true>(accT, sT);
         }
+#ifdef VOLT_B64_DIAG_STAMPS                              // tuning build: the diagonal block's own 32 stamps (s_memtime) behind the pieces'
+        diag64_body<true, LOCAL>(A, Winv, info, Np, i, b, sT, stamps ? stamps + (int64_t)gridDim.x * 8 + 32 * (int64_t)i * B : nullptr,
+                                 k >= 0, sub + i);
+#else
         diag64_body<false, LOCAL>(A, Winv, info, Np, i, b, sT, nullptr, k >= 0, sub + i);
+#endif
         batch_publish_release<LOCAL>(wdone, i + 1);
         return;
     }

@@ -301,7 +301,10 @@ __device__ __forceinline__ void rl_fma64_1(double& c0, double l, int lo, int hi,
 
 // One WAVE factors the 32x32 diagonal sub-block (kb,kb) with one matrix row per lane in registers -- the idiom of the
 // fp32 diagonal block (chol.hip): per pivot the pivot and the column entries travel by v_readlane (SGPR broadcast),
-// so the 32 dependent pivots cost no barrier and no LDS round trip.  Lanes 0..31 hold the rows of the diagonal
+// so the 32 dependent pivots cost no barrier and no LDS round trip.  (Round 5 tried the broadcast through LDS instead -- every
+// lane leaves its l in a per-wave buffer, all lanes read entries j+1 .. 31 back 16 bytes at a time: a quarter of the
+// instructions -- and measured 6.4 us per 32 pivots against 6.9 alone, but 9.5 against 6.3 while another wave inverts the
+// previous sub-block from the same LDS: not kept.)  Lanes 0..31 hold the rows of the diagonal
 // sub-block; lanes 32..63 the rows of the panel block (prow,kb) below it, which the very same instructions turn into
 // L[prow,kb] = A[prow,kb] L_kk^-T -- no inverse is needed on the way down.  Several waves run this side by side, each
 // with its own copy of the (tiny) diagonal factorisation and its own panel block; the one with `own` writes L_kk and
@@ -463,7 +466,7 @@ __device__ __forceinline__ void syrk64_slice(f64x4 (&acc)[16], const double* __r
 
 #define VOLT_STAMP64(i)                                                                \
     do {                                                                               \
-        if (STAMP && threadIdx.x == 0) stamps[32 * b + (i)] = __builtin_amdgcn_s_memtime();   \
+        if (STAMP && stamps && threadIdx.x == 0) stamps[32 * b + (i)] = __builtin_amdgcn_s_memrealtime();   \
     } while (0)
 // The diagonal block of matrix b, block column k.  image_ready: the caller has already put the (lower triangle of the)
 // block into the image sT (batch64_step.hip: the tile's last update lands there instead of in memory).
