@@ -5,6 +5,8 @@ import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 shapes = [f"{B}x{N}" for N in (512, 1024, 2048, 3072, 4096) for B in (1, 2, 4, 8, 12, 16, 24, 32)
           if not (N >= 3072 and B > 24)]
+if os.environ.get("SHAPES"):
+    shapes = os.environ["SHAPES"].split(",")
 res = {}
 for mode in ("0", "2"):
     env = dict(os.environ, VOLT_TUNE="1", VOLT_BATCH64=mode)

@@ -1,0 +1,104 @@
+"""The fp64 one-launch factorisation / gradient step (csrc/batch64_step.hip, round 5): D(i) tiles that solve against the
+diagonal block above them 32 columns at a time while it is still being factored, chased sums, progress words.
+reference call sites: psd_safe_cholesky at voltron/rollout_utils.py:35 on the noise-free train block; a double-precision
+model's step (voltron/train_utils.py:243-254 in the caller's dtype).
+
+All through the C ABI (ops.potrf -> volt_potrf_ws_f64, ops.mll_step -> volt_mll_step_f64):
+  * against fp64 LAPACK on the device (torch.linalg.cholesky + triangular solves): factor, mll, d mll / d sigma2, alpha;
+  * bitwise repeatable (the one launch has no atomics, unlike the K-sliced launches it replaces);
+  * both hand-off protocols -- batches that are a multiple of 8 (one XCD per matrix, no fences) and those that are not;
+  * 2 and 3 block columns (no look-ahead piece / one), ragged N, a matrix that is not positive definite in the batch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from volt_amd import ops as o
+    return o
+
+
+def _problem(ops, B, n, s2v=0.05):
+    from volt_amd.synthetic import sde_batch
+    x, F, vol = sde_batch(min(B, 4), n)
+    rep = B // min(B, 4) + 1
+    vol = np.tile(vol, (rep, 1))[:B] * (1.0 + 0.01 * np.arange(B)[:, None])
+    F = np.tile(F, (rep, 1))[:B]
+    K = ops.fill(ops.cumtrapz(torch.tensor(vol).cuda().double(), torch.tensor(x).cuda().double(), square=True))
+    y = torch.log(torch.tensor(F[:, 1:]).cuda().double())
+    r = (y - y.mean(-1, keepdim=True)).contiguous()
+    s2 = torch.full((B,), s2v, device="cuda", dtype=torch.float64)
+    return K, r, s2
+
+
+def _lapack(K, r, s2):
+    B, n, _ = K.shape
+    Lr = torch.linalg.cholesky(K + torch.diag_embed(s2[:, None].expand(B, n)))
+    st = torch.linalg.solve_triangular                 # (torch.cholesky_solve on a batch: launch failure on this image)
+    al = st(Lr.mT, st(Lr, r[..., None], upper=False), upper=True)[..., 0]
+    Li = st(Lr, torch.eye(n, device=K.device, dtype=torch.float64).expand(B, n, n), upper=False)
+    q = (r * al).sum(-1)
+    ld = 2 * torch.log(torch.diagonal(Lr, dim1=-2, dim2=-1)).sum(-1)
+    mll = -0.5 * (q + ld + n * np.log(2 * np.pi)) / n
+    dm = 0.5 * ((al ** 2).sum(-1) - (Li ** 2).sum((-2, -1))) / n
+    return Lr, mll, dm, al
+
+
+CASES = [(1, 4096), (8, 1024), (3, 2048), (2, 1000), (16, 512), (5, 300), (4, 256), (8, 2500), (24, 700)]
+
+
+@pytest.mark.parametrize("B,n", CASES)
+def test_one_launch_fp64_matches_lapack_and_repeats(ops, B, n):
+    from volt_amd import _lib
+    L = _lib.lib()
+    Np = ops.padded_n(n)
+    assert L.volt_potrf_workspace_bytes_f64(B, Np) > 0, "the shape must run as one launch"
+    K, r, s2 = _problem(ops, B, n)
+    f = ops.potrf(K, s2)
+    assert int(f.info.abs().sum()) == 0
+    ws = ops.MllWorkspace(B, n, True, K.device, torch.float64)
+    o, a, info = ops.mll_step(K, r, s2, ws)
+    assert int(info.abs().sum()) == 0
+    Lr, mll, dm, al = _lapack(K, r, s2)
+    tol = 1e-10 if n <= 1024 else 1e-9                  # (the tolerances the fp64 path has held since round 2)
+    assert float((f.L - Lr).abs().amax() / Lr.abs().amax()) < tol
+    assert float(((o[:, 0] - mll).abs() / mll.abs()).max()) < tol
+    assert float(((o[:, 1] - dm).abs() / dm.abs()).max()) < 100 * tol
+    assert float((a - al).abs().amax() / al.abs().amax()) < 100 * tol
+    A0, o0, a0 = f.A.clone(), o.clone(), a.clone()
+    for _ in range(3):
+        f2 = ops.potrf(K, s2)
+        o2, a2, _i = ops.mll_step(K, r, s2, ws)
+        assert torch.equal(torch.tril(f2.A), torch.tril(A0)) and torch.equal(o2, o0) and torch.equal(a2, a0)
+
+
+def test_one_launch_fp64_reports_a_matrix_that_is_not_pd(ops):
+    B, n = 4, 1024
+    K, r, s2 = _problem(ops, B, n)
+    K = K.clone()
+    K[2, 700, 700] = -5.0                               # block column 5, pivot 60 of it
+    f = ops.potrf(K, s2)
+    info = f.info.cpu().tolist()
+    assert info[0] == 0 and info[1] == 0 and info[3] == 0
+    assert info[2] == 701                               # 1-based index of the first bad pivot (potrf's convention)
+    Lr = torch.linalg.cholesky(K[[0, 1, 3]] + torch.diag_embed(s2[:3, None].expand(3, n)))
+    assert float((f.L[[0, 1, 3]] - Lr).abs().amax() / Lr.abs().amax()) < 1e-10
+
+
+def test_null_workspace_is_the_launch_per_column_path(ops):
+    """ws == NULL is volt_potrf_f64: same factor to fp64 round-off (the K-sliced path sums with atomics)."""
+    from volt_amd import _lib
+    L = _lib.lib()
+    B, n = 2, 1024
+    K, r, s2 = _problem(ops, B, n)
+    f = ops.potrf(K, s2)
+    A = torch.empty_like(f.A)
+    _lib.check(L.volt_prepare_f64(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n, _lib.stream_ptr()), "prep")
+    W, info = torch.empty_like(f.Winv), torch.empty_like(f.info)
+    _lib.check(L.volt_potrf_ws_f64(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, n, None, 0, _lib.stream_ptr()), "potrf")
+    assert int(info.abs().sum()) == 0
+    assert float((torch.tril(A) - torch.tril(f.A)).abs().amax()) < 1e-12 * float(f.A.abs().amax())
+    assert float((W - f.Winv).abs().amax()) < 1e-9 * float(f.Winv.abs().amax())

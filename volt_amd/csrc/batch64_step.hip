@@ -273,17 +273,19 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
 
 using namespace volt;
 
-// Where the one launch replaces chol64.hip's schedules: small batches of long series (one workgroup per CU; measured
-// crossovers in host.h).  (B, n) only, like every gate.
-bool volt_internal_batch64_applies(int B, int n) {
+// Where the one launch replaces chol64.hip's schedules: the measured crossovers of profiles/r05/batch64_gate_sweep.txt (host.h).
+// (B, n, inverse?) only, like every gate: volt_*_workspace_bytes and the step agree on it.
+bool volt_internal_batch64_applies(int B, int n, int has_y) {
     const Tunables& tn = tunables();
     if (tn.batch64 <= 0 || B < 1 || n < 2 || B > 65535) return false;
     if (tn.batch64 >= 2) return true;
-    return n >= 4 && (int64_t)B * (n + 1) <= tn.batch64_max;
+    const int64_t tiles = (int64_t)B * (n + 1);
+    if (has_y) return tiles <= (n >= 24 ? tn.batch64_max_step : 1700);
+    return tiles <= tn.batch64_max;
 }
 
-size_t volt_internal_batch64_bytes(int B, int n) {
-    if (!volt_internal_batch64_applies(B, n)) return 0;
+size_t volt_internal_batch64_bytes(int B, int n, int has_y) {
+    if (!volt_internal_batch64_applies(B, n, has_y)) return 0;
     return ((size_t)B * batch64_pstride(n) * sizeof(int) + 255) & ~(size_t)255;
 }
 
@@ -291,7 +293,8 @@ size_t volt_internal_batch64_bytes(int B, int n) {
 int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
                                void* stream) {
     const int n = Np / TS;
-    if (!state || !volt_internal_batch64_applies(B, n) || state_bytes < volt_internal_batch64_bytes(B, n)) return 0;
+    const int has_y = Y != nullptr;
+    if (!state || !volt_internal_batch64_applies(B, n, has_y) || state_bytes < volt_internal_batch64_bytes(B, n, has_y)) return 0;
     hipStream_t s = (hipStream_t)stream;
     int* prog = reinterpret_cast<int*>(state);
     const int pstride = batch64_pstride(n), nprog = B * pstride;

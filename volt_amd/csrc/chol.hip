@@ -467,6 +467,7 @@ static Tunables read_env(Tunables t) {                       // VOLT_TUNE=1 proc
         geti("VOLT_BATCH_LAD", t.batch_lad);
         geti("VOLT_BATCH64", t.batch64);
         geti("VOLT_BATCH64_MAX", t.batch64_max);
+        geti("VOLT_BATCH64_MAX_STEP", t.batch64_max_step);
         if (const char* e = getenv("VOLT_SCHED_FRAC")) t.sched_frac = (float)atof(e);
         geti("VOLT_FAKE_CUS", t.cus);                        // tests: plan as if the device had this many CUs / XCDs
         geti("VOLT_FAKE_XCCS", t.xccs);

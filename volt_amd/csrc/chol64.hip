@@ -297,8 +297,8 @@ static void trtri64_finish(const double* A, const double* Winv, double* Y, int B
 int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream, void* state = nullptr,
                              size_t state_bytes = 0);
 // batch64_step.hip: the one-launch schedule of small batches (state: the progress words, caller scratch)
-bool volt_internal_batch64_applies(int B, int n);
-size_t volt_internal_batch64_bytes(int B, int n);
+bool volt_internal_batch64_applies(int B, int n, int has_y);
+size_t volt_internal_batch64_bytes(int B, int n, int has_y);
 int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
                                void* stream);
 
@@ -381,7 +381,7 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
 
 size_t volt_potrf_workspace_bytes_f64(int B, int Np) {
     if (B <= 0 || Np < TS || Np % TS) return 0;
-    return volt_internal_batch64_bytes(B, Np / TS);
+    return volt_internal_batch64_bytes(B, Np / TS, 0);
 }
 
 int volt_potrf_ws_f64(double* A, double* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {

@@ -8,7 +8,7 @@
 #include "../../include/volt_hip.h"
 #include <math.h>
 
-size_t volt_internal_batch64_bytes(int B, int n);   // batch64_step.hip
+size_t volt_internal_batch64_bytes(int B, int n, int has_y);   // batch64_step.hip
 
 namespace volt {
 
@@ -118,7 +118,7 @@ static Mll64Ws carve64(void* base, int B, int N, int want_grad) {
     w.apad = take((size_t)B * Np);
     w.Y = want_grad ? take((size_t)B * Np * Np) : nullptr;
     w.frob = want_grad ? take((size_t)B * n) : nullptr;
-    w.prog_bytes = volt_internal_batch64_bytes(B, (int)n);
+    w.prog_bytes = volt_internal_batch64_bytes(B, (int)n, want_grad);
     w.prog = w.prog_bytes ? take(w.prog_bytes / sizeof(double)) : nullptr;
     w.bytes = off;
     return w;
