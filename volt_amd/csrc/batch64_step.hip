@@ -193,8 +193,16 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
                     Chase ch;
                     ch.p0 = rowp + i;
                     ch.p1 = rowp + k;
-                    gemm64_nt_128<true, LOCAL, 2>(Ab + (int64_t)i * TS * Np, Np, Ab + (int64_t)k * TS * Np, Np, k * CPB, acc, smem,
-                                                  &ch, &ok);
+                    const double *X = Ab + (int64_t)i * TS * Np, *Z = Ab + (int64_t)k * TS * Np;
+                    // DIAG: the last K block, L[k,k-1], comes from the tile that has just become block k's diagonal -- it is
+                    // always the late one.  A loop of its own: the blocks before it are finished (every staged chunk used)
+                    // instead of stopping four chunks short of the wait
+                    const int early = dg ? k - 1 : k;
+                    gemm64_nt_128<true, LOCAL, 2>(X, Np, Z, Np, early * CPB, acc, smem, &ch, &ok);
+                    if (dg) {
+                        ch.base0 = ch.base1 = k - 1;
+                        gemm64_nt_128<true, LOCAL, 2>(X + (int64_t)(k - 1) * TS, Np, Z + (int64_t)(k - 1) * TS, Np, CPB, acc, smem, &ch, &ok);
+                    }
                 }
                 tile64_to_image<false>(acc, sT);          // (the staging buffers are free: the loop ends with a barrier)
             }
@@ -211,8 +219,20 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             if (KB == 3) VOLT_B64_STAMP(4);                                     \
             trsm64_step<KB>(sT, Lkk, Np, Wk, P, Np);                            \
             if (dg) {                                                           \
+                /* the last slice: rowp[i] = k + 1 goes out HERE -- the next diagonal tile's sum waits for it.  Its barrier is */ \
+                /* the one the rank-32 update needs anyway, and the release + word are wave 1's: the quadrant above the */ \
+                /* diagonal needs no update, so nothing on the chain waits for that wave */ \
+                if (KB == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
                 __syncthreads();                                                \
-                syrk64_slice<KB>(accT, sT);                                     \
+                if (KB == 3 && threadIdx.x == 64) {                             \
+                    if constexpr (LOCAL) {                                      \
+                        *reinterpret_cast<volatile int*>(rowp + i) = k + 1;     \
+                    } else {                                                    \
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      \
+                        __hip_atomic_store(rowp + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                    }                                                           \
+                }                                                               \
+                if ((threadIdx.x >> 6) != 1) syrk64_slice<KB>(accT, sT);        \
             }
             VOLT_B64_STEP(0)
             VOLT_B64_STEP(1)
@@ -220,9 +240,13 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             VOLT_B64_STEP(3)
 #undef VOLT_B64_STEP
             if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
-            batch_publish_release<LOCAL>(rowp + i, k + 1);       // (drain, barrier: the image is free behind it)
+            if (!dg) {
+                batch_publish_release<LOCAL>(rowp + i, k + 1);
+                VOLT_B64_STAMP(5);
+                return;
+            }
+            __syncthreads();                                     // (the last rank-32 update has read the image)
             VOLT_B64_STAMP(5);
-            if (!dg) return;
             tile64_to_image<true>(accT, sT);
         }
 #ifdef VOLT_B64_DIAG_STAMPS                              // tuning build: the diagonal block's own 32 stamps (s_memtime) behind the pieces'

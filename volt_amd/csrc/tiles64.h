@@ -360,10 +360,15 @@ __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double*
         double x[32];
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
-            double acc = (r == c) ? 1.0 : 0.0;
+            // two partial sums: the 31 dependent FMAs of the last rows were half of the block's 3.5 us
+            double acc = (r == c) ? 1.0 : 0.0, acc1 = 0.0;
 #pragma unroll
-            for (int m = 0; m < r; ++m) acc -= D[r * DT64 + m] * x[m];      // x[m] == 0 for m < c
-            x[r] = acc * rdiag[32 * kb + r];
+            for (int m = 0; m + 1 < r; m += 2) {
+                acc -= D[r * DT64 + m] * x[m];                              // x[m] == 0 for m < c
+                acc1 -= D[r * DT64 + m + 1] * x[m + 1];
+            }
+            if (r & 1) acc -= D[r * DT64 + r - 1] * x[r - 1];
+            x[r] = (acc + acc1) * rdiag[32 * kb + r];
         }
         // every lane has read all of L it needs (its own column's rows >= c only use L, never X): write after a wave barrier
         __builtin_amdgcn_wave_barrier();
@@ -372,16 +377,19 @@ __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double*
     }
 }
 
-// X_kb (the 32x32 inverse of diagonal sub-block kb, in the image) into the diagonal block of W: 8-byte stores, 4 per thread
+// X_kb (the 32x32 inverse of diagonal sub-block kb, in the image) into the diagonal block of W: 16-byte stores, 2 per thread
 __device__ __forceinline__ void x64_out(const double* __restrict__ sT, double* __restrict__ W, int kb) {
-    for (int e = threadIdx.x; e < 32 * 32; e += NT) {
-        const int r = e >> 5, c = e & 31;
-        W[(int64_t)(32 * kb + r) * TS + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
+    for (int e = threadIdx.x; e < 32 * 16; e += NT) {
+        const int r = e >> 4, c = (e & 15) * 2;
+        const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
+        *reinterpret_cast<f64x2*>(W + (int64_t)(32 * kb + r) * TS + 32 * kb + c) = f64x2{s[0], s[1]};
     }
 }
 
 // ---- the blocked solve  tile <- tile L_kk^-T  in an LDS image, 32 columns at a time (batch64_step.hip) ---------------------
 // B operand of a 32x32x32 product straight from memory into registers: element [c][p] of a row-major block (ld doubles)
+// (Fetching these blocks with agent-scope (sc1) loads, so that the wait in front of them needs no acquire fence, was measured:
+// the loads are served by memory instead of the L2 and the block column takes 67.6 us instead of 61.2.)
 struct Blk64 { double v[8][2]; };
 __device__ __forceinline__ void blk64_load(Blk64& b, const double* __restrict__ B, int64_t ld) {
     const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
@@ -519,9 +527,10 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
         __syncthreads();
         VOLT_STAMP64(2 + 4 * kb);
         // L_kk out (zeros above the diagonal); progressive: with the blocks below it, which rode along and are final too
-        for (int e = tid; e < (sub ? TS - 32 * kb : 32) * 32; e += NT) {
-            const int r = e >> 5, c = e & 31;
-            D[(int64_t)(32 * kb + r) * Np + 32 * kb + c] = sT[(32 * kb + r) * DT64 + 32 * kb + c];
+        for (int e = tid; e < (sub ? TS - 32 * kb : 32) * 16; e += NT) {
+            const int r = e >> 4, c = (e & 15) * 2;
+            const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
+            *reinterpret_cast<f64x2*>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c) = f64x2{s[0], s[1]};
         }
         if (sub && kb >= 1) x64_out(sT, W, kb - 1);          // X_{kb-1}: wave 3 inverted it during this pivot phase
         VOLT_STAMP64(3 + 4 * kb);
