@@ -788,11 +788,12 @@ __device__ __forceinline__ void batch_wait(const int* p0, int want0, const int* 
 }
 // behind plain stores: drain, barrier, agent-scope release, the word.  LOCALP (readers on this XCD): the drain alone -- the
 // stores are in this L2 -- and a plain store of the word, which keeps its line there for the polls
+// pub_tid: the thread that fences and stores the word -- a wave the caller's latency chain does not wait for, if it has one
 template <bool LOCALP>
-__device__ __forceinline__ void batch_publish_release(int* word, int val) {
+__device__ __forceinline__ void batch_publish_release(int* word, int val, int pub_tid = 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x == pub_tid) {
         if constexpr (LOCALP) {
             *reinterpret_cast<volatile int*>(word) = val;
         } else {

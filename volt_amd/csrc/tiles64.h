@@ -547,17 +547,17 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
                     acc64_store(acc, C, 1.0);
                 }
             }
-        if (sub && kb >= 1) batch_publish_release<LOCALPUB>(sub, kb);       // (drain, barrier, word)
+        if (sub && kb >= 1) batch_publish_release<LOCALPUB>(sub, kb, 64);   // (drain, barrier; release + word by wave 1, idle from here on)
         else __syncthreads();
         VOLT_STAMP64(5 + 4 * kb);
     }
-    if (sub) batch_publish_release<LOCALPUB>(sub, 3);
+    if (sub) batch_publish_release<LOCALPUB>(sub, 3, 64);
     else __syncthreads();                  // the L_33 store above reads the image
     if (wave == 3) inv32_f64(sT, rdiag, 3);
     __syncthreads();
     if (sub) {
         x64_out(sT, W, 3);
-        batch_publish_release<LOCALPUB>(sub, 4);
+        batch_publish_release<LOCALPUB>(sub, 4, 64);
     }
     // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal: 16-byte stores, the
     // LDS reads of 8 of them in flight at a time
