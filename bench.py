@@ -508,7 +508,20 @@ def f64_leg(x, F, vol, dev, n, B):
     t_potrf = timeit(potrf) - t_copy
     t_step = timeit(lambda: ops.mll_step(K, r, s2, ws))
     fl = B * Np ** 3 / 3
+    # ONE series: the latency chain alone (32 diagonal blocks in a row; csrc/batch64_step.hip)
+    f1 = ops.potrf(K[:1], s2[:1])
+    A1 = f1.A.clone()
+
+    def potrf1():
+        f1.A.copy_(A1prep)
+        ops.potrf_f64_inplace(f1.A, f1.Winv, f1.info)
+    A1prep = Aprep[:1].clone()
+    t_copy1 = timeit(lambda: f1.A.copy_(A1prep), reps=10)
+    t_potrf1 = timeit(potrf1, reps=10) - t_copy1
+    one_launch = bool(L.volt_potrf_workspace_bytes_f64(B, Np))
     return {"workload": f"{B} series of N={n} in fp64 (v_mfma_f64_16x16x4_f64)",
+            "schedule": "one launch (csrc/batch64_step.hip)" if one_launch else "launch per block column (csrc/chol64.hip)",
+            "single_series_potrf_ms": round(t_potrf1, 3),
             "potrf_ms": round(t_potrf, 3), "potrf_tflops": round(fl / t_potrf / 1e9, 2),
             "potrf_frac_of_fp64_mfma_peak": round(fl / t_potrf / 1e9 / FP64_MFMA_PEAK_TF, 4),
             "mll_grad_step_ms": round(t_step, 3), "mll_grad_step_tflops": round(2 * fl / t_step / 1e9, 2),
