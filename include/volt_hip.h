@@ -126,6 +126,12 @@ int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stre
  * ONE launch (csrc/batch64_step.hip) instead of three launches per block column.  ws == NULL is volt_potrf_f64. */
 size_t volt_potrf_workspace_bytes_f64(int B, int Np);
 int volt_potrf_ws_f64(double* A, double* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream);
+/* volt_prepare_f64 + volt_potrf_ws_f64 in one, the fp64 twin of volt_potrf_k_f32: the factor of K + (sigma2 + jitter) I with K
+ * [B,N,N] read in place (row stride ldk, batch stride bsk; only the lower triangle) -- where the shape runs as one launch the
+ * tiles come straight from K and A [B,Np,Np] only receives L (no copy-in pass; the strictly upper tiles of A are then not
+ * written).  ws as for volt_potrf_ws_f64 (may be NULL: prepare + the launch-per-column schedule). */
+int volt_potrf_k_f64(const double* K, int64_t ldk, int64_t bsk, const double* sigma2, double jitter, double* A, double* Winv,
+                     int* info, int B, int N, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a5/a6: triangular solves with one right-hand side  (torch.cholesky_solve at
  * rollout_utils.py:36,44; gpytorch inv_quad) ------------------------------------------------

@@ -102,3 +102,19 @@ def test_null_workspace_is_the_launch_per_column_path(ops):
     assert int(info.abs().sum()) == 0
     assert float((torch.tril(A) - torch.tril(f.A)).abs().amax()) < 1e-12 * float(f.A.abs().amax())
     assert float((W - f.Winv).abs().amax()) < 1e-9 * float(f.Winv.abs().amax())
+
+
+@pytest.mark.parametrize("B,n", [(2, 1000), (8, 1024), (1, 2048)])
+def test_factor_straight_from_k_equals_the_prepared_copy(ops, B, n):
+    """volt_potrf_k_f64 reads its tiles from K (sigma2 + jitter added on the way, identity in the padding); volt_prepare_f64 +
+    volt_potrf_ws_f64 factor a prepared copy: the same arithmetic on the same numbers -- bitwise the same factor."""
+    from volt_amd import _lib
+    L = _lib.lib()
+    K, r, s2 = _problem(ops, B, n)
+    f = ops.potrf(K, s2, jitter=1e-7)                    # -> volt_potrf_k_f64
+    A = torch.empty_like(f.A)
+    _lib.check(L.volt_prepare_f64(K.data_ptr(), n, n * n, s2.data_ptr(), 1e-7, A.data_ptr(), B, n, _lib.stream_ptr()), "prep")
+    W, info = torch.empty_like(f.Winv), torch.empty_like(f.info)
+    ops.potrf_f64_inplace(A, W, info)
+    assert int(info.abs().sum()) == 0 and int(f.info.abs().sum()) == 0
+    assert torch.equal(torch.tril(A), torch.tril(f.A)) and torch.equal(W, f.Winv)

@@ -34,6 +34,7 @@ _SIGS = {
     "volt_potrf_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_potrf_workspace_bytes_f64": (C.c_size_t, [_i32, _i32]),
     "volt_potrf_ws_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
+    "volt_potrf_k_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, C.c_double, _ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
     "volt_trsv_lower_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_t_f64": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trsv_lower_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),

@@ -93,6 +93,32 @@ __device__ __forceinline__ void tile64_load_neg(f64x4 (&v)[16], const double* __
                 v[mt * 4 + nt][q] = -C[(int64_t)r * ld + c];
             }
 }
+// element (gi, gj) of the input matrix of series b, from the caller's K (prepare64_kernel's arithmetic)
+__device__ __forceinline__ double input64(const KSource64& src, const double* __restrict__ Kb, double add, int gi, int gj) {
+    double v = (gi < src.N && gj < src.N) ? Kb[(int64_t)gi * src.ldk + gj] : 0.0;
+    if (gi == gj) v = (gi < src.N) ? v + add : 1.0;
+    return v;
+}
+// -(tile (ti, tj) of the input) in the accumulator layout: from the prepared copy A, or straight from K
+__device__ __forceinline__ void tile64_input_neg(f64x4 (&v)[16], const KSource64& src, int b, const double* __restrict__ Ab,
+                                                 int Np, int ti, int tj) {
+    if (!src.K) {
+        tile64_load_neg(v, Ab + (int64_t)ti * TS * Np + (int64_t)tj * TS, Np);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double add = (src.sigma2 ? src.sigma2[b] : 0.0) + src.jitter;
+    const double* Kb = src.K + (int64_t)b * src.bsk;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                VOLT_ACC64_RC(mt, nt, q)
+                v[mt * 4 + nt][q] = -input64(src, Kb, add, ti * TS + r, tj * TS + c);
+            }
+}
 template <bool WT>
 __device__ __forceinline__ void tile64_store(const f64x4 (&v)[16], double* __restrict__ C, int64_t ld, double sign) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -133,7 +159,7 @@ static long long* g_batch64_stamps = nullptr;
 template <bool LOCAL>
 __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ A, double* __restrict__ Winv,
                                                            double* __restrict__ Y, int* __restrict__ info, int Np, int B,
-                                                           int* __restrict__ prog, int pstride,
+                                                           int* __restrict__ prog, int pstride, KSource64 src,
                                                            long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) double sT[];
     float* smem = reinterpret_cast<float*>(sT);
@@ -167,7 +193,7 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
         const int i = pc.row;
         double* C = Ab + (int64_t)i * TS * Np + (int64_t)i * TS;
         f64x4 acc[16];
-        tile64_load_neg(acc, C, Np);
+        tile64_input_neg(acc, src, b, Ab, Np, i, i);
         Chase ch;
         ch.p0 = ch.p1 = rowp + i;
         const double* Li = Ab + (int64_t)i * TS * Np;
@@ -188,7 +214,7 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             double* P = Ab + (int64_t)i * TS * Np + (int64_t)k * TS;
             {
                 f64x4 acc[16];
-                tile64_load_neg(acc, P, Np);
+                tile64_input_neg(acc, src, b, Ab, Np, i, k);
                 if (k > 0) {
                     Chase ch;
                     ch.p0 = rowp + i;
@@ -209,8 +235,12 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             VOLT_B64_STAMP(3);
             f64x4 accT[16];
             if (dg) {                                    // the diagonal tile's sum so far: the look-ahead's, or the input itself
-                if (i >= 2) batch_wait<LOCAL>(la + i, 1, nullptr, 0, info_b);
-                tile64_load_neg(accT, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np);
+                if (i >= 2) {
+                    batch_wait<LOCAL>(la + i, 1, nullptr, 0, info_b);
+                    tile64_load_neg(accT, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np);
+                } else {
+                    tile64_input_neg(accT, src, b, Ab, Np, i, i);
+                }
             }
             const double* Lkk = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
             const double* Wk = Wb + (int64_t)k * TS * TS;
@@ -249,11 +279,21 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             VOLT_B64_STAMP(5);
             tile64_to_image<true>(accT, sT);
         }
+        bool image = k >= 0;
+        if (!image && src.K) {                           // block 0 straight from K into the image
+            const double add = (src.sigma2 ? src.sigma2[b] : 0.0) + src.jitter;
+            const double* Kb = src.K + (int64_t)b * src.bsk;
+            for (int e = threadIdx.x; e < TS * TS; e += NT) {
+                const int r = e >> 7, c = e & 127;
+                sT[r * DT64 + c] = (c <= r) ? input64(src, Kb, add, r, c) : 0.0;
+            }
+            image = true;
+        }
 #ifdef VOLT_B64_DIAG_STAMPS                              // tuning build: the diagonal block's own 32 stamps (s_memtime) behind the pieces'
         diag64_body<true, LOCAL>(A, Winv, info, Np, i, b, sT, stamps ? stamps + (int64_t)gridDim.x * 8 + 32 * (int64_t)i * B : nullptr,
-                                 k >= 0, sub + i);
+                                 image, sub + i);
 #else
-        diag64_body<false, LOCAL>(A, Winv, info, Np, i, b, sT, nullptr, k >= 0, sub + i);
+        diag64_body<false, LOCAL>(A, Winv, info, Np, i, b, sT, nullptr, image, sub + i);
 #endif
         batch_publish_release<LOCAL>(wdone, i + 1);
         return;
@@ -314,8 +354,10 @@ size_t volt_internal_batch64_bytes(int B, int n, int has_y) {
 }
 
 // Returns 1 when the step was enqueued, 0 when the shape is not this schedule's (nothing enqueued), a HIP error otherwise.
+// src (optional): the caller's K -- the tiles are read from it and A only receives the factor (no copy-in pass).
 int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
-                               void* stream) {
+                               void* stream, const KSource64* ksrc) {
+    const KSource64 src = ksrc ? *ksrc : KSource64{nullptr, 0, 0, nullptr, 0.0, Np};
     const int n = Np / TS;
     const int has_y = Y != nullptr;
     if (!state || !volt_internal_batch64_applies(B, n, has_y) || state_bytes < volt_internal_batch64_bytes(B, n, has_y)) return 0;
@@ -334,13 +376,13 @@ int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, in
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, Y, info, Np, B, prog,
-                           pstride, g_batch64_stamps);
+                           pstride, src, g_batch64_stamps);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, Y, info, Np, B, prog,
-                           pstride, g_batch64_stamps);
+                           pstride, src, g_batch64_stamps);
     }
     e = hipGetLastError();
     return e != hipSuccess ? (int)e : 1;

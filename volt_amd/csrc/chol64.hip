@@ -300,7 +300,7 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
 bool volt_internal_batch64_applies(int B, int n, int has_y);
 size_t volt_internal_batch64_bytes(int B, int n, int has_y);
 int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
-                               void* stream);
+                               void* stream, const volt::KSource64* ksrc = nullptr);
 
 extern "C" {
 
@@ -386,6 +386,28 @@ size_t volt_potrf_workspace_bytes_f64(int B, int Np) {
 
 int volt_potrf_ws_f64(double* A, double* Winv, int* info, int B, int Np, void* ws, size_t ws_bytes, void* stream) {
     if (ws && ((uintptr_t)ws & 255)) return -6;
+    return volt_internal_factor_f64(A, Winv, info, nullptr, B, Np, stream, ws, ws_bytes);
+}
+
+int volt_potrf_k_f64(const double* K, int64_t ldk, int64_t bsk, const double* sigma2, double jitter, double* A, double* Winv,
+                     int* info, int B, int N, void* ws, size_t ws_bytes, void* stream) {
+    if (!K) return -1;
+    if (ldk < N) return -2;
+    if (!A) return -6;
+    if (!Winv) return -7;
+    if (!info) return -8;
+    if (B < 0) return -9;
+    if (N < 1) return -10;
+    if (ws && ((uintptr_t)ws & 255)) return -11;
+    if (B == 0) return 0;
+    const int Np = volt_padded_n(N);
+    if (ws) {                                                         // one launch, the tiles straight from K
+        const KSource64 src{K, ldk, bsk, sigma2, jitter, N};
+        const int rc = volt_internal_batch64_step(A, Winv, info, nullptr, B, Np, ws, ws_bytes, stream, &src);
+        if (rc != 0) return rc == 1 ? 0 : rc;
+    }
+    const int rc = volt_prepare_f64(K, ldk, bsk, sigma2, jitter, A, B, N, stream);
+    if (rc) return rc;
     return volt_internal_factor_f64(A, Winv, info, nullptr, B, Np, stream, ws, ws_bytes);
 }
 

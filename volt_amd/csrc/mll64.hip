@@ -5,6 +5,7 @@
 //     -> Y = L^-T (volt_trtri_f64) -> tr K_s^-1 = ||Y||_F^2 -> scalars.
 // The O(N^2) passes are HBM streams; the O(N^3) work runs on v_mfma_f64_16x16x4_f64 (chol64.hip).
 #include "common.h"
+#include "tiles64.h"
 #include "../../include/volt_hip.h"
 #include <math.h>
 
@@ -138,6 +139,8 @@ using namespace volt;
 
 int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int B, int Np, void* stream, void* state,
                              size_t state_bytes);   // chol64.hip
+int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
+                               void* stream, const volt::KSource64* ksrc);   // batch64_step.hip
 
 extern "C" {
 
@@ -163,9 +166,13 @@ int volt_mll_step_f64(const double* K, int64_t ldk, int64_t bsk, const double* r
     Mll64Ws w = carve64(workspace, B, N, want_grad);
     int rc;
     hipLaunchKernelGGL(pad_resid64_kernel, dim3((Np + 255) / 256, B), dim3(256), 0, s, resid, w.rpad, N, Np);
-    if ((rc = volt_prepare_f64(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
-    // factorisation and (gradient step) the triangular inverse in one multi-stream schedule (chol64.hip)
-    if ((rc = volt_internal_factor_f64(w.A, w.Winv, info, want_grad ? w.Y : nullptr, B, Np, stream, w.prog, w.prog_bytes))) return rc > 0 ? rc : -1;
+    // small / medium batches: factorisation (+ inverse) as ONE launch that reads its tiles straight from K (batch64_step.hip)
+    const KSource64 src{K, ldk, bsk, sigma2, jitter, N};
+    rc = w.prog ? volt_internal_batch64_step(w.A, w.Winv, info, want_grad ? w.Y : nullptr, B, Np, w.prog, w.prog_bytes, stream, &src) : 0;
+    if (rc != 0 && rc != 1) return rc > 0 ? rc : -1;
+    // otherwise a prepared copy, then factorisation and (gradient step) the triangular inverse in one multi-stream schedule (chol64.hip)
+    if (rc == 0 && (rc = volt_prepare_f64(K, ldk, bsk, sigma2, jitter, w.A, B, N, stream))) return rc > 0 ? rc : -1;
+    if (rc == 0 && (rc = volt_internal_factor_f64(w.A, w.Winv, info, want_grad ? w.Y : nullptr, B, Np, stream, w.prog, w.prog_bytes))) return rc > 0 ? rc : -1;
     if ((rc = volt_trsv_lower_f64(w.A, w.Winv, w.rpad, w.z, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;
     if (want_grad) {
         if ((rc = volt_trsv_lower_t_f64(w.A, w.Winv, w.z, w.apad, w.scratch, B, Np, stream))) return rc > 0 ? rc : -1;

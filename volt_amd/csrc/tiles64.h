@@ -8,6 +8,16 @@ namespace volt {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Where the one-launch step reads a tile of its input from (batch64_step.hip): K == nullptr -- the prepared copy A; else the
+// caller's K (+ sigma2[b] + jitter on the diagonal, identity in the padding): no copy-in pass ahead of the factorisation.
+struct KSource64 {
+    const double* K;
+    int64_t ldk, bsk;
+    const double* sigma2;
+    double jitter;
+    int N;
+};
+
 constexpr int SLD64 = SLD / 2;          // 18 doubles per LDS row
 constexpr int BK64 = BK / 2;            // 16 doubles of K per chunk
 

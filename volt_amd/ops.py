@@ -118,22 +118,26 @@ def _potrf_workspace(B: int, Np: int, device):
     return ((buf.data_ptr() + 255) // 256) * 256, nbytes
 
 
+def _potrf_ws_f64(B: int, Np: int, device):
+    """The few KB of progress words the fp64 one-launch schedule wants (csrc/batch64_step.hip): one buffer per (device, stream,
+    B, Np), as for the fp32 scratch.  Returns (aligned pointer or None, bytes)."""
+    nbytes = int(_lib.lib().volt_potrf_workspace_bytes_f64(B, Np))
+    if not nbytes:
+        return None, 0
+    key = (device.index, _lib.stream_ptr(), B, Np, "f64")
+    buf = _POTRF_WS.get(key)
+    if buf is None:
+        if len(_POTRF_WS) >= 8:
+            _POTRF_WS.pop(next(iter(_POTRF_WS)))
+        buf = _POTRF_WS[key] = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+    return ((buf.data_ptr() + 255) // 256) * 256, nbytes
+
+
 def potrf_f64_inplace(A: torch.Tensor, Winv: torch.Tensor, info: torch.Tensor) -> None:
-    """volt_potrf_ws_f64 on a prepared [B,Np,Np] fp64 buffer, with the few KB of progress words its one-launch schedule wants
-    for a small batch (csrc/batch64_step.hip) -- one buffer per (device, stream, B, Np), as for the fp32 scratch."""
+    """volt_potrf_ws_f64 on a prepared [B,Np,Np] fp64 buffer (the factor replaces it)."""
     B, Np = A.shape[0], A.shape[1]
-    L = _lib.lib()
-    nbytes = int(L.volt_potrf_workspace_bytes_f64(B, Np))
-    wp = None
-    if nbytes:
-        key = (A.device.index, _lib.stream_ptr(), B, Np, "f64")
-        buf = _POTRF_WS.get(key)
-        if buf is None:
-            if len(_POTRF_WS) >= 8:
-                _POTRF_WS.pop(next(iter(_POTRF_WS)))
-            buf = _POTRF_WS[key] = torch.empty(nbytes + 256, dtype=torch.uint8, device=A.device)
-        wp = ((buf.data_ptr() + 255) // 256) * 256
-    _lib.check(L.volt_potrf_ws_f64(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, wp, nbytes, _lib.stream_ptr()),
+    wp, nbytes = _potrf_ws_f64(B, Np, A.device)
+    _lib.check(_lib.lib().volt_potrf_ws_f64(A.data_ptr(), Winv.data_ptr(), info.data_ptr(), B, Np, wp, nbytes, _lib.stream_ptr()),
                "volt_potrf")
 
 
@@ -164,10 +168,10 @@ def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0
                                       Winv.data_ptr(), info.data_ptr(), B, n, wp, nbytes,
                                       _lib.WS_INITIALISED if wp else 0, st), "volt_potrf_k")
     else:
-        _lib.check(L.volt_prepare_f64(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(), B, n, st),
-                   "volt_prepare")
-        # a few KB of progress words where the shape runs as one launch (small batches; csrc/batch64_step.hip)
-        potrf_f64_inplace(A, Winv, info)
+        # straight from K where the shape runs as one launch (small / medium batches); prepare + launch-per-column otherwise
+        wp, nbytes = _potrf_ws_f64(B, Np, K.device)
+        _lib.check(L.volt_potrf_k_f64(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(), Winv.data_ptr(),
+                                      info.data_ptr(), B, n, wp, nbytes, st), "volt_potrf_k")
     return CholeskyFactor(A, Winv, info, n)
 
 
