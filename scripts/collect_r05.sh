@@ -43,7 +43,7 @@ tables)
   python scripts/resource_usage.py > $OUT/resource_usage.txt 2>/dev/null;;
 fp64)
   python scripts/batch64_gate_sweep.py $OUT/batch64_gate_sweep.txt 2>&1 | grep -v amdgpu.ids | tail -3
-  SHAPES=32x4096,48x4096,64x4096,32x3072,48x3072,48x2048,64x2048,96x2048,64x1024,128x1024,256x512,64x399 python scripts/batch64_gate_sweep.py $OUT/batch64_gate_sweep_large.txt 2>&1 | grep -v amdgpu.ids | tail -3
+  SHAPES=32x4096,48x4096,64x4096,96x4096,32x3072,48x3072,96x3072,48x2048,64x2048,96x2048,192x2048,64x1024,128x1024,256x1024,256x512,512x512,64x399 python scripts/batch64_gate_sweep.py $OUT/batch64_gate_sweep_large.txt 2>&1 | grep -v amdgpu.ids | tail -3
   python scripts/batch64_check.py 1x512 2x1000 5x300 1x4096 3x2048 8x1024 8x4096 24x700 --reps-check 5 2>&1 | grep -v amdgpu.ids > $OUT/batch64_check.txt; tail -3 $OUT/batch64_check.txt | cut -c1-200
   (python scripts/batch64_stamps.py 1x4096 potrf; python scripts/batch64_stamps.py 8x4096 step | head -16) 2>&1 | grep -v amdgpu.ids > $OUT/batch64_stamps.txt
   python scripts/tune_diag64.py 2>&1 | grep -v amdgpu.ids > $OUT/diag64_phases.txt

@@ -344,7 +344,7 @@ bool volt_internal_batch64_applies(int B, int n, int has_y) {
     if (tn.batch64 <= 0 || B < 1 || n < 2 || B > 65535) return false;
     if (tn.batch64 >= 2) return true;
     const int64_t tiles = (int64_t)B * (n + 1);
-    if (has_y) return tiles <= (n >= 24 ? tn.batch64_max_step : 1700);
+    if (has_y) return tiles <= (n >= 24 ? tn.batch64_max_step : tn.batch64_max);
     return tiles <= tn.batch64_max;
 }
 

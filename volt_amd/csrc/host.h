@@ -31,8 +31,8 @@ struct Tunables {
     int batch_lad = 0;                         // ... its look-ahead tiles listed this many block columns early (batch_sched.h).  Measured, ms/step at lad 0 / 1 / 2 / 3: 8 x 4096 3.64 / 3.65 / 3.68 / 3.69, 16 x 4096 5.94 / 5.95 / 6.00 / 6.13, 64 x 4096 21.95 / 21.98 / 21.99 / 22.01: no gain, off
     int batch_spread = 400;                    // ... with up to this many tiles per block column, B (n + 1), it runs ONE workgroup per CU.  ms/step two per CU -> one per CU at N = 4096: B = 2 1.90 -> 1.66, 4 2.57 -> 2.10, 8 3.64 -> 3.37, 12 4.80 -> 4.82, 16 5.89 -> 6.16, 24 8.51 -> 9.17; at N = 2048: B = 8 0.99 -> 0.82, 16 1.28 -> 1.11.  Shorter series cross over later (their tiles are shorter, the chain weighs more): + 9 tiles per block column short of 32 -- 24 x 2048 (408 tiles) 1.59 -> 1.48, 32 x 2048 (544) 1.840 -> 1.836, 64 x 2048 (1088) 3.26 -> 3.52; 32 x 1536 (416) 1.02 -> 0.92; 64 x 1024 (576) 0.70 -> 0.67, 40 x 1024 0.58 -> 0.48; 16 x 3072 (400) 2.92 -> 2.87, 24 x 3072 (600) 3.97 -> 4.21
     int batch64 = 1;                           // the fp64 factorisation / gradient step in one launch (batch64_step.hip): 0 off, 1 where measured faster, 2 wherever it can run
-    int batch64_max = 2000;                    // ... up to this many tiles per block column, B (n + 1) (one workgroup per CU: the diagonal block's 133 KB image).  Measured against chol64.hip's schedules (profiles/r05/batch64_gate_sweep.txt): the factorisation 1.02 - 2.07 x at every shape tried, 1 .. 48 matrices of N = 512 .. 4096 (64 x 4096, 2112 tiles: 0.99); the gradient step 1.01 - 1.85 x up to 32 x 4096 / 96 x 2048 and 0.97 - 0.98 at 48 and 64 x 4096: its limit is batch64_max_step from 24 block columns on, 1700 below
-    int batch64_max_step = 1100;
+    int batch64_max = 3300;                    // ... up to this many tiles per block column, B (n + 1) (one workgroup per CU: the diagonal block's 133 KB image).  Measured against chol64.hip's schedules (profiles/r05/batch64_gate_sweep.txt, _large.txt): the factorisation 1.06 - 2.17 x at every shape tried, 1 .. 512 matrices of N = 512 .. 4096 (up to 3264 tiles); the gradient step 1.01 - 1.90 x (96 x 4096, 3168 tiles: 1.01; 96 x 3072, 2400: 1.05): its limit from 24 block columns on is batch64_max_step
+    int batch64_max_step = 2500;
     int batch_local = 1;                       // ... batches that are a multiple of 8 hand their tiles on through the XCD's L2 (0: the agent-scope protocol everywhere)
 };
 // (the struct continues: what the device looks like, and what follows from it)
