@@ -68,10 +68,23 @@ __device__ __forceinline__ void alpha_item(const float* __restrict__ Y, const Tr
                                            float* __restrict__ apart, int Np, int b, int c, int chunk) {
     const int n = Np / TS, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
     f32x4 zc = {0.f, 0.f, 0.f, 0.f};
-    for (int jb = 0; jb <= c; ++jb) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(red.zpart + ((int64_t)b * n + jb) * Np + c * TS + 4 * l31);
+    {   // eight loads in flight, added in the order of ever (jb ascending): one at a time this was up to 32 round trips per piece
+        const float* zp = red.zpart + (int64_t)b * n * Np + c * TS + 4 * l31;
+        int jb = 0;
+        for (; jb + 8 <= c + 1; jb += 8) {
+            f32x4 v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) zc[e] += v[e];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(zp + (int64_t)(jb + u) * Np);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zc[e] += v[u][e];
+        }
+        for (; jb <= c; ++jb) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(zp + (int64_t)jb * Np);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zc[e] += v[e];
+        }
     }
     if (chunk == 0 && wave == 0 && h == 0) *reinterpret_cast<f32x4*>(z + (int64_t)b * Np + c * TS + 4 * l31) = zc;
     const float* Yc = Y + (int64_t)b * Np * Np + c * TS + 4 * l31 + (int64_t)h * Np;
