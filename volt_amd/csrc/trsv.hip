@@ -11,9 +11,12 @@
 // loads are issued before the wait for the current tile's dependency, so what remains on the critical path per
 // hop is: flag seen -> acquire -> 512 B of solution -> FMAs -> LDS reduction -> W_i product -> publish.
 //
-// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16): producer stores its block with plain stores,
-// drains, __syncthreads, lane 0 releases at agent scope and sets flag[b][i]; a consumer polls that one word relaxed
-// from one lane, then ONE agent-scope acquire, __syncthreads, plain loads.  Block indices are handed out by an
+// Inter-workgroup protocol: a solution block is 128 values -- the producer stores it WRITTEN THROUGH (agent-scope relaxed
+// atomic stores = sc1), every storing thread drains, __syncthreads, lane 0 sets flag[b][i]; a consumer polls that one word
+// relaxed from one lane, __syncthreads, and fetches the block with agent-scope (sc1) loads.  (Rounds 1-4 had plain stores
+// behind an agent-scope release and plain loads behind an acquire -- Guideline 16 of cdna_hip_programming.md -- which puts an
+// L2 write-back and an L2 / L1 invalidate on every hop of the chain: 8 x 4096 in fp32 4.1 us per hop against 3.0 now, in fp64
+// 7.4 against 6.2; 64 x 2048 0.194 -> 0.139 ms per solve; scripts/bench_trsv.py.)  Block indices are handed out by an
 // atomic ticket in dependency order (all matrices' block 0 first, ...), so a workgroup only ever waits for
 // workgroups that started before it: no co-residency or dispatch-order assumption.  Every spin is bounded by wall
 // clock; a time-out poisons the output with NaN instead of hanging and raises sync[1], the error word the caller can
@@ -32,21 +35,15 @@ template <> struct V16<double> { typedef f64x2 type; static constexpr int N = 2;
 __device__ __forceinline__ bool trsv_wait(const int* flag) {
     // one lane polls one word, relaxed, agent scope (bounded by wall clock, common.h); then one acquire for the workgroup
     bool ok = true;
-    if (threadIdx.x == 0) {
-        ok = wait_nonzero(flag, 2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
+    if (threadIdx.x == 0) ok = wait_nonzero(flag, 2);           // (no acquire: the block it announces is fetched with sc1 loads)
     return ok;      // meaningful in thread 0 only
 }
 
 __device__ __forceinline__ void trsv_publish(int* flag) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its stores
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the compiler may drop the fence's own wait
-        __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // (no release: the block went out written through -- sc1 -- and every storing thread has drained)
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Lane mapping of a 128 x CW sub-tile (CW = 32 VEC columns): lane = (half = l >> 5, lc = l & 31); wave w owns rows
@@ -144,7 +141,7 @@ __global__ __launch_bounds__(256) void trsv_kernel(const T* __restrict__ A, cons
                     atomicOr(&sync[1], 1);                  // the error word of the C ABI: this solve timed out
                 }
                 __syncthreads();                            // the acquire covers the workgroup
-                if (tid < TS) sV[dep & 1][tid] = ob[m * TS + tid];
+                if (tid < TS) sV[dep & 1][tid] = __hip_atomic_load(&ob[m * TS + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __syncthreads();
             }
             const T* v = sV[dep & 1];
@@ -197,7 +194,7 @@ __global__ __launch_bounds__(256) void trsv_kernel(const T* __restrict__ A, cons
     if (j < total) consume(bufA, j);
     // sV[0] is still being read by slower waves of the W phase: the barriers inside finish_phase order that
     finish_phase(false);                                    // sV[0] = the solution block
-    if (tid < TS) ob[i * TS + tid] = sFail ? (T)__builtin_nanf("") : sV[0][tid];
+    if (tid < TS) __hip_atomic_store(&ob[i * TS + tid], sFail ? (T)__builtin_nanf("") : sV[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     trsv_publish(flags + i);
 }
 
