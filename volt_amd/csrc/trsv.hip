@@ -22,6 +22,7 @@
 // clock; a time-out poisons the output with NaN instead of hanging and raises sync[1], the error word the caller can
 // read back.  sync[] (ticket, error word, flags) is zeroed by the launcher.
 #include "common.h"
+#include "host.h"
 #include "../../include/volt_hip.h"
 
 namespace volt {
@@ -48,7 +49,10 @@ __device__ __forceinline__ void trsv_publish(int* flag) {
 
 // Lane mapping of a 128 x CW sub-tile (CW = 32 VEC columns): lane = (half = l >> 5, lc = l & 31); wave w owns rows
 // 32 w .. 32 w + 31; load s (0..15) of a lane is row 32 w + 2 s + half, columns VEC lc .. VEC lc + VEC - 1.
-template <typename T, bool TRANS>
+// PREW: the NH sub-tiles of W_i -- they depend on nothing -- are requested at the very start and kept in registers (64 / 128
+// VGPRs), instead of behind the last dependency's tile: their load latency comes off every hop of the chain.  The host picks
+// it for the forward fp64 solve of launches of at most two workgroups per CU (launch_trsv: where it was measured to pay).
+template <typename T, bool TRANS, bool PREW>
 __global__ __launch_bounds__(256) void trsv_kernel(const T* __restrict__ A, const T* __restrict__ Winv,
                                                    const T* rhs, T* out, int* __restrict__ sync, int Np, int B) {
     typedef typename V16<T>::type vec_t;
@@ -183,15 +187,32 @@ __global__ __launch_bounds__(256) void trsv_kernel(const T* __restrict__ A, cons
         }
     };
 
-    load(bufA, 0);
-    int j = 0;
-    for (; j + 1 < total; j += 2) {
-        load(bufB, j + 1);
-        consume(bufA, j);
-        if (j + 2 < total) load(bufA, j + 2);
-        consume(bufB, j + 1);
+    if constexpr (PREW) {
+        vec_t bufW[NH][16];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) load(bufW[h], nl + h);
+        int j = 0;
+        if (nl > 0) load(bufA, 0);
+        for (; j + 1 < nl; j += 2) {
+            load(bufB, j + 1);
+            consume(bufA, j);
+            if (j + 2 < nl) load(bufA, j + 2);
+            consume(bufB, j + 1);
+        }
+        if (j < nl) consume(bufA, j);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) consume(bufW[h], nl + h);
+    } else {
+        load(bufA, 0);
+        int j = 0;
+        for (; j + 1 < total; j += 2) {
+            load(bufB, j + 1);
+            consume(bufA, j);
+            if (j + 2 < total) load(bufA, j + 2);
+            consume(bufB, j + 1);
+        }
+        if (j < total) consume(bufA, j);
     }
-    if (j < total) consume(bufA, j);
     // sV[0] is still being read by slower waves of the W phase: the barriers inside finish_phase order that
     finish_phase(false);                                    // sV[0] = the solution block
     if (tid < TS) __hip_atomic_store(&ob[i * TS + tid], sFail ? (T)__builtin_nanf("") : sV[0][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -214,7 +235,14 @@ static int launch_trsv(const T* A, const T* Winv, const T* rhs, T* out, T* scrat
     int* sync = reinterpret_cast<int*>(scratch);
     hipError_t e = hipMemsetAsync(sync, 0, sizeof(int) * (size_t)(2 + (size_t)B * n), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((trsv_kernel<T, TRANS>), dim3(n * B), dim3(256), 0, s, A, Winv, rhs, out, sync, Np, B);
+    // W_i ahead of the chain: measured (scripts/bench_trsv.py) 1 x 4096 fp64 forward 0.149 -> 0.114 ms, 8 x 4096 0.197 -> 0.146;
+    // the fp64 transposed solve gets SLOWER (its column-wise partial sums and 128 more registers spill: 0.127 -> 0.165) and
+    // the fp32 solves do not change (0.089 / 0.080): the forward fp64 solve only
+    constexpr bool prew = sizeof(T) == 8 && !TRANS;
+    if (prew && n * B <= 2 * tunables().cus)
+        hipLaunchKernelGGL((trsv_kernel<T, TRANS, prew>), dim3(n * B), dim3(256), 0, s, A, Winv, rhs, out, sync, Np, B);
+    else
+        hipLaunchKernelGGL((trsv_kernel<T, TRANS, false>), dim3(n * B), dim3(256), 0, s, A, Winv, rhs, out, sync, Np, B);
     VOLT_LAUNCH_CHECK();
     return 0;
 }
