@@ -92,7 +92,7 @@ __device__ __forceinline__ void alpha_item(const float* __restrict__ Y, const Tr
     const int r0 = chunk * BATCH_ALPHA_ROWS;
     const int r1 = (r0 + BATCH_ALPHA_ROWS < (c + 1) * TS) ? r0 + BATCH_ALPHA_ROWS : (c + 1) * TS;
     // a wave takes 32 consecutive rows per pass as 16 row pairs (r + 2 u + h), all sixteen loads in flight: the stream is
-    // latency-bound otherwise (four in flight: 280 us per piece)
+    // latency-bound otherwise (four in flight: 280 us per piece; thirty-two: no faster than sixteen)
     for (int r = r0 + 32 * wave; r < r1; r += 128) {
         f32x4 y[16];
 #pragma unroll
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
                                                            float* __restrict__ zvec, float* __restrict__ apart,
                                                            long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
+    __shared__ float srv[TS];                                // a tile of the inverse: the residuals of its block row (trtri_reduce)
     const int n = Np / TS;
     if (stamps && threadIdx.x == 0) {
         stamps[(int64_t)blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime();
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
     } else {
         const int i = d.y, j = d.z;
         jb = trtri_job(A, Winv, Y, Np, i, j, b);
+        if (red.rpad && threadIdx.x < TS) srv[threadIdx.x] = red.rpad[(int64_t)b * Np + j * TS + threadIdx.x];   // (read behind the pipeline's barriers)
         jb.t.flag = reinterpret_cast<const int*>(jb.t.W);    // W_i comes from a workgroup of this launch too
         jb.t.ch.p0 = rowp + i;                               // X = L[i, j ..]: block m is L[i, j + m]
         jb.t.ch.base0 = j;
@@ -232,11 +234,17 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
     job_t0(jb, T);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     const bool ok = tri_tile_run<true, LOCAL>(jb.t, T, O, smem, &pre);
+#ifndef VOLT_NO_EPILOGUE_PRIO
+    // The epilogue -- reductions, the tile through LDS, the drain -- is a few hundred instructions that, beside a co-resident
+    // tile in its K loop, took 9 + 6 us instead of 1 + 1.3 (profiles/r05/batch_stamps.txt: 64 x 4096 against 8 x 4096): raised
+    // above that tile's waves they are issued when they are ready, and the slot turns over sooner.
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);   // a hand-off timed out: internal error
     // the reductions of a tile of the inverse first (they read the accumulators and use LDS behind the tile image), then
     // the tile: its stores are the last thing before the drain
-    if (jb.i >= 0 && red.rpad) trtri_reduce<!LOCAL>(O, Np, jb.i, jb.j, jb.b, red, smem + TS * WLD);
+    if (jb.i >= 0 && red.rpad) trtri_reduce<!LOCAL>(O, Np, jb.i, jb.j, jb.b, red, smem + TS * WLD, srv);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     tri_store_lds<LOCAL ? 0 : AUX_WT>(O, jb.out, Np, smem);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();

@@ -784,16 +784,23 @@ __device__ __forceinline__ void trtri_diag_body(const float* __restrict__ Winv, 
 // stored written through at agent scope (batch_step.hip: a workgroup of the same launch, possibly on another XCD, adds
 // them up behind the tile's progress word).
 template <bool WT = false>
+// rvs (optional): the 128 residuals of block row j already in LDS (batch_step.hip parks them there at the tile's entry) -- beside a
+// co-resident tile in its K loop the sixteen gather loads per lane below queue behind that tile's buffer loads for microseconds
 __device__ __forceinline__ void trtri_reduce(const f32x16 (&O)[4], int Np, int i, int j, int b, TriReduce red,
-                                             float* smem) {
+                                             float* smem, const float* rvs = nullptr) {
     const int n = Np / TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int tile_id = i * (i + 1) / 2 + j;
     // rows of this block row are all < N (only block row n-1 is padded, and that is a diagonal tile)
     const float* rv = red.rpad + (int64_t)b * Np + j * TS + wave * 32;
     float rvq[16];
+    if (rvs) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) rvq[q] = rv[accrow(q, lane)];
+        for (int q = 0; q < 16; ++q) rvq[q] = rvs[wave * 32 + accrow(q, lane)];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rvq[q] = rv[accrow(q, lane)];
+    }
     float* sz = smem;                                 // [4 waves][128]  (tri_tile_run ended with a barrier)
     float ff = 0.f;
 #pragma unroll
