@@ -54,9 +54,24 @@ constexpr int AUX_WT = AUX_SC1;                // sc1: written through at agent 
 __device__ __forceinline__ void diag0_image(const KSource& src, int b, float* smem) {
     const float add = (src.sigma2 ? src.sigma2[b] : 0.f) + src.jitter;
     const float* Kb = src.K + (int64_t)b * src.bsk;
-    for (int e = threadIdx.x; e < TS * TS; e += NT) {
-        const int r = e >> 7, c = e & 127;
-        smem[r * DT + c] = (c <= r) ? input_elem(src, Kb, add, nullptr, 0, true, r, c) : 0.f;
+    // sixteen loads in flight per thread (clamped addresses; padding, diagonal and upper triangle selected afterwards) -- one
+    // element at a time this was 64 round trips in front of the first pivot of every matrix of the step
+    const int N = src.N;
+#pragma unroll 1
+    for (int e0 = threadIdx.x; e0 < TS * TS; e0 += 16 * NT) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + u * NT, r = e >> 7, c = e & 127;
+            v[u] = Kb[(int64_t)(r < N ? r : N - 1) * src.ldk + (c < N ? c : N - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = e0 + u * NT, r = e >> 7, c = e & 127;
+            float x = (r < N && c < N) ? v[u] : 0.f;
+            if (r == c) x = (r < N) ? x + add : 1.f;
+            smem[r * DT + c] = (c <= r) ? x : 0.f;
+        }
     }
 }
 
