@@ -761,9 +761,11 @@ __device__ __forceinline__ void trtri_diag_body(const float* __restrict__ Winv, 
     }
     if (red.rpad) {
         float* sred = smem + TS * WLD;               // 128 floats behind the W image
+        float* rv = sred + TS;                       // the residuals of block row i, staged: read from memory inside the loop
+        if (tid < TS) rv[tid] = red.rpad[(int64_t)b * Np + i * TS + tid];   // below they were up to 128 round trips per thread
+        __syncthreads();                             // (78 us per diagonal tile beside busy neighbours, 64 x 4096)
         float fz = 0.f, ff = 0.f;
         if (tid < TS) {
-            const float* rv = red.rpad + (int64_t)b * Np + i * TS;
             for (int c = 0; c <= tid; ++c) {         // column r = tid of Y: entries W[r][c], c <= r
                 const float y = smem[tid * WLD + c];
                 fz += y * rv[c];
