@@ -129,3 +129,24 @@ def test_not_positive_definite_is_reported_per_matrix(ops):
     ops.mll_step(K, r, s2, ws)
     info = ws.info.cpu().numpy()
     assert info[3] == 701 and (np.delete(info, 3) == 0).all()
+
+
+@pytest.mark.parametrize("B,n", [(16, 4096), (3, 2560), (64, 2048), (8, 1500)])
+def test_two_call_factorisation_equals_the_one_straight_from_k(ops, B, n):
+    """volt_prepare_f32 + volt_potrf_ws_f32 (a caller that keeps its own prepared copy) runs the same one launch as
+    volt_potrf_k_f32 -- its tiles read their input from A itself -- and gives the same factor bit for bit."""
+    from volt_amd import _lib
+    L = _lib.lib()
+    x, vol, y, mean = _series_problem(B, n)
+    K = ops.fill(ops.cumtrapz(dev(vol), dev(x), square=True))
+    s2 = torch.full((B,), SIG2, device="cuda")
+    f = ops.potrf(K, s2)
+    Np = ops.padded_n(n)
+    wp, nbytes = ops._potrf_workspace(B, Np, K.device)
+    assert wp is not None
+    A, W, info = torch.empty_like(f.A), torch.empty_like(f.Winv), torch.empty_like(f.info)
+    st = _lib.stream_ptr()
+    _lib.check(L.volt_prepare_f32(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n, st), "prepare")
+    _lib.check(L.volt_potrf_ws_f32(A.data_ptr(), W.data_ptr(), info.data_ptr(), B, Np, wp, nbytes, _lib.WS_INITIALISED, st), "potrf")
+    assert int(info.abs().sum()) == 0 and int(f.info.abs().sum()) == 0
+    assert torch.equal(torch.tril(A), torch.tril(f.A)) and torch.equal(W, f.Winv)

@@ -1159,6 +1159,16 @@ int volt_potrf_ws_f32(float* A, float* Winv, int* info, int B, int Np, void* ws,
     if (ws) {
         if (((uintptr_t)ws & 255) != 0) return -6;
         if (ws_bytes < need) return -7;
+        // the whole factorisation in one launch (batch_step.hip: the tiles read their input from A itself), on the caller's word
+        // that the init ran on this scratch -- the same schedule, and so the same bits, as volt_potrf_k_f32 on the same matrix
+        const size_t bb = volt_internal_batch_bytes(B, Np / TS, 0);
+        if (bb && (ws_flags & VOLT_WS_INITIALISED)) {
+            const int rc = volt_internal_batch_step(nullptr, 0, 0, nullptr, 0.f, A, Winv, nullptr, info, nullptr, nullptr, nullptr, B, Np,
+                                                    nullptr, nullptr, reinterpret_cast<char*>(ws) + potrf_ws_sched_bytes(B, Np), bb,
+                                                    stream, nullptr, nullptr);
+            if (rc == 1) return 0;
+            if (rc) return rc > 0 ? rc : -8;
+        }
         if (potrf_ws_sched_bytes(B, Np)) {                       // K-slices and the balanced schedule
             sk.slab = reinterpret_cast<float*>(ws);
             sk.count = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + potrf_ws_slab_bytes(B, Np));
