@@ -50,6 +50,18 @@ def test_argument_validation_without_a_device():
     assert L.volt_potrf_workspace_bytes(65, 4096) == batch(65, 32)        # above 64 matrices: no slabs, the piece list alone
     assert L.volt_batch_describe(8, 32, 0, 0, None, 0) == pieces(8, 32)
     assert L.volt_potrf_workspace_bytes(64, 4096) > 128 * 33 * 65536
+    # the fp64 twins (round 5: the one-launch schedule's progress words; csrc/batch64_step.hip)
+    assert L.volt_potrf_ws_f64(1, 1, 1, 1, 100, None, 0, None) == -5
+    assert L.volt_potrf_ws_f64(1, 1, 1, 1, 128, 3, 4096, None) == -6                  # scratch not 256-byte aligned
+    assert L.volt_potrf_k_f64(None, 8, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, None) == -1
+    assert L.volt_potrf_k_f64(1, 4, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, None) == -2    # row stride shorter than N
+    assert L.volt_potrf_k_f64(1, 8, 64, None, 0.0, None, 1, 1, 1, 8, None, 0, None) == -6
+    assert L.volt_potrf_workspace_bytes_f64(1, 100) == 0 and L.volt_potrf_workspace_bytes_f64(1, 128) == 0   # one block column: nothing to hand on
+    words = lambda B, n: (B * ((4 * n + 1 + 31) // 32 * 32) * 4 + 255) // 256 * 256
+    assert L.volt_potrf_workspace_bytes_f64(1, 4096) == words(1, 32) and L.volt_potrf_workspace_bytes_f64(8, 1024) == words(8, 8)
+    assert L.volt_potrf_workspace_bytes_f64(512, 4096) == 0                           # beyond the measured range: launch per block column
+    assert (L.volt_mll_workspace_bytes_f64(8, 4096, 1) - L.volt_mll_workspace_bytes_f64(8, 4096, 0)
+            >= 8 * 4096 * 4096 * 8 + 8 * 528 * 8)                                    # + Y, one norm partial per tile
     assert L.volt_mll_workspace_bytes(64, 4096, 1) > L.volt_mll_workspace_bytes(64, 4096, 0) > 0
     # the one-launch step for short series keeps its state and alpha's partial sums in the workspace: there for
     # the shapes it takes (few series of N <= 1024, gradient step), absent where the library keeps the launch-per-column path
