@@ -45,7 +45,8 @@ def test_argument_validation_without_a_device():
     # round 5: + the one-launch factorisation's piece list (16 B per piece, 16-slot header) and progress words (3 n ints per matrix)
     pieces = lambda B, n: B * sum(1 + (1 if 1 <= k <= n - 2 else 0) + (n - k - 1) for k in range(n))
     al = lambda b: (b + 255) // 256 * 256
-    batch = lambda B, n: al((16 + pieces(B, n)) * 16) + al(B * ((3 * n + 31) // 32 * 32) * 4)
+    # round 6: + the queue words of the pullers (8 queues x 32 ints: head and claim of each on a line of its own)
+    batch = lambda B, n: al((16 + pieces(B, n)) * 16) + al((B * ((3 * n + 31) // 32 * 32) + 8 * 32) * 4)
     assert L.volt_potrf_workspace_bytes(8, 4096) == 64 * 33 * 65536 + (33 * 33 * 8 * 4 + 255) // 256 * 256 + tables + batch(8, 32)
     assert L.volt_potrf_workspace_bytes(65, 4096) == batch(65, 32)        # above 64 matrices: no slabs, the piece list alone
     assert L.volt_batch_describe(8, 32, 0, 0, None, 0) == pieces(8, 32)
@@ -57,7 +58,7 @@ def test_argument_validation_without_a_device():
     assert L.volt_potrf_k_f64(1, 4, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, None) == -2    # row stride shorter than N
     assert L.volt_potrf_k_f64(1, 8, 64, None, 0.0, None, 1, 1, 1, 8, None, 0, None) == -6
     assert L.volt_potrf_workspace_bytes_f64(1, 100) == 0 and L.volt_potrf_workspace_bytes_f64(1, 128) == 0   # one block column: nothing to hand on
-    words = lambda B, n: (B * ((4 * n + 1 + 31) // 32 * 32) * 4 + 255) // 256 * 256
+    words = lambda B, n: ((B * ((4 * n + 1 + 31) // 32 * 32) + 8 * 32) * 4 + 255) // 256 * 256   # progress words + the pullers' queue words (round 6)
     assert L.volt_potrf_workspace_bytes_f64(1, 4096) == words(1, 32) and L.volt_potrf_workspace_bytes_f64(8, 1024) == words(8, 8)
     assert L.volt_potrf_workspace_bytes_f64(512, 4096) == 0                           # beyond the measured range: launch per block column
     assert (L.volt_mll_workspace_bytes_f64(8, 4096, 1) - L.volt_mll_workspace_bytes_f64(8, 4096, 0)

@@ -154,27 +154,34 @@ __device__ __forceinline__ void tile64_to_image(const f64x4 (&v)[16], double* __
 // the inverse: W seen [4], second product done [5]
 static long long* g_batch64_stamps = nullptr;
 
-// LOCAL: the batch is a multiple of 8 -- every piece of a matrix runs on ONE XCD (workgroup w on XCD w % 8, matrix w % B) and
-// that XCD's L2 is where its tiles are handed on: plain stores and a drain, no fences (common.h, LOCALP).
+struct Batch64Args {
+    double* A; double* Winv; double* Y; int* info;
+    int Np, B;
+    int* prog;
+    int pstride;
+    KSource64 src;
+    long long* stamps;
+    int npieces;
+};
+extern __shared__ __attribute__((aligned(16))) double g_sT64[];     // the diagonal block's image / the staging buffers
+static __shared__ int g_piece64;                                     // the piece thread 0 pulled
+
+// One piece of the list.  LOCAL: the batch is a multiple of 8 -- every piece of a matrix runs under ONE XCD's L2 (the pullers read
+// their XCC id and take the matrices of that XCD's queues: common.h) and that L2 is where its tiles are handed on: plain stores
+// and a drain, no fences (common.h, LOCALP).
 template <bool LOCAL>
-__global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ A, double* __restrict__ Winv,
-                                                           double* __restrict__ Y, int* __restrict__ info, int Np, int B,
-                                                           int* __restrict__ prog, int pstride, KSource64 src,
-                                                           long long* __restrict__ stamps) {
-    extern __shared__ __attribute__((aligned(16))) double sT[];
+__device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) {
+    double* const sT = g_sT64;
     float* smem = reinterpret_cast<float*>(sT);
-    const int n = Np / TS, b = blockIdx.x % B;
-    const Piece64 pc = batch64_piece(blockIdx.x / B, n, Y != nullptr);
+    double* const A = a.A; double* const Winv = a.Winv; double* const Y = a.Y; int* const info = a.info;
+    const int Np = a.Np, B = a.B, pstride = a.pstride;
+    int* const prog = a.prog;
+    const KSource64& src = a.src;
+    long long* const stamps = a.stamps;
+    const int n = Np / TS, b = w % B;
+    const Piece64 pc = batch64_piece(w / B, n, Y != nullptr);
 #define VOLT_B64_STAMP(i) \
-    do { if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    VOLT_B64_STAMP(0);
-    if (stamps && threadIdx.x == 0)
-        stamps[(int64_t)blockIdx.x * 8 + 2] = ((long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |
-                                              (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
-    struct Exit {
-        long long* st;
-        __device__ ~Exit() { if (st && threadIdx.x == 0) st[(int64_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
-    } exit_stamp{stamps};
+    do { if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     int* rowp = prog + (int64_t)b * pstride;
     int* tcol = rowp + n;
     int* sub = tcol + n;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
             image = true;
         }
 #ifdef VOLT_B64_DIAG_STAMPS                              // tuning build: the diagonal block's own 32 stamps (s_memtime) behind the pieces'
-        diag64_body<true, LOCAL>(A, Winv, info, Np, i, b, sT, stamps ? stamps + (int64_t)gridDim.x * 8 + 32 * (int64_t)i * B : nullptr,
+        diag64_body<true, LOCAL>(A, Winv, info, Np, i, b, sT, stamps ? stamps + (int64_t)a.npieces * 8 + 32 * (int64_t)i * B : nullptr,
                                  image, sub + i);
 #else
         diag64_body<false, LOCAL>(A, Winv, info, Np, i, b, sT, nullptr, image, sub + i);
@@ -348,6 +355,37 @@ __global__ __launch_bounds__(256) void batch64_step_kernel(double* __restrict__ 
 #undef VOLT_B64_STAMP
 }
 
+template <bool LOCAL>
+__global__ __launch_bounds__(256) void batch64_step_kernel(Batch64Args a, int xskew, int xdrop) {
+    int* const qw = a.prog + (int64_t)a.B * a.pstride;       // the queue words sit behind the progress words
+    const int hw = hw_xcc_id();
+    if (LOCAL && ((xdrop >> hw) & 1)) return;
+    const int xcc = (hw + xskew) & 7;
+    const int per_queue = LOCAL ? a.npieces / 8 : a.npieces;
+    BatchPull pull;
+    // the pullers' loop, hidden from the loop optimiser by a second (never taken) way in: batch_step.hip
+    int w;
+    if (xdrop & 0x40000000) {
+        w = xskew | (int)0x80000000;
+        goto piece;
+    }
+pull_next:
+    __syncthreads();                                         // the last piece's LDS traffic (and its read of g_piece64) is over
+    if (threadIdx.x == 0) g_piece64 = batch_next_piece<LOCAL>(pull, qw, xcc, per_queue);
+    __syncthreads();
+    w = g_piece64;
+piece:
+    w = __builtin_amdgcn_readfirstlane(w);
+    if (w < 0) return;
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[(int64_t)w * 8] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[(int64_t)w * 8 + 2] = ((long long)hw << 32) | (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+    }
+    batch64_piece<LOCAL>(a, w);
+    if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)w * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    goto pull_next;
+}
+
 }  // namespace volt
 
 using namespace volt;
@@ -365,7 +403,7 @@ bool volt_internal_batch64_applies(int B, int n, int has_y) {
 
 size_t volt_internal_batch64_bytes(int B, int n, int has_y) {
     if (!volt_internal_batch64_applies(B, n, has_y)) return 0;
-    return ((size_t)B * batch64_pstride(n) * sizeof(int) + 255) & ~(size_t)255;
+    return (((size_t)B * batch64_pstride(n) + BATCH_QWORDS) * sizeof(int) + 255) & ~(size_t)255;   // progress words, then the pullers' queue words
 }
 
 // Returns 1 when the step was enqueued, 0 when the shape is not this schedule's (nothing enqueued), a HIP error otherwise.
@@ -378,26 +416,30 @@ int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, in
     if (!state || !volt_internal_batch64_applies(B, n, has_y) || state_bytes < volt_internal_batch64_bytes(B, n, has_y)) return 0;
     hipStream_t s = (hipStream_t)stream;
     int* prog = reinterpret_cast<int*>(state);
-    const int pstride = batch64_pstride(n), nprog = B * pstride;
+    const int pstride = batch64_pstride(n), nprog = B * pstride + BATCH_QWORDS;
     int blocks = (std::max(B, nprog) + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks * 256 < B) blocks = (B + 255) / 256;
     hipLaunchKernelGGL(batch64_begin_kernel, dim3(blocks), dim3(256), 0, s, info, B, prog, nprog);
+    // eight queues, one per XCD, when the matrices divide among them evenly (the pullers read their XCC id: common.h)
     const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;
-    const unsigned grid = (unsigned)batch64_count(B, n, Y != nullptr);
+    const int64_t npieces = batch64_count(B, n, Y != nullptr);
+    if (npieces > 0x7fffffff) return 0;
+    // as many pullers as the chip holds at once: one per CU (the image's LDS); nothing depends on the number
+    const unsigned grid = (unsigned)std::min<int64_t>(npieces, tunables().batch_pullers > 0 ? (int64_t)tunables().cus * tunables().batch_pullers : npieces);
+    const Batch64Args args{A, Winv, Y, info, Np, B, prog, pstride, src, g_batch64_stamps, (int)npieces};
+    const int xskew = tunables().batch_xskew, xdrop = tunables().batch_xdrop;
     hipError_t e;
     if (local) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, Y, info, Np, B, prog,
-                           pstride, src, g_batch64_stamps);
+        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, A, Winv, Y, info, Np, B, prog,
-                           pstride, src, g_batch64_stamps);
+        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
     }
     e = hipGetLastError();
     return e != hipSuccess ? (int)e : 1;

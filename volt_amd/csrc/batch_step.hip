@@ -128,40 +128,46 @@ __device__ __forceinline__ void alpha_item(const float* __restrict__ Y, const Tr
 // the two-phase tiles the time the pipeline is entered and left
 static long long* g_batch_stamps = nullptr;
 
-// LOCAL: the batch is a multiple of 8, so every piece of a matrix runs on ONE XCD (piece w on XCD w % 8, matrix w % 8 mod
-// 8) and that XCD's L2 is where its tiles are handed on: plain (non-temporal) stores, acknowledged by the L2, instead of
-// write-through to memory -- the word of a tile follows its stores after ~1 us instead of ~10.
+// (who runs which piece -- the pullers, their queues and BATCH_QWORDS: common.h)
+struct BatchArgs {
+    float* A; float* Winv; float* Y; int* info;
+    int Np, B;
+    KSource src;
+    TriReduce red;
+    const int4* tab;
+    int* prog;
+    int pstride;
+    float* zvec; float* apart;
+    long long* stamps;
+};
+
+// LDS of the step kernel
+static __shared__ __attribute__((aligned(16))) float g_smem[2 * STAGE_FLOATS];
+static __shared__ float g_srv[TS];                           // a tile of the inverse: the residuals of its block row (trtri_reduce)
+static __shared__ int g_piece;                               // the piece thread 0 pulled
+
+// One piece of the list.  LOCAL: the hand-offs of this piece's matrix all happen under this workgroup's L2 (see above):
+// plain (non-temporal) stores, acknowledged by the L2, instead of write-through to memory -- the word of a tile follows its
+// stores after ~1 us instead of ~10.
 template <bool FROMK, bool LOCAL>
-__global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
-                                                           float* __restrict__ Y, int* __restrict__ info, int Np, int B,
-                                                           KSource src, TriReduce red, const int4* __restrict__ tab,
-                                                           int* __restrict__ prog, int pstride, int check,
-                                                           float* __restrict__ zvec, float* __restrict__ apart,
-                                                           long long* __restrict__ stamps) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    __shared__ float srv[TS];                                // a tile of the inverse: the residuals of its block row (trtri_reduce)
+__device__ __forceinline__ void batch_piece(const BatchArgs a, const int w) {
+    float* const smem = g_smem;
+    float* const srv = g_srv;
+    float* const A = a.A; float* const Winv = a.Winv; float* const Y = a.Y; int* const info = a.info;
+    const int Np = a.Np;
+    const KSource& src = a.src;
+    const TriReduce& red = a.red;
+    long long* const stamps = a.stamps;
     const int n = Np / TS;
-    if (stamps && threadIdx.x == 0) {
-        stamps[(int64_t)blockIdx.x * 8] = __builtin_amdgcn_s_memrealtime();
-        stamps[(int64_t)blockIdx.x * 8 + 2] = ((long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |
-                                              (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
-    }
-    struct Exit {                                            // every return path leaves its time behind
-        long long* st;
-        __device__ ~Exit() { if (st && threadIdx.x == 0) st[(int64_t)blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime(); }
-    } exit_stamp{stamps};
-    {   // the caller's scratch must hold the table this launch was sized for: anything else is reported, never followed
-        const int4 h0 = tab[0];
-        if (h0.x != BATCH_MAGIC || h0.y != B || h0.z != n || h0.w != check) {
-            if (blockIdx.x == 0)
-                for (int b = threadIdx.x; b < B; b += NT) info[b] = (int)0x80000001;
-            return;
-        }
-    }
-    const int4 d = tab[BATCH_HDR + blockIdx.x];
-    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    int4 d = a.tab[BATCH_HDR + w];
+    // (the descriptor arrives in vector registers: said to be uniform HERE, or the compiler may turn every scalar computation
+    // that follows from it -- tile addresses, buffer descriptors -- into per-lane code with a waterfall loop around each load)
+    d.x = __builtin_amdgcn_readfirstlane(d.x);
+    d.y = __builtin_amdgcn_readfirstlane(d.y);
+    d.z = __builtin_amdgcn_readfirstlane(d.z);
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     const int kind = d.x & 7, b = d.x >> 3;
-    int* rowp = prog + (int64_t)b * pstride;
+    int* rowp = a.prog + (int64_t)b * a.pstride;
     int* tcol = rowp + n;
     int* la = tcol + n;
     int* info_b = info + b;
@@ -185,10 +191,10 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
         }
         // L[k,k-1] (and with it all of row k) is there; k >= 2: the look-ahead part of A[k,k] is parked
         batch_wait<LOCAL>(rowp + k, k, k >= 2 ? la + k : nullptr, 1, info_b);
-        if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 3] = __builtin_amdgcn_s_memrealtime();
         if (k >= 2) update_body<FROMK>(A, Np, k, k, k - 1, k, false, b, src, smem, true);
         else update_body<FROMK>(A, Np, 1, 1, 0, 1, true, b, src, smem, true);
-        if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 4] = __builtin_amdgcn_s_memrealtime();
         diag_body<false, false, LOCAL>(A, Winv, info, Np, k, b, smem, nullptr, true);
         return;
     }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
             acquire_unless_local<LOCAL>();
         }
         __syncthreads();
-        alpha_item(Y, red, zvec, apart, Np, b, c, d.z);
+        alpha_item(Y, red, a.zvec, a.apart, Np, b, c, d.z);
         return;
     }
     // ---- the two-phase tiles
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
     ChasePre pre = {0, 0};
     if (jb.t.n1 > 0) pre = chase_issue<LOCAL>(jb.t.ch);             // the polls go out ahead of the input tile's loads: one round trip
     job_t0(jb, T);
-    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     const bool ok = tri_tile_run<true, LOCAL>(jb.t, T, O, smem, &pre);
 #ifndef VOLT_NO_EPILOGUE_PRIO
     // The epilogue -- reductions, the tile through LDS, the drain -- is a few hundred instructions that, beside a co-resident
@@ -255,15 +261,59 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(float* __restrict__ 
     // above that tile's waves they are issued when they are ready, and the slot turns over sooner.
     __builtin_amdgcn_s_setprio(3);
 #endif
-    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);   // a hand-off timed out: internal error
     // the reductions of a tile of the inverse first (they read the accumulators and use LDS behind the tile image), then
     // the tile: its stores are the last thing before the drain
     if (jb.i >= 0 && red.rpad) trtri_reduce<!LOCAL>(O, Np, jb.i, jb.j, jb.b, red, smem + TS * WLD, srv);
-    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     tri_store_lds<LOCAL ? 0 : AUX_WT>(O, jb.out, Np, smem);
-    if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     batch_publish_wt<LOCAL>(word, val);
+}
+
+template <bool FROMK, bool LOCAL>
+__global__ __launch_bounds__(256, 2) void batch_step_kernel(BatchArgs a, int check, int npieces, int xskew, int xdrop) {
+    {   // the caller's scratch must hold the table this launch was sized for: anything else is reported, never followed
+        const int4 h0 = a.tab[0];
+        if (h0.x != BATCH_MAGIC || h0.y != a.B || h0.z != a.Np / TS || h0.w != check) {
+            if (blockIdx.x == 0)
+                for (int b = threadIdx.x; b < a.B; b += NT) a.info[b] = (int)0x80000001;
+            return;
+        }
+    }
+    int* const qw = a.prog + (int64_t)a.B * a.pstride;       // the queue words sit behind the progress words
+    const int hw = hw_xcc_id();
+    if (LOCAL && ((xdrop >> hw) & 1)) return;
+    const int xcc = (hw + xskew) & 7;
+    const int per_queue = LOCAL ? npieces / 8 : npieces;
+    BatchPull pull;
+    // The pullers' loop -- written so that the optimiser does NOT see a loop.  As `for (;;)` everything a piece kind derives
+    // from the thread index and the arguments (lane offsets, strides, descriptors: of all six kinds) is hoisted out as loop
+    // invariant, kept alive across the tile pipelines and spilled (400 - 1000 VGPRs); as a called function the body saves 112
+    // callee-saved registers per piece.  A second way into the cycle (never taken: the host passes xdrop without bit 30) makes
+    // it irreducible: no loop pass touches it, and the body compiles as round 5's one-piece kernel did (254 VGPRs, no scratch).
+    int w;
+    if (xdrop & 0x40000000) {
+        w = xskew | (int)0x80000000;
+        goto piece;
+    }
+pull_next:
+    __syncthreads();                                         // the last piece's LDS traffic (and its read of g_piece) is over
+    if (threadIdx.x == 0) g_piece = batch_next_piece<LOCAL>(pull, qw, xcc, per_queue);
+    __syncthreads();
+    w = g_piece;
+piece:
+    w = __builtin_amdgcn_readfirstlane(w);
+    if (w < 0) return;
+    __builtin_amdgcn_s_setprio(0);
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[(int64_t)w * 8] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[(int64_t)w * 8 + 2] = ((long long)hw << 32) | (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
+    }
+    batch_piece<FROMK, LOCAL>(a, w);
+    if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)w * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    goto pull_next;
 }
 
 }  // namespace volt
@@ -305,7 +355,9 @@ static int batch_lad(int B) {
 static size_t batch_table_bytes(int B, int n, bool has_y) {
     return ((size_t)(BATCH_HDR + batch_count(B, n, has_y)) * sizeof(BatchItem) + 255) & ~(size_t)255;
 }
-static size_t batch_prog_bytes(int B, int n) { return ((size_t)B * batch_pstride(n) * sizeof(int) + 255) & ~(size_t)255; }
+static size_t batch_prog_bytes(int B, int n) {                 // progress words of every matrix, then the queue words
+    return (((size_t)B * batch_pstride(n) + BATCH_QWORDS) * sizeof(int) + 255) & ~(size_t)255;
+}
 
 size_t volt_internal_batch_bytes(int B, int n, int has_y) {
     if (!volt_internal_batch_applies(B, n, has_y)) return 0;
@@ -314,7 +366,9 @@ size_t volt_internal_batch_bytes(int B, int n, int has_y) {
 
 // the word every piece of a table carries: what the table was built for
 static int batch_check_word(int B, int n, bool has_y) {
-    return BATCH_MAGIC ^ (B * 0x01000193) ^ (n << 20) ^ (has_y ? 0x40000000 : 0) ^ (tunables().batch_order << 28) ^ (batch_lad(B) << 16);
+    const uint32_t w = (uint32_t)BATCH_MAGIC ^ ((uint32_t)B * 0x01000193u) ^ ((uint32_t)n << 20) ^ (has_y ? 0x40000000u : 0u) ^
+                       ((uint32_t)tunables().batch_order << 28) ^ ((uint32_t)batch_lad(B) << 16);
+    return (int)w;
 }
 
 // The table, built once per (B, n, inverse?, order) in pinned host memory and kept for the life of the library (host
@@ -374,26 +428,32 @@ int volt_internal_batch_step(const float* K, int64_t ldk, int64_t bsk, const flo
     hipStream_t s = (hipStream_t)stream;
     const int4* tab = reinterpret_cast<const int4*>(state);
     int* prog = reinterpret_cast<int*>(reinterpret_cast<char*>(state) + batch_table_bytes(B, n, has_y));
-    const int pstride = batch_pstride(n), nprog = B * pstride, nflags = B * n;
+    const int pstride = batch_pstride(n), nprog = B * pstride + BATCH_QWORDS, nflags = B * n;
     int blocks = (std::max(std::max(nflags, B), nprog) + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks * 256 < std::max(nflags, B)) blocks = (std::max(nflags, B) + 255) / 256;
     hipLaunchKernelGGL(batch_begin_kernel, dim3(blocks), dim3(256), 0, s, Winv, nflags, info, B, prog, nprog);
     const int check = batch_check_word(B, n, has_y);
-    const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;   // (workgroup w on XCD w % 8)
+    // eight queues, one per XCD, when the matrices divide among them evenly (the pullers read their XCC id: batch_step_kernel)
+    const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;
     const KSource src{K, ldk, bsk, sigma2, jitter, N};
     const TriReduce red{has_y ? rpad : nullptr, zpart, frob, N};
-    const unsigned grid = (unsigned)batch_count(B, n, has_y);
+    const int64_t npieces = batch_count(B, n, has_y);
     // Few matrices: ONE workgroup per CU (16 KB of dynamic LDS padding).  With two, the diagonal tile -- the latency chain a
     // block column waits for -- shares its CU's LDS and issue slots with a tile in its K loop and takes 80 us instead of 32
     // (8 x 4096 stamps, profiles/r05); alone on the CU it runs at its own pace, and the tiles lose only the few percent
     // that a second resident tile adds to the MFMA duty.
     const int spread = tunables().batch_spread + (n < 32 ? 9 * (32 - n) * tunables().cus / 256 : 0);   // (measured crossovers: host.h)
     const unsigned pad = (int64_t)B * (n + 1) <= spread ? 16 * 1024 : 0;
+    // as many pullers as the chip holds at once (nothing depends on the number: a puller that starts late finds the queues
+    // further on, or dry)
+    const int64_t slots = (int64_t)tunables().cus * (pad ? 1 : 2) * std::max(1, tunables().batch_pullers);
+    const unsigned grid = (unsigned)std::min<int64_t>(npieces, tunables().batch_pullers > 0 ? slots : npieces);
+    const BatchArgs args{A, Winv, Y, info, Np, B, src, red, tab, prog, pstride, z, apart, g_batch_stamps};
+    const int xskew = tunables().batch_xskew, xdrop = tunables().batch_xdrop;
     if (e0 && hipEventRecord(e0, s) != hipSuccess) return (int)hipGetLastError();
-#define VOLT_BATCH_LAUNCH(FK, LC)                                                                                         \
-    hipLaunchKernelGGL((batch_step_kernel<FK, LC>), dim3(grid), dim3(256), pad, s, A, Winv, Y, info, Np, B, src, red, tab, prog, \
-                       pstride, check, z, apart, g_batch_stamps)
+#define VOLT_BATCH_LAUNCH(FK, LC) \
+    hipLaunchKernelGGL((batch_step_kernel<FK, LC>), dim3(grid), dim3(256), pad, s, args, check, (int)npieces, xskew, xdrop)
     if (K && local) VOLT_BATCH_LAUNCH(true, true);
     else if (K) VOLT_BATCH_LAUNCH(true, false);
     else if (local) VOLT_BATCH_LAUNCH(false, true);

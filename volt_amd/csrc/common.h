@@ -815,4 +815,65 @@ __device__ __forceinline__ void batch_publish_wt(int* word, int val) {
 }
 
 
+// ---- who runs which piece (round 6) ------------------------------------------------------------------------------------
+// Round 5 ran piece w as workgroup w and leaned on two things HIP does not promise (MI355X_MICROARCH.md, "Workgroup
+// dispatch, XCD placement"): workgroups start in grid order (deadlock freedom) and workgroup w sits on XCD w % 8 (LOCAL's
+// fence-free hand-offs through one L2).  Now the grid is a set of PULLERS -- as many workgroups as the chip holds at once,
+// though nothing depends on that number -- and a piece is whatever the next ticket of a queue says:
+//   * a waiter only ever waits for a piece with a SMALLER ticket of its own queue (the list is topologically ordered), and
+//     a ticket is taken by a workgroup that is running: whatever is waited for is running or finished, whatever order
+//     and wherever the dispatcher starts workgroups;
+//   * LOCAL (batch a multiple of 8): eight queues, queue q = the pieces of the matrices b = q (mod 8) -- piece 8 t + q of
+//     the list is ticket t of queue q, the list being matrix-innermost.  A workgroup asks the HARDWARE which XCD it is on
+//     (s_getreg HW_REG_XCC_ID) and pulls from the queues that XCD owns; ownership is one compare-and-swap per queue
+//     (claim[q] = XCD + 1): first its own number, and when that queue is dry, any queue nobody has claimed (an XCD that got
+//     no workgroup at all -- a CU mask -- leaves an orphan that the others adopt whole).  So every piece of a matrix runs
+//     under ONE L2 because the workgroups that run them read their own XCC_ID, not because of where workgroup w landed.
+//   * otherwise: one queue, the agent-scope protocol, any workgroup anywhere.
+// Queue words (ints, behind the progress words, cleared with them): head of queue q at [32 q], claim at [32 q + 1].
+constexpr int BATCH_QWORDS = 8 * 32;
+
+// HW_REG_XCC_ID (hwreg 20), bits 3:0: the XCD this wave runs on
+__device__ __forceinline__ int hw_xcc_id() { return (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7; }
+
+// Thread 0's view of the queues: which one it pulls from and how many it has tried to claim (see the block comment above).
+//   xskew (tuning / tests): added to the hardware's XCC id -- the queues then sit on other XCDs than their numbers say;
+//   xdrop (tuning / tests): bit x set = the workgroups on XCD x leave at once, as if a CU mask had emptied it -- their queues
+//   are adopted by the others.
+struct BatchPull {
+    int q = -1, scan = 0;
+};
+template <bool LOCAL>
+__device__ __forceinline__ int batch_next_piece(BatchPull& p, int* __restrict__ qw, int xcc, int per_queue) {
+    for (;;) {
+        if (p.q >= 0) {
+            const int t = __hip_atomic_fetch_add(qw + 32 * p.q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < per_queue) return LOCAL ? 8 * t + p.q : t;
+            p.q = -1;
+        }
+        if (!LOCAL) {
+            if (p.scan) return -1;
+            p.scan = 1;
+            p.q = 0;
+            continue;
+        }
+        while (p.q < 0 && p.scan < 8) {
+            const int cand = (xcc + p.scan) & 7;
+            ++p.scan;
+            int seen = __hip_atomic_load(qw + 32 * cand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (seen == 0) {
+                int expect = 0;
+                if (__hip_atomic_compare_exchange_strong(qw + 32 * cand + 1, &expect, xcc + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT))
+                    seen = xcc + 1;
+                else
+                    seen = expect;
+            }
+            if (seen == xcc + 1) p.q = cand;
+        }
+        if (p.q < 0) return -1;
+    }
+}
+
+
 }  // namespace volt

@@ -34,6 +34,8 @@ struct Tunables {
     int batch64_max = 3300;                    // ... up to this many tiles per block column, B (n + 1) (one workgroup per CU: the diagonal block's 133 KB image).  Measured against chol64.hip's schedules (profiles/r05/batch64_gate_sweep.txt, _large.txt): the factorisation 1.06 - 2.17 x at every shape tried, 1 .. 512 matrices of N = 512 .. 4096 (up to 3264 tiles); the gradient step 1.01 - 1.90 x (96 x 4096, 3168 tiles: 1.01; 96 x 3072, 2400: 1.05): its limit from 24 block columns on is batch64_max_step
     int batch64_max_step = 2500;
     int batch_local = 1;                       // ... batches that are a multiple of 8 hand their tiles on through the XCD's L2 (0: the agent-scope protocol everywhere)
+    int batch_pullers = 1;                     // ... its grid: this many times the workgroups the chip holds at once, pulling pieces by ticket (0: one workgroup per piece -- they pull all the same)
+    int batch_xskew = 0, batch_xdrop = 0;      // ... tests only: the queues of the XCDs shifted by this many (the map is nobody's assumption); bit x set = the pullers on XCD x leave at once (an XCD a CU mask emptied: its queue is adopted)
 };
 // (the struct continues: what the device looks like, and what follows from it)
 const Tunables& tunables();                    // chol.hip: read once per process (VOLT_TUNE=1 only)
