@@ -755,33 +755,37 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256, dist=None, world=1, rank
     res = None
     if dist is None:
         tot_r, ker_r, bad_r, smp_r = run(solve="closed", resubstitute=True)
-        same = bool(torch.equal(smp_c, smp_r))
+        same = float((smp_c - smp_r).abs().max().item())    # (rounds 3 - 5: bitwise; round 6's engine sums w_s'w_s in fp64: to rounding)
         del smp_r
         red = G * S * H ** 3 / 6 * 4
         res = {"total_s": round(tot_r, 5), "kernel_ms": round(ker_r * 1e3, 3), "non_pd_paths": bad_r,
-               "bitwise_equal_to_default": same, "redundant_bytes": int(red),
+               "max_abs_dev_from_default": same, "redundant_bytes": int(red),
                "streamed_GBps": round(red / ker_r / 1e9, 1),
                "frac_of_hbm_peak_on_redundant_bytes": round(red / ker_r / 1e9 / HBM_PEAK_GBS, 4)}
     del smp_c
     alg = G * S * H * 12.0
-    # VALU wave-instructions per sample-step of rollout_bordered_kernel<1,false>, from the PMC pass in profiles/r04/
-    # (scripts/pmc_rollout_issue.sh: SQ_INSTS_VALU / (G S H)); null when the summary is not there or is for another shape
-    issue = None
+    # VALU wave-instructions per sample-step of the rollout kernel, from the PMC pass scripts/pmc_rollout_issue.sh writes to
+    # profiles/rollout_pmc.json (SQ_INSTS_VALU / (G S H)) together with the shape AND the hash of the library sources the counter
+    # was taken on: emitted only when both match what is running (a counter of another binary is not evidence: VERDICT r5 weak 4)
+    issue, issue_why = None, None
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "r04", "rollout_pmc.json")))
-        # the per-sample-step count was measured at ONE shape (it grows with H: a step's work is O(steps so far)): the
-        # figure is emitted only for that shape, and labelled as derived from a stored counter
+        pj = json.load(open(os.path.join(ROOT, "profiles", "rollout_pmc.json")))
+        # the per-sample-step count was measured at ONE shape (it grows with H: a step's work is O(steps so far))
         if pj.get("shape") != {"G": G, "S": S, "H": H, "n": n}:
-            raise ValueError("rollout_pmc.json is for another shape")
+            raise ValueError("profiles/rollout_pmc.json is for another shape")
+        from volt_amd import _lib
+        have = _lib.lib().volt_source_hash().decode()
+        if pj.get("source_hash") != have:
+            raise ValueError(f"profiles/rollout_pmc.json was taken on sources {pj.get('source_hash')}, running {have}")
         per = float(pj["valu_wave_insts_per_sample_step"])
         ach = G * S * H * per / ker_f
-        issue = {"kernel": "rollout_bordered_kernel<1,false>", "bound": "valu_issue", "achieved": round(ach / 1e12, 3),
+        issue = {"kernel": pj.get("kernel", "rollout_bordered_kernel<1, false, 0>"), "bound": "valu_issue", "achieved": round(ach / 1e12, 3),
                  "peak": round(VALU_WAVE_INSTS_PER_S / 1e12, 3), "unit": "T wave-instructions/s",
                  "frac": round(ach / VALU_WAVE_INSTS_PER_S, 4), "valu_wave_insts_per_sample_step": per,
-                 "source": "instruction count per sample-step: a STORED counter (profiles/r04/rollout_pmc.json, rocprofv3 --pmc "
-                           "SQ_INSTS_VALU at this very shape); kernel time: live (HIP events)"}
-    except Exception:
-        issue = None
+                 "source": f"instruction count per sample-step: profiles/rollout_pmc.json ({pj.get('date')}, rocprofv3 --pmc SQ_INSTS_VALU "
+                           f"at this very shape on sources {have} = the running library); kernel time: live (HIP events)"}
+    except Exception as err:
+        issue, issue_why = None, str(err)
     return {"workload": f"{G} series x {S} paths x {H} steps, N={n} (BASELINE config 5"
                         + (", per-GPU share" if dist is None else f", {G} of 64 series on each of {world} ranks")
                         + "); append-only bordered engine; train block by the reference's route (fp64 factorisation + two "
@@ -792,7 +796,7 @@ def rollout_leg(x, F, vol, dev, n, G=8, S=10000, H=256, dist=None, world=1, rank
             "closed_form": {"total_s": round(tot_c, 5), "kernel_ms": round(ker_c * 1e3, 3),
                             "sample_steps_per_s": round(G * S * H / tot_c), "non_pd_paths": bad_c,
                             "max_abs_dev_from_factor_route": dev_cf},
-            "roofline": issue,
+            "roofline": issue, "roofline_absent_because": issue_why,
             "hbm": {"algorithmic_GB": round(alg / 1e9, 3), "GBps": round(alg / ker_f / 1e9, 1),
                     "note": "12 B per sample-step: far from HBM-bound (one wave per path, H dependent steps each)"},
             "resubstitute": res, "multi_rank": multi}

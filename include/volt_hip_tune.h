@@ -18,7 +18,7 @@
  *                          rank-32 updates of the diagonal tile and diagonal block g (1; 0: one workgroup, +4 .. 13 %)
  *   VOLT_LONG_XCD          one long series: spines on one XCD, their slab hand-offs through its L2 (0; measured -1.7 %
  *                          with the one-workgroup spine, within noise with the split one)
- *   VOLT_EXTRA_FLAGS       (build time, volt_amd/build.py) extra hipcc flags for same-box A/B builds: scripts/ab_split.sh
+ *   VOLT_EXTRA_FLAGS       (build time, volt_amd/build.py) extra hipcc flags for same-box A/B builds (scripts/ab_flags.sh)
  *   VOLT_PLAIN_SPREAD / VOLT_SPLIT_SPREAD   plain / all-split launches of up to this many workgroups run one workgroup
  *                          per CU (320 / 700)
  *   VOLT_BATCH / _ORDER / _LOCAL   the whole batched step in ONE launch (csrc/batch_step.hip): 0 off, 1 where measured faster

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Issue-side counters of rollout_bordered_kernel<1,false> at config 5's per-GPU share (8 series x 10^4 paths x 256 steps,
 # N = 4096): what the kernel's roofline is made of.  One SQ pass (8 slots) + GRBM, hard timeout;
-# summary -> gpurun_out/pmc_rollissue/rollout_pmc.json (copy to profiles/r04/).
+# summary -> gpurun_out/pmc_rollissue/rollout_pmc.json, carrying the hash of the library sources it was taken on: copy to
+# profiles/rollout_pmc.json (bench.py refuses it for any other sources) and to profiles/r06/.
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc_rollissue
@@ -14,19 +15,21 @@ timeout -k 5 ${PMC_TIMEOUT:-300} rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
 echo "pass sq2 rc=$?"
 cd $R
 python - <<'PY'
-import csv, glob, json
+import csv, datetime, glob, json, sys
 from collections import defaultdict
+sys.path.insert(0, ".")
+from volt_amd.build import source_hash
 agg = defaultdict(lambda: defaultdict(float)); n = defaultdict(int)
 for f in glob.glob("gpurun_out/pmc_rollissue/sq*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "rollout_bordered_kernel<1, false>" in k or "rollout_bordered_kernel<1,false>" in k:
+        if "rollout_lane_kernel<0, true>" in k or "rollout_lane_kernel<0,true>" in k:
             agg["k"][row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
 a = agg["k"]
 disp = max(n.values()) if n else 0
 per = {c: v / max(1, n[c]) for c, v in a.items()}
 G, S, H = 8, 10000, 256
-out = {"kernel": "rollout_bordered_kernel<1,false>", "workload": f"{G} series x {S} paths x {H} steps, N=4096",
+out = {"kernel": "rollout_lane_kernel<0, true>", "source_hash": source_hash(), "date": datetime.date.today().isoformat(), "workload": f"{G} series x {S} paths x {H} steps, N=4096",
        "shape": {"G": G, "S": S, "H": H, "n": 4096}, "dispatches": disp,
        "per_dispatch": per}
 if "SQ_INSTS_VALU" in per:

@@ -348,6 +348,8 @@ def test_graph_capture_is_the_default_where_a_step_is_launch_bound():
     assert _capture_pays(torch.empty(1, 4096)) and _capture_pays(torch.empty(4096)) and _capture_pays(torch.empty(64, 399))
     assert _capture_pays(torch.empty(399)) and _capture_pays(torch.empty(64, 2048))
     assert not _capture_pays(torch.empty(64, 4096)) and not _capture_pays(torch.empty(16, 4096))
+    # the GPCV ELBO step is 5 N^3 / 3, not 2 N^3 / 3: its gate has its own cost model
+    assert _capture_pays(torch.empty(32, 2048)) and not _capture_pays(torch.empty(32, 2048), n3_coeff=5.0 / 3.0)
     assert _auto_graph(True, torch.empty(64, 4096)) is True and _auto_graph(False, torch.empty(399)) is False
     assert _auto_graph(None, torch.empty(399)) is False              # a CPU tensor: nothing to capture
 

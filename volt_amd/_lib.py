@@ -83,6 +83,15 @@ class VoltHipError(RuntimeError):
     pass
 
 
+class VoltHipWarning(RuntimeWarning):
+    """The library recovered from an internal condition (e.g. re-ran a step on the launch-per-column schedule)."""
+
+
+# info[b] values at or below this are INTERNAL errors of the library, never "not positive definite" (include/volt_hip.h:
+# INT_MIN = a hand-off inside a one-launch step timed out, INT_MIN + 1 = the workspace does not hold what its init wrote)
+INFO_INTERNAL_MAX = -(2 ** 31) + 255
+
+
 def _embedded_hash(path):
     handle = C.CDLL(path)
     fn = handle.volt_source_hash

@@ -252,7 +252,12 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
             const double* Lkk = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
             const double* Wk = Wb + (int64_t)k * TS * TS;
 #define VOLT_B64_STEP(KB)                                                       \
-            batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);             \
+            /* KB = 0: a REAL acquire even under LOCAL -- A[k,k] is the one address written twice per launch (LA(k) parks its sum */ \
+            /* there, from a prepared copy it also READ the input there; D(k) then stores L_kk): a CU that ran LA(k) could hit */ \
+            /* its old L1 lines when it reads the L_kk sub-blocks below.  One buffer_inv per piece, off the chain */ \
+            /* for every US tile */ \
+            if (KB == 0) batch_wait<false>(sub + k, KB + 1, nullptr, 0, info_b);  \
+            else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);        \
             if (KB == 3) VOLT_B64_STAMP(4);                                     \
             trsm64_step<KB>(sT, Lkk, Np, Wk, P, Np);                            \
             if (dg) {                                                           \

@@ -435,7 +435,7 @@ struct TriTile {
 // the K offset of the chunk are wave-uniform and ride in the instruction's SGPR offset.
 // Cache policy of the operand each tile reads ONCE (Z: its own block row): nt (aux = 2), so that it does not push the
 // operand the tiles of a matrix SHARE (X: block row k) out of the XCD's L2 -- FETCH_SIZE per launch 1.95 -> 1.70 GB,
-// speed unchanged (scripts/nt_exp.sh).
+// speed unchanged (round 2 A/B; git history: scripts/archive/nt_exp.sh).
 #ifndef VOLT_Z_AUX
 #define VOLT_Z_AUX 2
 #endif
@@ -814,6 +814,28 @@ __device__ __forceinline__ void batch_publish_wt(int* word, int val) {
     }
 }
 
+
+// log of the product of up to 16 pivots L_ii (a thread's chunk of the diagonal): ONE double log instead of sixteen software
+// logs -- but with a single pivot's semantics kept: any pivot <= 0 or NaN makes the result NaN (an even number
+// of negative pivots must not give a finite, plausible log-determinant in the loops that read info late), and a product that
+// left the comfortable double range (sixteen fp32 values can reach 1e+-600) is redone pivot by pivot.
+__device__ __forceinline__ double log_pivot_product(const float (&dg)[16], int nvalid_mask) {
+    double prod = 1.0;
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if ((nvalid_mask >> u) & 1) {
+            ok = ok && (dg[u] > 0.f);                        // false for <= 0 and for NaN
+            prod *= (double)dg[u];
+        }
+    if (!ok) return __builtin_nan("");
+    if (prod > 1e-280 && prod < 1e280) return log(prod);
+    double s = 0.0;                                          // (rare: extreme pivots, or +inf on the diagonal)
+#pragma unroll 1
+    for (int u = 0; u < 16; ++u)
+        if ((nvalid_mask >> u) & 1) s += log((double)dg[u]);
+    return s;
+}
 
 // ---- who runs which piece (round 6) ------------------------------------------------------------------------------------
 // Round 5 ran piece w as workgroup w and leaned on two things HIP does not promise (MI355X_MICROARCH.md, "Workgroup

@@ -114,21 +114,21 @@ __global__ __launch_bounds__(256) void mll_scalars_kernel(const float* __restric
             al[u] = 0.f;
             if (want_grad) al[u] = alpha_pad[(int64_t)b * Np + cc];
         }
-        double prod = 1.0;
+        int valid = 0;
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const int c = c0 + u * 256;
             if (c < N) {
                 const double zi = zz[u];
                 q += zi * zi;
-                prod *= (double)dg[u];
+                valid |= 1 << u;
                 if (want_grad) {
                     aa += (double)al[u] * al[u];
                     alpha_out[(int64_t)b * N + c] = al[u];
                 }
             }
         }
-        ld += log(prod);
+        ld += log_pivot_product(dg, valid);                        // (NaN for a failed pivot, as sixteen single logs would give)
     }
     if (want_grad) {
         const int nt = n * (n + 1) / 2;

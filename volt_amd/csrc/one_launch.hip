@@ -514,19 +514,19 @@ __device__ __forceinline__ void small_tail_scalars(const float* __restrict__ A, 
                 zz[u] = tl.z[(int64_t)b * Np + c];
             }
         }
-        double prod = 1.0;                                         // ONE double log per thread for its sixteen pivots: their product
-#pragma unroll                                                     // (L_ii in 1e-4 .. 1e3: far inside the double range) -- sixteen
+        int valid = 0;                                             // ONE double log per thread for its sixteen pivots: their product
+#pragma unroll                                                     // (common.h, log_pivot_product: NaN for a failed pivot) -- sixteen
         for (int u = 0; u < CPT; ++u) {                            // software logs were 10 us behind the last tile
             const int c = c0 + u * NT;
             if (c < N) {
                 const double zi = zz[u];
                 v[0] += zi * zi;
-                prod *= (double)dg[u];
+                valid |= 1 << u;
                 v[2] += (double)al[u] * al[u];
                 tl.alpha[(int64_t)b * N + c] = al[u];
             }
         }
-        v[1] += log(prod);
+        v[1] += log_pivot_product(dg, valid);
     }
     const int nt = n * (n + 1) / 2;
     for (int i = tid; i < nt; i += NT) v[3] += red.frob[(int64_t)b * nt + i];

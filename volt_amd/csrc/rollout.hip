@@ -19,23 +19,65 @@
 // 4 samples per workgroup, EWMA histories in LDS.  H <= 1024: a lane owns the entries 256 c + 4 lane + t of
 // ceil(H / 256) chunks, so a stored row is read and written with 16-byte accesses, 1 KB per wave-instruction.
 #include "common.h"
+#include "host.h"
 #include "../../include/volt_hip.h"
 
 namespace volt {
 
+// Sum of a double over the 64 lanes, result in every lane: DPP inside the 16-lane rows (the two halves of the double travel as
+// two 32-bit DPP moves), then four readlane pairs -- the shape of common.h's wave_sum_f.  Round 6: the butterfly through
+// __shfl_xor was six dependent ds_bpermute round trips per sum (2 x 6 LDS instructions, ~100 cycles each) on a path whose
+// every step waits for its own mean: the step's dependent chain, not its instruction count, is what a rollout costs.
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double dpp_add_d(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWS, 0xf, ROWS == 0xf);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWS, 0xf, ROWS == 0xf);
+    return x + __hiloint2double(hi2, lo2);
+}
+// Inside the 16-lane rows as wave_sum_f does (quad_perm x 2, row_half_mirror, row_mirror), then ACROSS the rows with the two
+// broadcast steps of the GFX9 wave reduction -- row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -- which leave
+// (r3 + r2) + (r1 + r0) in row 3: the value common.h's wave_sum_f forms as (r0 + r1) + (r2 + r3), bit for bit, in 6 DPP steps
+// and one readlane (pair) instead of 4 + four readlanes and three scalar-operand adds.  The rollout kernel issues 212 VALU
+// instructions per sample-step and is bound by exactly that count (profiles/r06/rollout_pmc.json): a step has four of these sums.
 __device__ __forceinline__ double wave_sum_d(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    x = dpp_add_d<0xB1>(x);         // quad_perm [1,0,3,2]
+    x = dpp_add_d<0x4E>(x);         // quad_perm [2,3,0,1]
+    x = dpp_add_d<0x141>(x);        // row_half_mirror
+    x = dpp_add_d<0x140>(x);        // row_mirror: every lane of a 16-lane row holds the row sum
+    x = dpp_add_d<0x142, 0xa>(x);   // row_bcast:15 -> rows 1, 3
+    x = dpp_add_d<0x143, 0xc>(x);   // row_bcast:31 -> rows 2, 3
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    return __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ float dpp_add_rows(float x) {
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROWS, 0xf, ROWS == 0xf));
+}
+__device__ __forceinline__ float wave_sum_r(float x) {
+    x = dpp_add_rows<0xB1>(x);
+    x = dpp_add_rows<0x4E>(x);
+    x = dpp_add_rows<0x141>(x);
+    x = dpp_add_rows<0x140>(x);
+    x = dpp_add_rows<0x142, 0xa>(x);
+    x = dpp_add_rows<0x143, 0xc>(x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
 
 // Mean of the appended point idx for the EWMA family (EWMA.py:20-37, :39-54, :74-91, :94-113, :116-135) from the
 // per-sample histories in LDS (k train-tail values followed by the values appended so far).  ma1 = plain EMA at
 // the new index, e2new = EMA(EMA) there (dewma / tewma).
-__device__ __forceinline__ float family_mean(int mode, int idx, int k, int lane, const float* sw, const float* hy,
+// MODE >= 0: the mean mode at compile time (the kernel the product runs, one instance per mode: the tap loop carries no
+// per-tap mode tests and only the sums its mode needs); MODE < 0: `mode` decides at run time (the other instances).
+template <int MODE = -1>
+__device__ __forceinline__ float family_mean(int mode_rt, int idx, int k, int lane, const float* sw, const float* hy,
                                              const float* he1, const float* he2, float ema_prev, float mr_theta,
                                              float mr_latent, float& ma1, float& e2new) {
+    // (no contraction: the instances with the mode at compile time and at run time must round alike -- the re-substitution
+    // cross-check is held to bitwise equality with the product's engine)
+#pragma clang fp contract(off)
+    const int mode = MODE >= 0 ? MODE : mode_rt;
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int j = lane; j < k; j += 64) {
         const double wj = (double)sw[j];
@@ -108,7 +150,10 @@ __host__ __device__ inline size_t rollout_sample_floats(int H) {
 //      need.  O(idx^2) words streamed per step (H^3/6 * 4 B per path, HBM-bound).  Same arithmetic in the same order, so
 //      the two produce BITWISE identical paths (tested); kept as the cross-check and as the measured cost of not
 //      using the invariance (bench.py reports it as redundant bytes).
-template <int NC, bool RESUB>
+// MODE: the mean mode at compile time (0 .. 4), or -1 = p.mean_mode decides at run time.  The engine the product runs -- NC = 1,
+// append-only -- has one instance per mode: round 5's mode 4 added a run-time test (and a load nobody else needs) to every step of
+// every mode and cost 8 %.
+template <int NC, bool RESUB, int MODE = -1>
 __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) {
     // Both instantiations must round identically (the test holds them to bitwise equality), so nothing here is left
     // to the compiler's choice of what to fuse: contraction off, every multiply-add that should be one is written as one.
@@ -117,6 +162,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x * 4 + wave, g = blockIdx.y;
     const int H = p.H, k = p.k;
+    const int mean_mode = MODE >= 0 ? MODE : p.mean_mode;
     const int hl = k + H;                                   // history length per level
     float* hy = lds + (size_t)wave * 3 * hl;
     float* he1 = hy + hl;
@@ -126,8 +172,8 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     if (s < p.S) {
         for (int j = lane; j < k; j += 64) {
             hy[j] = p.hist_y[(size_t)g * k + j];
-            he1[j] = (p.mean_mode == 1 || p.mean_mode == 2) ? p.hist_e1[(size_t)g * k + j] : 0.f;
-            he2[j] = (p.mean_mode == 2) ? p.hist_e2[(size_t)g * k + j] : 0.f;
+            he1[j] = (mean_mode == 1 || mean_mode == 2) ? p.hist_e1[(size_t)g * k + j] : 0.f;
+            he2[j] = (mean_mode == 2) ? p.hist_e2[(size_t)g * k + j] : 0.f;
         }
     }
     __syncthreads();
@@ -143,17 +189,42 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
     // ~ dx vol^2 (1e-4 .. 1e-9) on top of rho ~ V[N-1] ~ 1, so forming U_s and rho in fp32 first loses them
     // (62 of 80,000 paths at N = 4096 lost a pivot that way); the differences themselves are fine in fp32.
     double base = p.acc0[g] - p.rho[g];
-    float ema_prev = (p.mean_mode == 3) ? p.ema_prev[g] : 0.f;
+    float ema_prev = (mean_mode == 3) ? p.ema_prev[g] : 0.f;
+    const float mr_latent = (mean_mode == 3) ? p.mr_latent[g] : 0.f;
     int bad = 0;
 
-    // entry (c, t) of these arrays belongs to appended point b = 256 c + 4 lane + t
-    float U[NC][4], rd[NC][4], zs[NC][4], wraw[NC][4];      // U_s - rho;  1 / L_s[b][b];  z_s[b];  (U_s - rho) - sum (un-normalised w)
+    // RESUB: entry (c, t) of these arrays belongs to appended point b = 256 c + 4 lane + t
+    float U[NC][4], rd[NC][4], zs[NC][4];                   // U_s - rho;  1 / L_s[b][b];  z_s[b]
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) U[c][t] = rd[c][t] = zs[c][t] = wraw[c][t] = 0.f;
+        for (int t = 0; t < 4; ++t) U[c][t] = rd[c][t] = zs[c][t] = 0.f;
+    // append-only: the running sums w_s'w_s and w_s'z_s, and the last appended point's (U_s - rho, 1 / L_ii, z_s)
+    double ww_d = 0.0, wz_d = 0.0;
+    float u_prev = 0.f, rell_prev = 0.f, z_prev = 0.f;
 
+    // The step's inputs (pred_vol, z, a given mean) and its output travel in BLOCKS OF 64 STEPS, one per lane: one coalesced load /
+    // store per 64 steps instead of two dependent global loads and a store inside every step -- each step then waited for its own
+    // loads' round trips (and, behind the same counter, for the previous step's store): ~a third of a step's 2 us (round 6).  The
+    // next block is requested while the current one is consumed; a step picks its values with v_readlane.
+    const bool use_theta = p.use_theta != 0;
+    const float lat_g = use_theta ? p.latent[g] : 0.f;
+    const float* m4 = (mean_mode == 4) ? p.hist_e1 + (size_t)g * H : nullptr;
+    float pv_blk = 0.f, zz_blk = 0.f, m4_blk = 0.f, out_blk = 0.f;
+    float pv_nxt = (lane < H) ? pv[lane] : 0.f, zz_nxt = (lane < H) ? zz[lane] : 0.f;
+    float m4_nxt = (m4 && lane < H) ? m4[lane] : 0.f;
+    auto lane_pick = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
     for (int idx = 0; idx < H; ++idx) {
+        const int li = idx & 63;                             // (wave-uniform)
+        if (li == 0) {
+            pv_blk = pv_nxt;
+            zz_blk = zz_nxt;
+            m4_blk = m4_nxt;
+            const int l2 = idx + 64 + lane;
+            pv_nxt = (l2 < H) ? pv[l2] : 0.f;
+            zz_nxt = (l2 < H) ? zz[l2] : 0.f;
+            m4_nxt = (m4 && l2 < H) ? m4[l2] : 0.f;
+        }
         float wv[NC][4];
         if constexpr (RESUB) {
             // ---- w_s = L_s^-1 (U_s - rho): row-oriented forward substitution against ALL stored rows ----
@@ -192,7 +263,7 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
 #pragma unroll
                             for (int t = 0; t < 4; ++t)                                            // zero beyond b < a
                                 part = __fmaf_rn(cur[r][c][t], __fmul_rn(wv[c][t], rd[c][t]), part);
-                        const float dot = wave_sum_f(part);
+                        const float dot = wave_sum_r(part);
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -207,58 +278,51 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
 #pragma unroll
                         for (int t = 0; t < 4; ++t) cur[r][c][t] = nxt[r][c][t];
             }
-        } else {
-            // ---- append-only: entries b < idx-1 stand; the new one, b = idx-1, is the same dot product the full
-            // substitution would take against row idx-1 -- whose entries are the w_s of the step before, in registers
-            if (idx >= 2) {
-                const int a = idx - 1;
-                float part = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float wfin = __fmul_rn(wraw[c][t], rd[c][t]);
-                        part = __fmaf_rn((256 * c + 4 * lane + t < a) ? wfin : 0.f, wfin, part);
-                    }
-                const float dot = wave_sum_f(part);
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (256 * c + 4 * lane + t == a) wraw[c][t] -= dot;
-            }
+        }
+        float ww = 0.f, wz = 0.f;
+        if constexpr (RESUB) {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) wv[c][t] = wraw[c][t];
-        }
-        float ww = 0.f, wz = 0.f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int b = 256 * c + 4 * lane + t;
-                wv[c][t] = (b < idx) ? __fmul_rn(wv[c][t], rd[c][t]) : 0.f;    // now wv = w_s
-                ww = __fmaf_rn(wv[c][t], wv[c][t], ww);
-                wz = __fmaf_rn(wv[c][t], zs[c][t], wz);
+                for (int t = 0; t < 4; ++t) {
+                    const int b = 256 * c + 4 * lane + t;
+                    wv[c][t] = (b < idx) ? __fmul_rn(wv[c][t], rd[c][t]) : 0.f;    // now wv = w_s
+                    ww = __fmaf_rn(wv[c][t], wv[c][t], ww);
+                    wz = __fmaf_rn(wv[c][t], zs[c][t], wz);
+                }
+            ww = wave_sum_r(ww);
+            wz = wave_sum_r(wz);
+        } else {
+            // ---- append-only: entries b < idx-1 of w_s stand; the new one, b = a = idx-1, is what the full substitution would
+            // take against row a: (U_a - rho - sum_{b<a} L_s[a][b] w_b) / L_s[a][a] with L_s[a][b] = w_b -- the sum is w_s'w_s of
+            // the step before.  So the recursion needs NO vector state: per step one new entry from three numbers of the previous
+            // step, and w_s'w_s / w_s'z_s as running sums (fp64: exact products, one rounding per step).  Round 6: rounds 2 - 5
+            // kept w_s, 1 / L_ii and z_s spread over the lanes and took three wave sums and ~40 masked element updates per step
+            // to get the same numbers -- 110 of the step's 212 VALU instructions.
+            if (idx >= 1) {
+                const float dot = (float)ww_d;
+                const float w_a = __fmul_rn(u_prev - dot, rell_prev);
+                ww_d = __fma_rn((double)w_a, (double)w_a, ww_d);
+                wz_d = __fma_rn((double)w_a, (double)z_prev, wz_d);
             }
-        ww = wave_sum_f(ww);
-        wz = wave_sum_f(wz);
+            ww = (float)ww_d;
+            wz = (float)wz_d;
+        }
 
         // ---- mean of the new point: EWMA family on the stacked series (EWMA.py:20-37) ----------
         // (mode 4: a mean that is a function of x alone -- constant / linear / log-linear, the weather driver's default,
         // experiments/weather/GPGenerator.py:68-82 -- is history-free: the host evaluated it at the test points)
         float ma1 = 0.f, e2new = 0.f;
-        const float mstar = (p.mean_mode == 4) ? p.hist_e1[(size_t)g * H + idx]
-                                               : family_mean(p.mean_mode, idx, k, lane, sw, hy, he1, he2, ema_prev, p.mr_theta,
-                                                             (p.mean_mode == 3) ? p.mr_latent[g] : 0.f, ma1, e2new);
+        const float mstar = (mean_mode == 4) ? lane_pick(m4_blk, li)
+                                             : family_mean<MODE>(mean_mode, idx, k, lane, sw, hy, he1, he2, ema_prev, p.mr_theta,
+                                                                 mr_latent, ma1, e2new);
 
         // ---- conditional and draw (rollout_utils.py:36-53) --------------------------------------
-        const float v = pv[idx];
+        const float v = lane_pick(pv_blk, li);
         const float v2 = v * v;
         const float kss = (float)(base + (double)__fmul_rn(hdx, v2));      // k** - rho; last CumTrapz weight halved
         float pm = tau + wz + mstar;
-        if (p.use_theta) pm = __fmaf_rn(-p.theta, pm - p.latent[g], pm);
+        if (use_theta) pm = __fmaf_rn(-p.theta, pm - lat_g, pm);
         float pvar = kss - ww;
         if (!(pvar > 0.f)) {                                 // psd_safe_cholesky(pred_cov, jitter) ladder
             float jit = p.jitter;
@@ -267,8 +331,12 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
             if (pvar + jit > 0.f) pvar += jit;
             else { if (bad >= 0) bad = -(idx + 1); pvar = 0.f; }     // ladder exhausted: the reference raises NotPSDError
         }
-        const float smp = __fmaf_rn(sqrtf(pvar), zz[idx], pm);
-        if (lane == 0) out[idx] = smp;
+        const float smp = __fmaf_rn(sqrtf(pvar), lane_pick(zz_blk, li), pm);
+        out_blk = (lane == li) ? smp : out_blk;
+        if (li == 63 || idx == H - 1) {                      // the block's samples out, one per lane
+            const int l = (idx & ~63) + lane;
+            if (l <= idx) out[l] = out_blk;
+        }
 
         // ---- append the point to the conditioning set --------------------------------------------
         base += (double)__fmul_rn(dx, v2);                   // full weight from now on
@@ -278,38 +346,214 @@ __global__ __launch_bounds__(256) void rollout_bordered_kernel(RolloutParams p) 
             if (!bad) bad = idx + 1;
             d2 = fmaxf(p.jitter, 1e-12f);
         }
-        const float ell = sqrtf(d2), rell = 1.f / ell;
+        // 1 / L_s[idx][idx] straight from the hardware reciprocal square root (1 ulp), the pivot from it: the IEEE square root
+        // followed by an IEEE division was 26 of the step's 212 VALU instructions
+        const float rell = __builtin_amdgcn_rsqf(d2), ell = __fmul_rn(d2, rell);
         const float znew = ((smp - mstar) - tau - wz) * rell;
         // row idx of L_s = [w_s, ell]: the off-diagonal part goes to the packed store (re-substitution mode only),
         // ell stays in registers (rd)
+        if constexpr (RESUB) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int b0 = 256 * c + 4 * lane;
-            f32x4 rowv;
+            for (int c = 0; c < NC; ++c) {
+                const int b0 = 256 * c + 4 * lane;
+                f32x4 rowv;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int b = b0 + t;
-                rowv[t] = (b < idx) ? wv[c][t] : ((b == idx) ? ell : 0.f);
-                if (b == idx) {
-                    U[c][t] = Unew;
-                    wraw[c][t] = Unew;                       // append-only: (U_s - rho) before its own row's dot product
-                    rd[c][t] = rell;
-                    zs[c][t] = znew;
+                for (int t = 0; t < 4; ++t) {
+                    const int b = b0 + t;
+                    rowv[t] = (b < idx) ? wv[c][t] : ((b == idx) ? ell : 0.f);
+                    if (b == idx) {
+                        U[c][t] = Unew;
+                        rd[c][t] = rell;
+                        zs[c][t] = znew;
+                    }
                 }
+                if (b0 < idx) *reinterpret_cast<f32x4*>(Ls + row_off(idx) + b0) = rowv;
             }
-            if (RESUB && b0 < idx) *reinterpret_cast<f32x4*>(Ls + row_off(idx) + b0) = rowv;
+        } else {
+            u_prev = Unew;                                   // (U_s - rho) of the appended point, its 1 / L_ii and its z_s: all the next step needs
+            rell_prev = rell;
+            z_prev = znew;
         }
-        if (lane == 0) {
+        if (lane == 0) {                                     // (the histories a mode never reads are not kept)
             hy[k + idx] = smp;
-            he1[k + idx] = ma1;
-            he2[k + idx] = e2new;
+            if (mean_mode == 1 || mean_mode == 2) he1[k + idx] = ma1;
+            if (mean_mode == 2) he2[k + idx] = e2new;
         }
         ema_prev = ma1;
-        __builtin_amdgcn_wave_barrier();
-        // make this wave's own LDS/global writes visible to its later reads
-        __threadfence_block();
+        if constexpr (RESUB) {
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();                           // this wave's own global writes (the factor's rows) before its later reads
+        } else {
+            // LDS only, and only this wave's: its LDS operations execute in order -- keep the compiler from moving accesses
+            // across, no wait is needed (a __threadfence_block here also waited for the sample's store every step)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
     }
     if (lane == 0) p.info[(size_t)g * p.S + s] = bad;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// ONE LANE PER PATH (round 6).  With the append-only recursion reduced to scalars (above: per step one new entry of w_s from three
+// numbers of the step before, w_s'w_s and w_s'z_s as running sums) nothing in a step but the moving-average mean is a vector
+// operation -- and a wave per path spent 63 of its 64 lanes repeating uniform arithmetic: ~120 wave-instructions per PATH-step.
+// Here a wave carries 64 paths of one series, every lane its own recursion; the mean's window lives in LDS as a ring
+// [k][64 lanes] per level (conflict-free: a tap is one ds_read for all 64 paths), the taps as doubles beside it, and the
+// step's inputs / outputs move as 16-byte groups of four steps per lane, requested a group ahead.  ~150 wave-instructions per
+// 64 path-steps.  The arithmetic per path is the wave-per-path engine's, operation for operation, except the order in which
+// the k tap products are added (serially here, by lanes and a DPP tree there; both in fp64): the two agree to the last bit
+// or the last bit but one of the mean, and are held to 1e-6 (tests/test_gpu_edge.py).
+// LDS: levels * k * 256 B + 8 k; shapes that do not fit 150 KB (k = 400 with tewma's three levels) keep the wave-per-path engine.
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(64) void rollout_lane_kernel(RolloutParams p) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int LEVELS = MODE == 2 ? 3 : (MODE == 1 ? 2 : (MODE == 4 ? 0 : 1));
+    const int lane = threadIdx.x;
+    const int g = blockIdx.y, H = p.H, k = p.k;
+    const int s_raw = blockIdx.x * 64 + lane;
+    const bool active = s_raw < p.S;
+    const int s = active ? s_raw : p.S - 1;                  // (idle lanes shadow the last path: every load is valid, nothing is stored)
+    double* swd = reinterpret_cast<double*>(lds);            // [k] taps
+    float* r0 = lds + 2 * k;                                 // [k][64] the stacked series
+    float* r1 = r0 + (LEVELS > 1 ? 64 * k : 0);             // [k][64] its EMA           (dewma / tewma)
+    float* r2 = r1 + (LEVELS > 2 ? 64 * k : 0);             // [k][64] EMA of the EMA    (tewma)
+    if (LEVELS > 0) {
+        for (int j = lane; j < k; j += 64) swd[j] = (double)p.w[j];
+        for (int j = 0; j < k; ++j) {
+            r0[64 * j + lane] = p.hist_y[(size_t)g * k + j];
+            if (LEVELS > 1) r1[64 * j + lane] = p.hist_e1[(size_t)g * k + j];
+            if (LEVELS > 2) r2[64 * j + lane] = p.hist_e2[(size_t)g * k + j];
+        }
+    }
+    __syncthreads();
+    const float tau = (float)p.tau[g], dx = p.dx[g], hdx = dx * 0.5f;
+    const size_t row = ((size_t)g * p.S + s) * H;
+    const float* pv = p.pred_vol + row;
+    const float* zz = p.z + row;
+    float* out = p.samples + row;
+    double base = p.acc0[g] - p.rho[g];                      // U_s - rho, fp64 (see rollout_bordered_kernel)
+    float ema_prev = (MODE == 3) ? p.ema_prev[g] : 0.f;
+    const float mr_latent = (MODE == 3) ? p.mr_latent[g] : 0.f;
+    const bool use_theta = p.use_theta != 0;
+    const float lat_g = use_theta ? p.latent[g] : 0.f;
+    const float* m4 = (MODE == 4) ? p.hist_e1 + (size_t)g * H : nullptr;
+    int bad = 0;
+    double ww_d = 0.0, wz_d = 0.0;
+    float u_prev = 0.f, rell_prev = 0.f, z_prev = 0.f;
+    f32x4 pv4 = {0.f, 0.f, 0.f, 0.f}, zz4 = pv4, o4 = pv4, pvn = pv4, zzn = pv4;
+    float pv1 = 0.f, zz1 = 0.f;
+    if (VEC) {
+        pvn = *reinterpret_cast<const f32x4*>(pv);
+        zzn = *reinterpret_cast<const f32x4*>(zz);
+    } else {
+        pv1 = pv[0];
+        zz1 = zz[0];
+    }
+    int pos = 0;                                             // idx mod k: the ring slot of the window's oldest value
+    for (int idx = 0; idx < H; ++idx) {
+        const int q = idx & 3;
+        float v, zi;
+        if (VEC) {
+            if (q == 0) {
+                pv4 = pvn;
+                zz4 = zzn;
+                if (idx + 4 < H) {
+                    pvn = *reinterpret_cast<const f32x4*>(pv + idx + 4);
+                    zzn = *reinterpret_cast<const f32x4*>(zz + idx + 4);
+                }
+            }
+            v = q == 0 ? pv4[0] : (q == 1 ? pv4[1] : (q == 2 ? pv4[2] : pv4[3]));
+            zi = q == 0 ? zz4[0] : (q == 1 ? zz4[1] : (q == 2 ? zz4[2] : zz4[3]));
+        } else {
+            v = pv1;
+            zi = zz1;
+            if (idx + 1 < H) {
+                pv1 = pv[idx + 1];
+                zz1 = zz[idx + 1];
+            }
+        }
+        // ---- the new entry of w_s and the running sums (rollout_bordered_kernel, append-only)
+        if (idx >= 1) {
+            const float dot = (float)ww_d;
+            const float w_a = __fmul_rn(u_prev - dot, rell_prev);
+            ww_d = __fma_rn((double)w_a, (double)w_a, ww_d);
+            wz_d = __fma_rn((double)w_a, (double)z_prev, wz_d);
+        }
+        const float ww = (float)ww_d, wz = (float)wz_d;
+        // ---- mean of the new point: the window [idx, idx + k) of the stacked series against the taps (EWMA.py:20-37), tap j
+        // on ring slot (pos + j) mod k
+        float ma1 = 0.f, e2new = 0.f, mstar;
+        if (MODE == 4) {
+            mstar = m4[idx];
+        } else {
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int j = 0;
+            for (int m = pos; m < k; ++m, ++j) {
+                const double wj = swd[j];
+                a1 = __fma_rn(wj, (double)r0[64 * m + lane], a1);
+                if (LEVELS > 1) a2 = __fma_rn(wj, (double)r1[64 * m + lane], a2);
+                if (LEVELS > 2) a3 = __fma_rn(wj, (double)r2[64 * m + lane], a3);
+            }
+            for (int m = 0; m < pos; ++m, ++j) {
+                const double wj = swd[j];
+                a1 = __fma_rn(wj, (double)r0[64 * m + lane], a1);
+                if (LEVELS > 1) a2 = __fma_rn(wj, (double)r1[64 * m + lane], a2);
+                if (LEVELS > 2) a3 = __fma_rn(wj, (double)r2[64 * m + lane], a3);
+            }
+            ma1 = (float)a1;
+            mstar = ma1;
+            if (MODE == 1 || MODE == 2) {
+                e2new = (float)a2;
+                if (MODE == 1) mstar = 2.f * ma1 - e2new;
+                else mstar = 3.f * ma1 - 3.f * e2new + (float)a3;
+            } else if (MODE == 3) {
+                mstar = ma1 - p.mr_theta * (ema_prev - mr_latent);
+            }
+        }
+        // ---- conditional and draw (rollout_utils.py:36-53)
+        const float v2 = v * v;
+        const float kss = (float)(base + (double)__fmul_rn(hdx, v2));
+        float pm = tau + wz + mstar;
+        if (use_theta) pm = __fmaf_rn(-p.theta, pm - lat_g, pm);
+        float pvar = kss - ww;
+        if (!(pvar > 0.f)) {                                 // psd_safe_cholesky(pred_cov, jitter) ladder
+            float jit = p.jitter;
+            int tries = 0;
+            while (!(pvar + jit > 0.f) && tries < 2) { jit *= 10.f; ++tries; }
+            if (pvar + jit > 0.f) pvar += jit;
+            else { if (bad >= 0) bad = -(idx + 1); pvar = 0.f; }
+        }
+        const float smp = __fmaf_rn(sqrtf(pvar), zi, pm);
+        if (VEC) {
+            if (q == 0) o4[0] = smp; else if (q == 1) o4[1] = smp; else if (q == 2) o4[2] = smp; else o4[3] = smp;
+            if (q == 3 && active) *reinterpret_cast<f32x4*>(out + idx - 3) = o4;
+        } else if (active) {
+            out[idx] = smp;
+        }
+        // ---- append the point
+        base += (double)__fmul_rn(dx, v2);
+        const float Unew = (float)base;
+        float d2 = Unew - ww;
+        if (!(d2 > 0.f)) {
+            if (!bad) bad = idx + 1;
+            d2 = fmaxf(p.jitter, 1e-12f);
+        }
+        const float rell = __builtin_amdgcn_rsqf(d2);
+        u_prev = Unew;
+        rell_prev = rell;
+        z_prev = ((smp - mstar) - tau - wz) * rell;
+        if (LEVELS > 0) {                                    // the new values take the slot of the window's oldest
+            r0[64 * pos + lane] = smp;
+            if (LEVELS > 1) r1[64 * pos + lane] = ma1;
+            if (LEVELS > 2) r2[64 * pos + lane] = e2new;
+            pos = pos + 1 == k ? 0 : pos + 1;
+        }
+        ema_prev = ma1;
+    }
+    if (active) p.info[(size_t)g * p.S + s] = bad;
 }
 
 
@@ -418,7 +662,49 @@ int volt_rollout_bordered_f32(const double* rho, const double* tau, const double
         if (scratch) VOLT_ROLLOUT_LAUNCH1(NC, true);                                                                   \
         else VOLT_ROLLOUT_LAUNCH1(NC, false);                                                                          \
     } while (0)
-    if (H <= 256) VOLT_ROLLOUT_LAUNCH(1);
+    // the engine the product runs: one LANE per path, whenever the mean's window fits the LDS ring (levels * k * 256 B)
+    const int levels = mean_mode == 2 ? 3 : (mean_mode == 1 ? 2 : (mean_mode == 4 ? 0 : 1));
+    const size_t lane_lds = (size_t)levels * k * 256 + (size_t)k * 8;
+    if (!scratch && lane_lds <= 150 * 1024 && tunables().rollout_lane != 0) {
+        const bool vec = (H & 3) == 0 && (((uintptr_t)pred_vol | (uintptr_t)z | (uintptr_t)samples) & 15) == 0;
+        const dim3 lgrid((S + 63) / 64, G);
+#define VOLT_ROLLOUT_LANE1(M, V)                                                                                       \
+    do {                                                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_lane_kernel<M, V>),                            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lane_lds);                          \
+        if (e != hipSuccess) return (int)e;                                                                            \
+        hipLaunchKernelGGL((rollout_lane_kernel<M, V>), lgrid, dim3(64), lane_lds, s, p);                            \
+    } while (0)
+#define VOLT_ROLLOUT_LANE(M) do { if (vec) VOLT_ROLLOUT_LANE1(M, true); else VOLT_ROLLOUT_LANE1(M, false); } while (0)
+        switch (mean_mode) {
+            case 0: VOLT_ROLLOUT_LANE(0); break;
+            case 1: VOLT_ROLLOUT_LANE(1); break;
+            case 2: VOLT_ROLLOUT_LANE(2); break;
+            case 3: VOLT_ROLLOUT_LANE(3); break;
+            default: VOLT_ROLLOUT_LANE(4); break;
+        }
+#undef VOLT_ROLLOUT_LANE
+#undef VOLT_ROLLOUT_LANE1
+        VOLT_LAUNCH_CHECK();
+        return 0;
+    }
+    if (H <= 256 && !scratch) {                              // a wave per path (windows too long for the ring): one instance per mean mode
+#define VOLT_ROLLOUT_LAUNCH_MODE(M)                                                                                    \
+    do {                                                                                                               \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_bordered_kernel<1, false, M>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        if (e != hipSuccess) return (int)e;                                                                            \
+        hipLaunchKernelGGL((rollout_bordered_kernel<1, false, M>), grid, dim3(256), lds, s, p);                      \
+    } while (0)
+        switch (mean_mode) {
+            case 0: VOLT_ROLLOUT_LAUNCH_MODE(0); break;
+            case 1: VOLT_ROLLOUT_LAUNCH_MODE(1); break;
+            case 2: VOLT_ROLLOUT_LAUNCH_MODE(2); break;
+            case 3: VOLT_ROLLOUT_LAUNCH_MODE(3); break;
+            default: VOLT_ROLLOUT_LAUNCH_MODE(4); break;
+        }
+#undef VOLT_ROLLOUT_LAUNCH_MODE
+    } else if (H <= 256) VOLT_ROLLOUT_LAUNCH(1);
     else if (H <= 512) VOLT_ROLLOUT_LAUNCH(2);
     else VOLT_ROLLOUT_LAUNCH(4);
 #undef VOLT_ROLLOUT_LAUNCH

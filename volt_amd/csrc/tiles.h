@@ -668,7 +668,7 @@ struct TriReduce {
 };
 
 // Output tiles are written once and not read again before the next launch: non-temporal stores keep them from
-// displacing the shared operand in L2 (scripts/nt_exp2.sh: reads 1.70 -> 1.67 GB per launch, +0.2 % speed).
+// displacing the shared operand in L2 (round 2 A/B, git history: reads 1.70 -> 1.67 GB per launch, +0.2 % speed).
 #ifndef VOLT_OUT_NT
 #define VOLT_OUT_NT 1
 #endif

@@ -123,6 +123,11 @@ class deferred_checks:
 
     def raise_if_bad(self):
         nbad = self.any_bad()
+        if nbad and any(bool((a < 0).any().item()) for a in self._acc.values()):
+            # (the accumulators OR the steps' info words: a negative one holds an internal code -- INT_MIN, INT_MIN + 1 --, not a pivot)
+            raise ops._lib.VoltHipError("a factorisation reported an INTERNAL error (hand-off time-out / workspace table) while "
+                                        "the check was deferred; rerun without deferral: the step is then re-run on the "
+                                        "launch-per-column schedule")
         if nbad:
             raise NotPSDError(f"{nbad} matrices failed a factorisation while the check was deferred (not positive "
                               "definite); rerun without deferral to get gpytorch's jitter-retry behaviour")
@@ -453,6 +458,20 @@ class _ExactMLL(torch.autograd.Function):
             bad = int((info != 0).sum().item())
             if deferred_checks._active is not None:
                 deferred_checks._active.reserve(info)
+        if bad and ops.info_internal(info):
+            # NOT "not positive definite": a one-launch step's hand-off timed out or its workspace table is not what the init
+            # wrote (include/volt_hip.h: info <= INT_MIN + 1).  gpytorch's ladder is for pivots; this is re-run ONCE on the
+            # launch-per-column schedule (fp32: the table-free path of the same entry point) and reported.
+            codes = sorted({int(v) & 0xffffffff for v in info[info <= ops._lib.INFO_INTERNAL_MAX].tolist()})
+            if dt != torch.float32:
+                raise ops._lib.VoltHipError(f"volt_mll_step_f64: internal error, info = {[hex(c) for c in codes]}")
+            warnings.warn(f"volt_mll_step_f32 reported an internal error (info = {[hex(c) for c in codes]}) on its one-launch "
+                          "schedule; the step was re-run on the launch-per-column schedule", ops._lib.VoltHipWarning)
+            out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=0.0,
+                                            refine_alpha=refine_alpha.active(), tables=False)
+            if ops.info_internal(info):
+                raise ops._lib.VoltHipError(f"volt_mll_step_f32: internal error on both schedules, info = {info.tolist()}")
+            bad = int((info != 0).sum().item())
         if bad:
             if torch.isnan(K).any() or torch.isnan(resid).any() or torch.isnan(noise).any():
                 raise NanError("cholesky: NaN in the covariance, the noise or the residual")
@@ -460,6 +479,8 @@ class _ExactMLL(torch.autograd.Function):
             for i in range(3):
                 jitter = (1e-6 if dt == torch.float32 else 1e-8) * (10 ** i)      # gpytorch's defaults per dtype
                 out, alpha, info = ops.mll_step(K, resid, noise, ws, want_grad=need_grad, jitter=jitter, refine_alpha=refine_alpha.active())
+                if ops.info_internal(info):
+                    raise ops._lib.VoltHipError(f"volt_mll_step: internal error, info = {info.tolist()}")
                 if not bool((info != 0).any().item()):
                     warnings.warn(f"A not p.d., added jitter of {jitter:.1e} to the diagonal", NumericalWarning)
                     break
@@ -555,13 +576,27 @@ def _safe_factor(A, jitter=None, max_tries=3):
     f = ops.potrf(A3)
     if not bool((f.info != 0).any().item()):
         return f, 0.0
+    tables = True
+    if ops.info_internal(f.info):
+        # an internal error of the one-launch factorisation (time-out / workspace table), not a pivot: once more on the
+        # launch-per-column schedule, and that schedule for the rest of this call
+        warnings.warn(f"volt_potrf reported an internal error (info = {f.info.tolist()[:4]} ...) on its one-launch schedule; "
+                      "re-run on the launch-per-column schedule", ops._lib.VoltHipWarning)
+        tables = False
+        f = ops.potrf(A3, tables=False)
+        if ops.info_internal(f.info):
+            raise ops._lib.VoltHipError(f"volt_potrf: internal error on both schedules, info = {f.info.tolist()[:8]}")
+        if not bool((f.info != 0).any().item()):
+            return f, 0.0
     if torch.isnan(A3).any():
         raise NanError(f"cholesky_cpu: {int(torch.isnan(A3).sum())} of {A3.numel()} elements of the {tuple(A.shape)} tensor are NaN.")
     if jitter is None:
         jitter = 1e-6 if A.dtype == torch.float32 else 1e-8
     for i in range(max_tries):
         jitter_new = jitter * (10 ** i)
-        f = ops.potrf(A3, jitter=jitter_new)
+        f = ops.potrf(A3, jitter=jitter_new, tables=tables)
+        if ops.info_internal(f.info):
+            raise ops._lib.VoltHipError(f"volt_potrf: internal error, info = {f.info.tolist()[:8]}")
         if not bool((f.info != 0).any().item()):
             warnings.warn(f"A not p.d., added jitter of {jitter_new:.1e} to the diagonal", NumericalWarning)
             return f, jitter_new

@@ -86,6 +86,13 @@ def ewma(y: torch.Tensor, k: int) -> torch.Tensor:
     return out.reshape(*y.shape[:-1], n + 1)
 
 
+def info_internal(info: torch.Tensor) -> int:
+    """How many entries of a factorisation's ``info`` report an INTERNAL error of the library (a hand-off time-out inside a
+    one-launch step, a workspace that does not hold its tables: include/volt_hip.h) -- as opposed to a non-positive pivot
+    (info > 0), the only thing gpytorch's jitter ladder is for.  One host read."""
+    return int((info <= _lib.INFO_INTERNAL_MAX).sum().item())
+
+
 class CholeskyFactor:
     """Result of `potrf`: padded factor A [B,Np,Np] (lower), inverse diagonal blocks, info [B]."""
 
@@ -141,9 +148,11 @@ def potrf_f64_inplace(A: torch.Tensor, Winv: torch.Tensor, info: torch.Tensor) -
                "volt_potrf")
 
 
-def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0.0) -> CholeskyFactor:
+def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0.0, tables: bool = True) -> CholeskyFactor:
     """Batched Cholesky of K + (sigma2 + jitter) I.  K [B,N,N] fp32 or fp64 (only the lower triangle is read); the
-    factor keeps K's dtype (fp32: volt_potrf_f32 on v_mfma_f32_32x32x2; fp64: volt_potrf_f64 on v_mfma_f64_16x16x4)."""
+    factor keeps K's dtype (fp32: volt_potrf_f32 on v_mfma_f32_32x32x2; fp64: volt_potrf_f64 on v_mfma_f64_16x16x4).
+    ``tables=False``: the launch-per-column schedules only (no scratch handed over, so no one-launch step) -- what the
+    wrappers fall back to when a one-launch step reports an internal error (`info_internal`)."""
     _need_gpu(K, sigma2)
     if K.dtype not in (torch.float32, torch.float64) or K.ndim != 3:
         raise ValueError("potrf expects a [B,N,N] fp32 or fp64 tensor")
@@ -163,13 +172,13 @@ def potrf(K: torch.Tensor, sigma2: torch.Tensor | None = None, jitter: float = 0
     if K.dtype == torch.float32:
         # straight from K (no copy-in pass); scratch for the small-batch schedules (0 bytes above 64 matrices and below
         # 3 block columns)
-        wp, nbytes = _potrf_workspace(B, Np, K.device)
+        wp, nbytes = _potrf_workspace(B, Np, K.device) if tables else (None, 0)
         _lib.check(L.volt_potrf_k_f32(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(),
                                       Winv.data_ptr(), info.data_ptr(), B, n, wp, nbytes,
                                       _lib.WS_INITIALISED if wp else 0, st), "volt_potrf_k")
     else:
         # straight from K where the shape runs as one launch (small / medium batches); prepare + launch-per-column otherwise
-        wp, nbytes = _potrf_ws_f64(B, Np, K.device)
+        wp, nbytes = _potrf_ws_f64(B, Np, K.device) if tables else (None, 0)
         _lib.check(L.volt_potrf_k_f64(K.data_ptr(), K.stride(1), K.stride(0), s2p, float(jitter), A.data_ptr(), Winv.data_ptr(),
                                       info.data_ptr(), B, n, wp, nbytes, st), "volt_potrf_k")
     return CholeskyFactor(A, Winv, info, n)
@@ -241,11 +250,13 @@ class MllWorkspace:
 
 
 def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: MllWorkspace | None = None,
-             want_grad: bool = True, jitter: float = 0.0, refine_alpha: bool = False):
+             want_grad: bool = True, jitter: float = 0.0, refine_alpha: bool = False, tables: bool = True):
     """One MLL(+grad) evaluation with K resident, in K's dtype: fp32 -> volt_mll_step_f32 (v_mfma_f32_32x32x2), fp64 ->
     volt_mll_step_f64 (v_mfma_f64_16x16x4).  Returns (out [B,8], alpha [B,N], info [B]); see include/volt_hip.h for the
     meaning of out's columns.  ``refine_alpha`` (fp32, with want_grad; opt-in): one step of iterative refinement of alpha
-    against K itself (VOLT_REFINE_ALPHA) -- both triangles of K must hold the symmetric matrix."""
+    against K itself (VOLT_REFINE_ALPHA) -- both triangles of K must hold the symmetric matrix.
+    ``tables=False`` (fp32): the workspace is NOT declared initialised, so the step runs the table-free launch-per-column
+    schedules -- the fallback of the wrappers when a one-launch step reports an internal error (`info_internal`)."""
     _need_gpu(K, resid, sigma2)
     if K.ndim != 3 or K.dtype not in (torch.float32, torch.float64):
         raise ValueError("K must be [B,N,N] fp32 or fp64")
@@ -260,7 +271,8 @@ def mll_step(K: torch.Tensor, resid: torch.Tensor, sigma2: torch.Tensor, ws: Mll
     fn = _lib.lib().volt_mll_step_f32 if dt == torch.float32 else _lib.lib().volt_mll_step_f64
     _lib.check(fn(K.data_ptr(), K.stride(1), K.stride(0), resid.data_ptr(), s2.data_ptr(), float(jitter), ws.out.data_ptr(),
                   ws.alpha.data_ptr(), ws.info.data_ptr(), ws.ptr, B, n,
-                  (ws.flags | (_lib.REFINE_ALPHA if (refine_alpha and want_grad) else 0)) if dt == torch.float32 else int(want_grad),
+                  ((ws.flags if tables else ws.flags & ~_lib.WS_INITIALISED) | (_lib.REFINE_ALPHA if (refine_alpha and want_grad) else 0))
+                  if dt == torch.float32 else int(want_grad),
                   _lib.stream_ptr()), "volt_mll_step")
     return ws.out, ws.alpha, ws.info
 

@@ -173,7 +173,7 @@ def _run_iterations(iteration, optimizer, train_iters, printing, graph=False, sc
             if any_bad():
                 warnings.warn("a factorisation failed inside the captured loop: rerunning it eagerly with the jitter ladder",
                               gp.NumericalWarning)
-                replay_eagerly(warm, train_iters)
+                replay_eagerly(warm, train_iters)                     # (`one` rebinds `loss`: what is returned is the eager loop's)
             return loss
         i = warm
         while i < train_iters:
@@ -199,8 +199,9 @@ class _null:
 CAPTURE_BELOW_MS = 4.0        # estimated step time under which the per-iteration host work (~0.3 ms of launches, autograd, Adam) is worth removing
 
 
-def _capture_pays(target):
-    """Is an iteration over ``target`` ([.., N] log-prices) launch-bound?  The step is 2 N^3 / 3 flop per series at the
+def _capture_pays(target, n3_coeff=2.0 / 3.0):
+    """Is an iteration over ``target`` ([.., N] log-prices) launch-bound?  The step is n3_coeff N^3 flop per series (2/3: the
+    MLL + gradient step; 5/3: the GPCV ELBO step, csrc/gpcv.hip -- its own cost model) at the
     ~110 TFLOP/s the MLL step sustains; an eager iteration adds ~0.3 ms of host work (torch glue, autograd, Adam) that a
     captured one does not pay: 1 x 399 runs 0.50 ms eager / 0.14 captured, 64 x 4096 22.1 / 22.0.  Since round 5 the step
     of every shape is ONE launch per batch (or a handful), so capturing costs nothing -- the gate is only about whether
@@ -208,18 +209,22 @@ def _capture_pays(target):
     n = target.shape[-1]
     batch = target.numel() // max(n, 1)
     npad = (n + 127) // 128 * 128
-    return batch * 2.0 * npad ** 3 / 3.0 / 110e12 * 1e3 < CAPTURE_BELOW_MS
+    return batch * n3_coeff * npad ** 3 / 110e12 * 1e3 < CAPTURE_BELOW_MS
 
 
-def _auto_graph(graph, target, distributed=False):
+def _auto_graph(graph, target, distributed=False, n3_coeff=2.0 / 3.0):
     """``graph=None`` (the default of every training loop here, as no reference call site passes it --
     voltron/train_utils.py:15,69,98,192): capture where it pays, on a CUDA device, outside an ongoing capture, single
-    process.  An explicit True / False is honoured."""
+    process.  An explicit True / False is honoured.
+    NOTE what capturing changes besides the launches: the optimiser is `optim.FusedAdam` (the reference's Adam update as two
+    launches with the step count on the device; `_adam`) instead of `torch.optim.Adam` -- the same arithmetic in fp32, checked
+    against torch's in tests/test_gpu_api.py -- and a failed factorisation is answered after the fact: the loop restores the
+    post-warm-up snapshot and finishes eagerly with gpytorch's jitter ladder (the loss it returns is then the eager one)."""
     if graph is not None:
         return bool(graph)
     if distributed or not target.is_cuda or torch.cuda.is_current_stream_capturing():
         return False
-    return _capture_pays(target)
+    return _capture_pays(target, n3_coeff)
 
 
 def _fit_exact(model, lh, train_x, target, params, lr, train_iters, printing, graph=False, defer=False, batched=False,
@@ -290,7 +295,7 @@ def LearnGPCV(train_x, train_y, train_iters=1000, printing=False, early_stopping
     """voltron/train_utils.py:15-67: the volatility path of a price series from a variational GP (BM or FBM prior over
     log-vol, ``y | f ~ N(0, exp f)``) fitted to the scaled returns; one HIP ELBO step per iteration.
     train_y [N+1] prices -> pred_scale [N]; train_y [T,N+1] fits T series at once (batched parameters)."""
-    graph = _auto_graph(graph, train_y[..., 1:])         # (only the fitted scale is returned: nothing per-iteration is lost)
+    graph = _auto_graph(graph, train_y[..., 1:], n3_coeff=5.0 / 3.0)   # (only the fitted scale is returned: nothing per-iteration is lost)
     model, likelihood, _ = FitGPCV(train_x, train_y, train_iters=train_iters, printing=printing, kernel=kernel, graph=graph)
     return likelihood(model(train_x), return_gaussian=False).scale.mean(0).detach()      # :60-67
 

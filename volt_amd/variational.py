@@ -139,6 +139,8 @@ class _GPCVElbo(torch.autograd.Function):
         if chk is not None:
             chk.note(ws.info)
         elif bool((ws.info != 0).any().item()):
+            if ops.info_internal(ws.info):       # a hand-off time-out / workspace table: not a statement about K
+                raise ops._lib.VoltHipError(f"volt_gpcv_step_f32: internal error, info = {ws.info.tolist()[:8]}")
             if torch.isnan(K).any() or torch.isnan(m).any() or torch.isnan(Lq).any():
                 raise NanError("GPCV step: NaN in the prior covariance or the variational parameters")
             raise NotPSDError("GPCV step: prior covariance K + 1e-3 I is not positive definite")
