@@ -384,6 +384,14 @@ def main():
     if rank == 0 and not args.no_aux_legs:
         f64 = f64_leg(x, F, vol, dev, n, min(8, B))
 
+    # ---- the (f) rows: GPCV's ELBO step and the vol model's step, at the reference's sizes and at 8 x 4096 (rank 0, N=1)
+    nxt = None
+    if rank == 0 and world == 1 and not args.no_aux_legs:
+        try:
+            nxt = next_rows_leg(dev)
+        except Exception as e:
+            nxt = {"error": repr(e)[:300]}
+
     # ---- CPU baseline leg (rank 0, N=1 only): torch-CPU restatement of the gpytorch path (+ real gpytorch if present)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -418,6 +426,7 @@ def main():
             "fp64": f64,
             "rollouts": roll,
             "configs": cfgs,
+            "next_rows": nxt,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
@@ -608,6 +617,93 @@ def api_default_leg(dev, n=399, t1=30, t2=230):
             "ms_per_iteration": round(res["default"], 4), "over_raw_op": round(res["default"] / raw, 3),
             "captured_by_default": bool(_capture_pays(y)), "eager_ms_per_iteration": round(res["eager"], 4),
             "iterations": [t1, t2]}
+
+
+def next_rows_leg(dev):
+    """SURVEY 8(f) rows 1 and 4 on the record: the step of the two fits that precede the data model in the
+    reference's per-window pipeline (experiments/stocks/GenerateMultiMeanPreds.py:100-111) --
+      * LearnGPCV's ELBO + gradient step (voltron/train_utils.py:15-67): volt_gpcv_step_f32, algorithmic 5 N^3 / 3 flop per
+        series (factor + L^-T through the exact-GP step's one-launch schedules, T' = Lq' L^-T, G = K^-1 Lq);
+      * TrainVolModel's MLL + gradient step (:69-95): volt_mll_step_f32 on K = vol * min(x, x'), 2 N^3 / 3 (the gradient wrt
+        the kernel's scale is in closed form from the step's scalars: no dK contraction) --
+    at the reference's default size for one ticker and for 64, and at 8 x 4096: ms of the raw HIP step (K resident, tight
+    loop, HIP events), and ms per iteration of the public entry point with the reference's arguments (captured where the
+    step is launch-bound; difference of two runs).  frac = algorithmic flops / time / the fp32 MFMA peak."""
+    import math
+    from volt_amd import ops
+    from volt_amd.synthetic import sde_batch
+    from volt_amd.train_utils import LearnGPCV, TrainVolModel, TrainVolModelBatch
+    from volt_amd.variational import _gauss_hermite
+    out = {}
+    for B, n in ((1, 399), (64, 399), (8, 4096)):
+        x, F, vol = sde_batch(B, n, seed=5)
+        tx = torch.tensor(x, device=dev)
+        prices = torch.tensor(F, device=dev)                                  # [B, n + 1]
+        volp = torch.tensor(vol, device=dev).clamp_min(1e-3)
+        dtx = float(x[1] - x[0])
+        yy = (prices[:, 1:] - prices[:, :-1]) / prices[:, :-1] / dtx ** 0.5   # scaled returns (train_utils.py:16-18)
+        K = 0.2 * torch.minimum(tx[:, None], tx[None, :]).expand(B, n, n).contiguous() + 0.0
+        Lq = (0.05 * torch.eye(n, device=dev) + 0.001 * torch.randn(n, n, device=dev, generator=torch.Generator(dev).manual_seed(0))).tril()
+        Lq = Lq.expand(B, n, n).contiguous()
+        m = yy.abs().clamp_min(1e-2).log()
+        mu = torch.full((B, n), -1.5, device=dev)
+        gx, gw = _gauss_hermite(75, dev)
+        reps = 100 if n < 1000 else 10
+
+        def timed_loop(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        gws = ops.gpcv_step(K, m - mu, m, Lq, yy, gx, gw, w_ell=1 / n, w_kl=1 / n)
+        g_ms = timed_loop(lambda: ops.gpcv_step(K, m - mu, m, Lq, yy, gx, gw, gws, w_ell=1 / n, w_kl=1 / n))
+        g_bad = int((gws.info != 0).sum().item())
+        del gws
+        lv = volp.log()
+        r = (lv - lv.mean(-1, keepdim=True)).contiguous()
+        s2 = torch.full((B,), 0.6932, device=dev)
+        mws = ops.MllWorkspace(B, n, True, dev)
+        v_ms = timed_loop(lambda: ops.mll_step(K, r, s2, mws))
+        v_bad = int((mws.info != 0).sum().item())
+        del mws
+
+        def api(fn, t1, t2):
+            def run(iters):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn(iters)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            run(t1)
+            a = min(run(t1) for _ in range(2))
+            b = min(run(t2) for _ in range(2))
+            return (b - a) / (t2 - t1) * 1e3
+        t1, t2 = (20, 120) if n < 1000 else (5, 13)
+        py = prices[0] if B == 1 else prices
+        vp = volp[0] if B == 1 else volp
+        try:
+            ga = api(lambda it: LearnGPCV(tx, py, train_iters=it), t1, t2)
+            va = api(lambda it: (TrainVolModel if B == 1 else TrainVolModelBatch)(tx, vp, train_iters=it), t1, t2)
+        except Exception as e:                                                # never let the extra leg cost the line
+            ga = va = None
+            out.setdefault("errors", []).append(repr(e)[:200])
+        gfl, vfl = B * 5 * n ** 3 / 3, B * 2 * n ** 3 / 3
+        row = lambda ms, fl: None if ms is None else {"ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 2),
+                                                      "frac": round(fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4)}
+        out[f"{B}x{n}"] = {"gpcv_elbo_step": {"algorithmic_flops": "5 N^3 / 3 per series", "raw_step": row(g_ms, gfl),
+                                              "LearnGPCV_iteration": row(ga, gfl), "not_pd": g_bad},
+                           "vol_model_step": {"algorithmic_flops": "2 N^3 / 3 per series", "raw_step": row(v_ms, vfl),
+                                              "TrainVolModel_iteration": row(va, vfl), "not_pd": v_bad}}
+        del K, Lq
+    out["what"] = ("SURVEY 8(f) rows 1 (TrainVolModel, voltron/train_utils.py:69-95) and 4 (LearnGPCV, :15-67): raw HIP step and one "
+                   "iteration of the public entry point with the reference's arguments")
+    return out
 
 
 def configs_leg(make_step, timed, dev, K_all, y_all, n_head, batch_head, steps=50, warmup=5, api_inputs=None):

@@ -23,7 +23,13 @@
  *                          per CU (320 / 700)
  *   VOLT_BATCH / _ORDER / _LOCAL   the whole batched step in ONE launch (csrc/batch_step.hip): 0 off, 1 where measured faster
  *                          (default), 2 wherever it can run, 3 also ahead of the short- / long-series one-launch steps; order of
- *                          a column's tiles in the list (0; VOLT_BATCH_LAD: look-ahead tiles listed this many columns early, 0: measured no gain); hand-offs through the XCD's L2 when the batch is a multiple of 8 (1)
+ *                          a column's tiles in the list (-1: by shape -- windows of 32 positions x 16 matrices from 48 x 3584 on, else
+ *                          matrix innermost; VOLT_BATCH_LAD: look-ahead tiles listed this many columns early, 0: measured no gain);
+ *                          hand-offs through the XCD's L2 when the batch is a multiple of 8 (1)
+ *   VOLT_BATCH_PULLERS     the one-launch steps' grid: this many times the resident workgroups, pulling pieces by ticket (1)
+ *   VOLT_BATCH_XSKEW / _XDROP   tests: the XCDs' queues shifted against the XCC ids / the pullers of the XCDs in the bit mask
+ *                          leave at once (their queues are adopted): tests/test_gpu_topology.py
+ *   VOLT_ROLLOUT_LANE      rollouts: one lane per path (1; 0: the wave-per-path engine everywhere)
  *   VOLT_F64_LOOKAHEAD     fp64 factorisation: look-ahead depth of the chain / bulk multi-stream schedule, 0 = one stream,
  *                          1 = one column, 2 = two columns (2 from 6 matrices on, else 1)           (read in csrc/chol64.hip)
  *   VOLT_F64_TRTRI_LOOKAHEAD  fp64 inverse: one-row look-ahead on its own stream, 0 / 1 (on up to 4 matrices)
@@ -94,8 +100,10 @@ int volt_long_describe(int n, int first, int emin, int* items, int max_items, in
  * block columns, in grid order: items [max_items][4] int32 {kind | b << 3, row, col, 0}, kind 0 diagonal tile D(k = row),
  * 1 look-ahead for tile (row+1,row+1), 2 panel tile (row, col), 3 tile (row, col) of the inverse, 4 its diagonal tile.
  * order: bit 0: 0 positions in column order with the matrix innermost, 1 matrix-group-major inside a block column; bits
- * 1.. : how many block columns early the look-ahead tiles are listed (VOLT_BATCH_LAD).  items may be
- * NULL (count only).  Returns the number of pieces (= workgroups of the launch), -1 bad argument, -2 max_items too small. */
+ * 1.. : how many block columns early the look-ahead tiles are listed (VOLT_BATCH_LAD); 1000 + w: the windowed order w of
+ * batch_sched.h (2 + 4 log2(window) + 32 (groups of 8 matrices side by side - 1)); -1: the order the step itself picks for
+ * this shape.  items may be NULL (count only).  Returns the number of pieces (= tickets of the launch: since round 6 a grid
+ * of resident pullers takes them by ticket), -1 bad argument, -2 max_items too small. */
 int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_items);
 /* The one-launch batched step: while `stamps` (device, 8 int64 per workgroup of the launch = per piece of the list) is set,
  * every workgroup of the following steps records [0] s_memrealtime (100 MHz) at entry, [1] at exit, [2] XCC_ID << 32 | HW_ID,

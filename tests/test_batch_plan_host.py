@@ -23,9 +23,13 @@ def plan(B, n, has_y, order=0):
 
 
 @pytest.mark.parametrize("B,n,has_y,order", [(8, 4, 1, 0), (3, 5, 1, 0), (16, 7, 1, 1), (5, 6, 0, 0), (1, 1, 1, 0), (2, 2, 1, 0), (64, 32, 1, 0),
-                                             (8, 9, 1, 2 << 1), (16, 12, 0, 1 << 1), (8, 32, 1, 2 << 1 | 1)])
+                                             (8, 9, 1, 2 << 1), (16, 12, 0, 1 << 1), (8, 32, 1, 2 << 1 | 1),
+                                             (64, 32, 1, 1054), (16, 9, 1, 1022), (64, 8, 0, 1054), (24, 12, 1, 1118), (64, 32, 1, -1)])
 def test_list_is_topological_and_complete(B, n, has_y, order):
-    lad = order >> 1                     # look-ahead tiles listed this many block columns early (the one sanctioned forward wait)
+    # order < 16: look-ahead tiles listed (order >> 1) block columns early (the one sanctioned forward wait); 1000 + w: round 6's
+    # windowed orders (batch_sched.h) -- what 64 x 4096 runs (order -1 = the step's own choice) -- which only permute a block
+    # column's tiles among the matrices: the same pieces, still behind everything they wait for, still matrix w % 8 at index w
+    lad = order >> 1 if 0 <= order < 16 else 0
     it = plan(B, n, has_y, order)
     kind, b, row, col = it[:, 0] & 7, it[:, 0] >> 3, it[:, 1], it[:, 2]
     pos = {}

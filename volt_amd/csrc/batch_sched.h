@@ -70,9 +70,22 @@ inline void batch_build(int B, int n, bool has_y, int order, std::vector<BatchIt
             for (int p = 0; p < npos; ++p) emit(kind, rowf(p), colf(p));
             return;
         }
-        for (int g = 0; g < B / 8; ++g)
-            for (int p = 0; p < npos; ++p)
-                for (int x = 0; x < 8; ++x) items.push_back({kind | (g * 8 + x) << 3, rowf(p), colf(p), 0});
+        if (order == 1) {
+            for (int g = 0; g < B / 8; ++g)
+                for (int p = 0; p < npos; ++p)
+                    for (int x = 0; x < 8; ++x) items.push_back({kind | (g * 8 + x) << 3, rowf(p), colf(p), 0});
+            return;
+        }
+        // order = 2 + 4 * (log2 of the window) + 32 * (groups of 8 matrices side by side - 1)  (round 6): positions in
+        // WINDOWS of `win`, and inside a window `side` groups of 8 matrices at a time -- a queue (one XCD) then sees `side` of
+        // its matrices x `win` consecutive positions back to back, so that the tiles resident on an XCD share the block row k of
+        // FEWER matrices (its 64 pullers: side x win tiles; order 0: 8 matrices x 8 positions)
+        const int win = 1 << ((order >> 2) & 7), side = ((order >> 5) & 7) + 1, G = B / 8;
+        for (int p0 = 0; p0 < npos; p0 += win)
+            for (int g0 = 0; g0 < G; g0 += side)
+                for (int p = p0; p < npos && p < p0 + win; ++p)
+                    for (int g = g0; g < G && g < g0 + side; ++g)
+                        for (int x = 0; x < 8; ++x) items.push_back({kind | (g * 8 + x) << 3, rowf(p), colf(p), 0});
     };
     auto alpha = [&](int c) {
         for (int q = 0; q * BATCH_ALPHA_ROWS < (c + 1) * 128; ++q) emit(BK_ALPHA, c, q);

@@ -145,12 +145,15 @@ struct BatchArgs {
 static __shared__ __attribute__((aligned(16))) float g_smem[2 * STAGE_FLOATS];
 static __shared__ float g_srv[TS];                           // a tile of the inverse: the residuals of its block row (trtri_reduce)
 static __shared__ int g_piece;                               // the piece thread 0 pulled
+static __shared__ int g_ahead[2];                            // [iteration parity] 1: g_piece / g_desc were fetched AHEAD, during the last tile's epilogue
+static __shared__ int4 g_desc;                               // ... that piece's table entry
 
 // One piece of the list.  LOCAL: the hand-offs of this piece's matrix all happen under this workgroup's L2 (see above):
 // plain (non-temporal) stores, acknowledged by the L2, instead of write-through to memory -- the word of a tile follows its
 // stores after ~1 us instead of ~10.
 template <bool FROMK, bool LOCAL>
-__device__ __forceinline__ void batch_piece(const BatchArgs a, const int w) {
+__device__ __forceinline__ void batch_piece(const BatchArgs a, const int w, const bool ahead, const int par, BatchPull& pull,
+                                            int* qw, int per_queue) {
     float* const smem = g_smem;
     float* const srv = g_srv;
     float* const A = a.A; float* const Winv = a.Winv; float* const Y = a.Y; int* const info = a.info;
@@ -159,7 +162,7 @@ __device__ __forceinline__ void batch_piece(const BatchArgs a, const int w) {
     const TriReduce& red = a.red;
     long long* const stamps = a.stamps;
     const int n = Np / TS;
-    int4 d = a.tab[BATCH_HDR + w];
+    int4 d = ahead ? g_desc : a.tab[BATCH_HDR + w];          // (fetched during the last tile's epilogue, or now)
     // (the descriptor arrives in vector registers: said to be uniform HERE, or the compiler may turn every scalar computation
     // that follows from it -- tile addresses, buffer descriptors -- into per-lane code with a waterfall loop around each load)
     d.x = __builtin_amdgcn_readfirstlane(d.x);
@@ -263,13 +266,35 @@ __device__ __forceinline__ void batch_piece(const BatchArgs a, const int w) {
 #endif
     if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 4] = __builtin_amdgcn_s_memrealtime();
     if (!ok && (threadIdx.x & 63) == 0) atomicCAS(info_b, 0, (int)0x80000000);   // a hand-off timed out: internal error
+    // The NEXT piece's ticket goes out here, ahead of the epilogue: the atomic's round trip (~1 us beside busy neighbours) rides
+    // under the reductions and the tile's stores, whose drain (tri_store_lds ends on vmcnt(0)) also brings it back; its table
+    // entry is then requested ahead of the publish's drain + barrier.  At the top of the loop both are there -- a tile every
+    // ~40 us (64 x 2048) to ~160 us (64 x 4096) per puller otherwise starts with two dependent round trips.  Taking a ticket
+    // early is safe: its holder runs it right after this piece, and a ticket only ever waits for smaller ones.
+    int t_next = -1;
+    if (threadIdx.x == 0 && pull.q >= 0) t_next = __hip_atomic_fetch_add(qw + 32 * pull.q, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the reductions of a tile of the inverse first (they read the accumulators and use LDS behind the tile image), then
     // the tile: its stores are the last thing before the drain
     if (jb.i >= 0 && red.rpad) trtri_reduce<!LOCAL>(O, Np, jb.i, jb.j, jb.b, red, smem + TS * WLD, srv);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 6] = __builtin_amdgcn_s_memrealtime();
     tri_store_lds<LOCAL ? 0 : AUX_WT>(O, jb.out, Np, smem);
     if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+    int4 d_next = {0, 0, 0, 0};
+    int w_next = -1;
+    if (threadIdx.x == 0 && pull.q >= 0) {
+        if (t_next < per_queue) {
+            w_next = LOCAL ? 8 * t_next + pull.q : t_next;
+            d_next = a.tab[BATCH_HDR + w_next];
+        } else {
+            pull.q = -1;                                     // this queue is dry: the loop's own pull looks for another
+        }
+    }
     batch_publish_wt<LOCAL>(word, val);
+    if (threadIdx.x == 0 && w_next >= 0) {                   // (the loop's barriers order these against the other waves' reads)
+        g_ahead[par ^ 1] = 1;
+        g_piece = w_next;
+        g_desc = d_next;
+    }
 }
 
 template <bool FROMK, bool LOCAL>
@@ -293,16 +318,19 @@ __global__ __launch_bounds__(256, 2) void batch_step_kernel(BatchArgs a, int che
     // invariant, kept alive across the tile pipelines and spilled (400 - 1000 VGPRs); as a called function the body saves 112
     // callee-saved registers per piece.  A second way into the cycle (never taken: the host passes xdrop without bit 30) makes
     // it irreducible: no loop pass touches it, and the body compiles as round 5's one-piece kernel did (254 VGPRs, no scratch).
-    int w;
+    int w, ahead = 0, par = -1;                              // par: parity of the iteration (-1: the first, nothing fetched ahead)
     if (xdrop & 0x40000000) {
         w = xskew | (int)0x80000000;
         goto piece;
     }
 pull_next:
     __syncthreads();                                         // the last piece's LDS traffic (and its read of g_piece) is over
-    if (threadIdx.x == 0) g_piece = batch_next_piece<LOCAL>(pull, qw, xcc, per_queue);
+    if (threadIdx.x == 0 && !(par >= 0 && g_ahead[par])) g_piece = batch_next_piece<LOCAL>(pull, qw, xcc, per_queue);
     __syncthreads();
     w = g_piece;
+    ahead = par >= 0 ? g_ahead[par] : 0;
+    par = par < 0 ? 0 : par;
+    if (threadIdx.x == 0) g_ahead[par ^ 1] = 0;              // (nobody reads the other parity before the next two barriers; a tile's epilogue may set it)
 piece:
     w = __builtin_amdgcn_readfirstlane(w);
     if (w < 0) return;
@@ -311,7 +339,9 @@ piece:
         a.stamps[(int64_t)w * 8] = __builtin_amdgcn_s_memrealtime();
         a.stamps[(int64_t)w * 8 + 2] = ((long long)hw << 32) | (unsigned)__builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4);
     }
-    batch_piece<FROMK, LOCAL>(a, w);
+    par = __builtin_amdgcn_readfirstlane(par < 0 ? 0 : par);
+    batch_piece<FROMK, LOCAL>(a, w, __builtin_amdgcn_readfirstlane(ahead) != 0, par, pull, qw, per_queue);
+    par ^= 1;
     if (a.stamps && threadIdx.x == 0) a.stamps[(int64_t)w * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     goto pull_next;
 }
@@ -320,7 +350,8 @@ piece:
 
 using namespace volt;
 
-// Where the one launch replaces the launch-per-column schedules: the measured crossovers of profiles/r05/batch_gate_sweep.txt
+// Where the one launch replaces the launch-per-column schedules: the measured crossovers of profiles/r05/batch_gate_sweep.txt (re-swept
+// around the borders with round 6's pullers: profiles/r06/batch_gate_sweep.txt)
 // (ms launch-per-column / ms one-launch over B = 2 .. 96, N = 1024 .. 4096, for the gradient step and for the factorisation
 // alone).  (B, n, inverse?) only: the gate is part of the shape's identity -- volt_*_workspace_bytes / _init and the step
 // agree on it.  Short series of few matrices stay with the short-series one-launch step (small_step_kernel), one long series
@@ -331,7 +362,8 @@ bool volt_internal_batch_applies(int B, int n, int has_y) {
     if (tn.batch >= 2) return true;
     if (has_y) {
         if (n >= 20) return B >= 2;                          // N = 3072, 4096: 1.01 - 1.44 x at every batch size from 2 on
-        if (n >= 10) return B >= 6;                          // N = 1536, 2048: 1.02 - 1.59 x (2 - 4 matrices: 0.90 - 0.99)
+        if (n >= 16) return B >= 4;                          // N = 2048: 4 matrices 1.05 x with the pullers (round 6 sweep; 2 - 3: 0.94 - 0.99)
+        if (n >= 10) return B >= 6;                          // N = 1536: 1.04 - 1.42 x (2 - 4 matrices: 0.97)
         if (n >= 8) return B >= 20;                          // N = 1024: 1.07 - 1.48 x
         return false;
     }
@@ -364,10 +396,22 @@ size_t volt_internal_batch_bytes(int B, int n, int has_y) {
     return batch_table_bytes(B, n, has_y != 0) + batch_prog_bytes(B, n);
 }
 
+// Order of a block column's tiles in the list (batch_sched.h).  Round 6: with the pullers a queue's order is
+// free, and WINDOWS of 32 positions x 2 groups of 8 matrices (order 54: an XCD's 64 pullers then work on 2 of its matrices at a
+// time, not 8) cut the step's HBM reads 79.4 -> 64.0 GB at 64 x 4096 (84.1 -> 68.7 GB with the writes; every window shape tried
+// plateaus at 68.5: profiles/r06/order_traffic.txt) at the SAME time (22.06 against 22.10 ms) -- but cost 0.7 % at 32 x 4096 and 2 %
+// at 64 x 2048, where a window is most of a block column and the chain waits for it.  So: windows from 48 matrices of 28 block
+// columns on, positions matrix-innermost elsewhere.  VOLT_BATCH_ORDER >= 0 (tuning) forces one order everywhere.
+static int batch_order_for(int B, int n) {
+    const int forced = tunables().batch_order;
+    if (forced >= 0) return forced;
+    return (B >= 48 && n >= 28 && (B & 7) == 0) ? 54 : 0;
+}
+
 // the word every piece of a table carries: what the table was built for
 static int batch_check_word(int B, int n, bool has_y) {
     const uint32_t w = (uint32_t)BATCH_MAGIC ^ ((uint32_t)B * 0x01000193u) ^ ((uint32_t)n << 20) ^ (has_y ? 0x40000000u : 0u) ^
-                       ((uint32_t)tunables().batch_order << 28) ^ ((uint32_t)batch_lad(B) << 16);
+                       ((uint32_t)batch_order_for(B, n) * 2654435761u) ^ ((uint32_t)batch_lad(B) << 16);
     return (int)w;
 }
 
@@ -380,7 +424,7 @@ struct BatchTable {
 static const BatchTable* get_batch_table(int B, int n, bool has_y) {
     static std::mutex mu;
     static std::map<std::array<int, 4>, BatchTable*> cache;
-    const int order = tunables().batch_order;
+    const int order = batch_order_for(B, n);
     const std::array<int, 4> key{B, n, has_y ? 1 : 0, order * 16 + batch_lad(B)};
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
@@ -491,9 +535,13 @@ int volt_tune_batch_stamps(long long* stamps) {
 // Host only (no GPU): the piece list of the one-launch batched step, in grid order -- items [max_items][4] int32
 // {kind | b << 3, row, col, 0} (batch_sched.h).  Returns the number of pieces, -1 bad argument, -2 max_items too small.
 int volt_batch_describe(int B, int n, int has_y, int order, int* items, int max_items) {
-    if (B < 1 || n < 1 || order < 0 || order > 15) return -1;
+    // order 0 .. 15: (order & 1) = matrix innermost / matrix-major, order >> 1 = look-ahead tiles listed that many columns early;
+    // 1000 + w: the windowed order w of batch_sched.h (what large batches run: batch_order_for);  -1: the order the step picks
+    if (order == -1) order = 1000 + batch_order_for(B, n);
+    if (B < 1 || n < 1 || order < 0 || (order > 15 && order < 1000) || order > 1255) return -1;
     std::vector<BatchItem> it;
-    batch_build(B, n, has_y != 0, order & 1, it, order >> 1);
+    if (order >= 1000) batch_build(B, n, has_y != 0, order - 1000, it, 0);
+    else batch_build(B, n, has_y != 0, order & 1, it, order >> 1);
     if ((int64_t)it.size() != batch_count(B, n, has_y != 0)) return -1;
     if (items) {
         if ((int)it.size() > max_items) return -2;

@@ -27,7 +27,7 @@ struct Tunables {
     int cus = 256, xccs = 8;
     int group_gate = 700;                      // launches of fewer workgroups than this run as one stream group
     int batch = 1;                             // the whole batched step in one launch (batch_step.hip): 0 off, 1 where measured faster, 2 wherever it can run
-    int batch_order = 0;                       // ... order of a block column's panel tiles in its list: 0 row-major (matrix innermost), 1 matrix-major
+    int batch_order = -1;                      // ... order of a block column's tiles in its list: -1 by shape (batch_step.hip, batch_order_for), 0 matrix innermost, 1 matrix-major, 2 + 4 log2(window) + 32 (groups side by side - 1) windowed (batch_sched.h)
     int batch_lad = 0;                         // ... its look-ahead tiles listed this many block columns early (batch_sched.h).  Measured, ms/step at lad 0 / 1 / 2 / 3: 8 x 4096 3.64 / 3.65 / 3.68 / 3.69, 16 x 4096 5.94 / 5.95 / 6.00 / 6.13, 64 x 4096 21.95 / 21.98 / 21.99 / 22.01: no gain, off
     int batch_spread = 400;                    // ... with up to this many tiles per block column, B (n + 1), it runs ONE workgroup per CU.  ms/step two per CU -> one per CU at N = 4096: B = 2 1.90 -> 1.66, 4 2.57 -> 2.10, 8 3.64 -> 3.37, 12 4.80 -> 4.82, 16 5.89 -> 6.16, 24 8.51 -> 9.17; at N = 2048: B = 8 0.99 -> 0.82, 16 1.28 -> 1.11.  Shorter series cross over later (their tiles are shorter, the chain weighs more): + 9 tiles per block column short of 32 -- 24 x 2048 (408 tiles) 1.59 -> 1.48, 32 x 2048 (544) 1.840 -> 1.836, 64 x 2048 (1088) 3.26 -> 3.52; 32 x 1536 (416) 1.02 -> 0.92; 64 x 1024 (576) 0.70 -> 0.67, 40 x 1024 0.58 -> 0.48; 16 x 3072 (400) 2.92 -> 2.87, 24 x 3072 (600) 3.97 -> 4.21
     int batch64 = 1;                           // the fp64 factorisation / gradient step in one launch (batch64_step.hip): 0 off, 1 where measured faster, 2 wherever it can run
