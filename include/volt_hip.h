@@ -154,6 +154,13 @@ int volt_trsv_lower_t_f64(const double* A, const double* Winv, const double* rhs
  * diagonal of Y as scratch: only the upper triangle (diagonal included) is meaningful on return. */
 int volt_trtri_f32(const float* A, const float* Winv, float* Y, int B, int Np, void* stream);
 int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np, void* stream);
+/* The fp64 inverse with caller scratch (round 6): ws of volt_trtri_workspace_bytes_f64(B, Np) bytes (a few KB of progress words,
+ * nothing to initialise; 0 = this shape has no one-launch schedule) lets the whole inverse run as ONE launch -- the rows' tiles
+ * chase each other inside it (csrc/batch64_step.hip) instead of two launches per block row: 8 x 4096 4.8 -> 3.4 ms.  ws == NULL,
+ * or a shape beyond the gate: exactly volt_trtri_f64.  Same result to rounding (different summation order of a tile's K blocks:
+ * none -- the tiles' arithmetic is the launch-per-row kernels'). */
+size_t volt_trtri_workspace_bytes_f64(int B, int Np);
+int volt_trtri_ws_f64(const double* A, const double* Winv, double* Y, int B, int Np, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a7/a8: sequential posterior rollouts  (voltron/rollout_utils.py:57-93 + :6-53) ----------
  * Bordered-Cholesky engine: the shared train block of every sample's matrix enters through two scalars per series,

@@ -37,7 +37,13 @@ for B, n in shapes:
     t_copy = timeit(lambda: A.copy_(Aprep))
     t_potrf = timeit(potrf_only) - t_copy
     Y = torch.empty_like(A)
-    t_trtri = timeit(lambda: _lib.check(L.volt_trtri_f64(A.data_ptr(), W.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()), "trtri"))
+    t_trtri_rows = timeit(lambda: _lib.check(L.volt_trtri_f64(A.data_ptr(), W.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()), "trtri"))
+    Yr = Y.triu().clone()
+    tb = int(L.volt_trtri_workspace_bytes_f64(B, Np))
+    tws = torch.empty(tb + 256, dtype=torch.uint8, device="cuda")
+    twp = (tws.data_ptr() + 255) // 256 * 256 if tb else None
+    t_trtri = timeit(lambda: _lib.check(L.volt_trtri_ws_f64(A.data_ptr(), W.data_ptr(), Y.data_ptr(), B, Np, twp, tb, _lib.stream_ptr()), "trtri"))
+    trtri_dev = float((Y.triu() - Yr).abs().max() / Yr.abs().max())
     r = torch.randn(B, n, device="cuda", dtype=torch.float64)
     ws = ops.MllWorkspace(B, n, True, "cuda", torch.float64)
     t_step = timeit(lambda: ops.mll_step(K, r, s2, ws))
@@ -45,7 +51,8 @@ for B, n in shapes:
     t_fwd = timeit(lambda: ops.mll_step(K, r, s2, ws0, want_grad=False))
     fl = B * Np ** 3 / 3
     rows.append({"tag": tag, "B": B, "N": n, "potrf_ms": round(t_potrf, 3), "potrf_TF": round(fl / t_potrf / 1e9, 2),
-                 "trtri_ms": round(t_trtri, 3), "trtri_TF": round(fl / t_trtri / 1e9, 2),
+                 "trtri_ms": round(t_trtri, 3), "trtri_TF": round(fl / t_trtri / 1e9, 2), "trtri_launch_per_row_ms": round(t_trtri_rows, 3),
+                 "trtri_one_launch": bool(tb), "trtri_rel_dev_from_launch_per_row": trtri_dev,
                  "mll_step_ms": round(t_step, 3), "mll_step_TF": round(2 * fl / t_step / 1e9, 2), "mll_fwd_ms": round(t_fwd, 3),
                  "info": int(info.abs().sum())})
     print(json.dumps(rows[-1]), flush=True)

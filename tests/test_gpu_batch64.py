@@ -118,3 +118,37 @@ def test_factor_straight_from_k_equals_the_prepared_copy(ops, B, n):
     ops.potrf_f64_inplace(A, W, info)
     assert int(info.abs().sum()) == 0 and int(f.info.abs().sum()) == 0
     assert torch.equal(torch.tril(A), torch.tril(f.A)) and torch.equal(W, f.Winv)
+
+
+@pytest.mark.parametrize("B,n", [(1, 640), (8, 1024), (3, 1500), (16, 512), (2, 4096)])
+def test_trtri_f64_one_launch_vs_lapack_and_launch_per_row(B, n):
+    """volt_trtri_ws_f64 runs the whole inverse as ONE launch (the TD / T pieces of the one-launch step with the
+    factor complete: csrc/batch64_step.hip) -- against torch's fp64 triangular inverse (1e-11 of max |Y|), bitwise against
+    volt_trtri_f64's launch-per-row kernels where the tiles' arithmetic is the same (it is: one gemm64 chain per tile, then the
+    product with W_i), and bitwise repeatable.  B = 8 / 16 take the fence-free LOCAL hand-offs."""
+    import torch
+    from volt_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    M = torch.randn(B, n, n, device="cuda", dtype=torch.float64, generator=g)
+    K = M @ M.mT / n + torch.eye(n, device="cuda", dtype=torch.float64)
+    f = ops.potrf(K)
+    assert int(f.info.abs().sum()) == 0
+    Np = f.A.shape[1]
+    nb = int(L.volt_trtri_workspace_bytes_f64(B, Np))
+    assert nb > 0
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device="cuda")
+    wp = (ws.data_ptr() + 255) // 256 * 256
+    Y = torch.full((B, Np, Np), float("nan"), device="cuda", dtype=torch.float64)
+    _lib.check(L.volt_trtri_ws_f64(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, wp, nb, _lib.stream_ptr()), "trtri_ws")
+    Y1 = Y[:, :n, :n].triu().clone()
+    ref = torch.linalg.inv(torch.linalg.cholesky(K.cpu())).mT.triu()          # L^-T
+    assert float((Y1.cpu() - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+    Y2 = torch.empty_like(Y)
+    _lib.check(L.volt_trtri_f64(f.A.data_ptr(), f.Winv.data_ptr(), Y2.data_ptr(), B, Np, _lib.stream_ptr()), "trtri")
+    assert float((Y2[:, :n, :n].triu() - Y1).abs().max()) <= 1e-13 * float(ref.abs().max())
+    for _ in range(3):
+        Y.fill_(float("nan"))
+        _lib.check(L.volt_trtri_ws_f64(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, wp, nb, _lib.stream_ptr()), "trtri_ws")
+        assert torch.equal(Y[:, :n, :n].triu(), Y1)
+    assert torch.equal(ops.trtri(f), Y1)                                      # the Python op takes the one launch too

@@ -41,6 +41,8 @@ _SIGS = {
     "volt_trsv_lower_t_f32": (C.c_int, [_ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trtri_f32": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     "volt_trtri_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    "volt_trtri_workspace_bytes_f64": (C.c_size_t, [_i32, _i32]),
+    "volt_trtri_ws_f64": (C.c_int, [_ptr, _ptr, _ptr, _i32, _i32, _ptr, C.c_size_t, _ptr]),
     "volt_mll_workspace_bytes_f64": (_sz, [_i32, _i32, _i32]),
     "volt_mll_step_f64": (C.c_int, [_ptr, _i64, _i64, _ptr, _ptr, _f64, _ptr, _ptr, _ptr, _ptr, _i32, _i32, _i32, _ptr]),
     "volt_rollout_scratch_bytes": (_sz, [_i32, _i32, _i32]),

@@ -44,10 +44,20 @@ static inline int64_t batch64_count(int B, int n, bool has_y) {
     return (int64_t)B * per;
 }
 
-__global__ void batch64_begin_kernel(int* __restrict__ info, int ninfo, int* __restrict__ prog, int nprog) {
+// inv_n > 0 (the inverse alone, volt_trtri_ws_f64): the factor is complete before the launch -- rowp[i] = n, wdone = n (every
+// block row of L and every W_i is there), only the inverse's own words (tcol) start at 0
+__global__ void batch64_begin_kernel(int* __restrict__ info, int ninfo, int* __restrict__ prog, int nprog, int inv_n, int pstride,
+                                     int nwords) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ninfo) info[i] = 0;
-    for (int c = i; c < nprog; c += gridDim.x * blockDim.x) prog[c] = 0;
+    for (int c = i; c < nprog; c += gridDim.x * blockDim.x) {
+        int v = 0;
+        if (inv_n > 0 && c < nwords) {
+            const int o = c % pstride;                        // rowp[n] | tcol[n] | sub[n] | la[n] | wdone
+            if (o < inv_n || o == 4 * inv_n) v = inv_n;
+        }
+        prog[c] = v;
+    }
 }
 
 enum Piece64Kind { P64_DIAG = 0, P64_PANEL = 1, P64_TRTRI_DIAG = 2, P64_TRTRI = 3, P64_LOOKAHEAD = 4 };
@@ -77,6 +87,17 @@ __device__ __host__ inline Piece64 batch64_piece(int p, int n, bool has_y) {
     }
     if (p == 0) return {P64_TRTRI_DIAG, n - 1, n - 1};
     return {P64_TRTRI, n - 1, p - 1};
+}
+
+// position p of a matrix's list when only the inverse runs: row by row, the diagonal tile first, then the row's tiles longest first
+__device__ __host__ inline Piece64 batch64_trtri_piece(int p, int n) {
+    int i = 0;
+    while (p > i) {                                          // row i has i + 1 pieces
+        p -= i + 1;
+        ++i;
+    }
+    if (p == 0) return {P64_TRTRI_DIAG, i, i};
+    return {P64_TRTRI, i, p - 1};
 }
 
 // the wave's 64x64 of a 128x128 tile of doubles <-> accumulator layout (VOLT_ACC64_RC).  WT: written through at agent scope
@@ -162,6 +183,7 @@ struct Batch64Args {
     KSource64 src;
     long long* stamps;
     int npieces;
+    int inverse_only;        // 1: the factor is there, the launch runs the rows of the inverse alone (volt_trtri_ws_f64)
 };
 extern __shared__ __attribute__((aligned(16))) double g_sT64[];     // the diagonal block's image / the staging buffers
 static __shared__ int g_piece64;                                     // the piece thread 0 pulled
@@ -179,7 +201,7 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
     const KSource64& src = a.src;
     long long* const stamps = a.stamps;
     const int n = Np / TS, b = w % B;
-    const Piece64 pc = batch64_piece(w / B, n, Y != nullptr);
+    const Piece64 pc = a.inverse_only ? batch64_trtri_piece(w / B, n) : batch64_piece(w / B, n, Y != nullptr);
 #define VOLT_B64_STAMP(i) \
     do { if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     int* rowp = prog + (int64_t)b * pstride;
@@ -425,14 +447,63 @@ int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, in
     int blocks = (std::max(B, nprog) + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks * 256 < B) blocks = (B + 255) / 256;
-    hipLaunchKernelGGL(batch64_begin_kernel, dim3(blocks), dim3(256), 0, s, info, B, prog, nprog);
+    hipLaunchKernelGGL(batch64_begin_kernel, dim3(blocks), dim3(256), 0, s, info, B, prog, nprog, 0, pstride, B * pstride);
     // eight queues, one per XCD, when the matrices divide among them evenly (the pullers read their XCC id: common.h)
     const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;
     const int64_t npieces = batch64_count(B, n, Y != nullptr);
     if (npieces > 0x7fffffff) return 0;
     // as many pullers as the chip holds at once: one per CU (the image's LDS); nothing depends on the number
     const unsigned grid = (unsigned)std::min<int64_t>(npieces, tunables().batch_pullers > 0 ? (int64_t)tunables().cus * tunables().batch_pullers : npieces);
-    const Batch64Args args{A, Winv, Y, info, Np, B, prog, pstride, src, g_batch64_stamps, (int)npieces};
+    const Batch64Args args{A, Winv, Y, info, Np, B, prog, pstride, src, g_batch64_stamps, (int)npieces, 0};
+    const int xskew = tunables().batch_xskew, xdrop = tunables().batch_xdrop;
+    hipError_t e;
+    if (local) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
+    }
+    e = hipGetLastError();
+    return e != hipSuccess ? (int)e : 1;
+}
+
+// The triangular inverse alone as one launch: the rows of the inverse are pieces of the one-launch step already
+// (TD / T above: a chased sum, then the product with W_i); with the factor complete they only wait for each other -- tile (i,j)
+// for tiles (j .. i-1, j) of its column, one K block behind.  chol64.hip's volt_trtri_f64 walks the rows as launches (two
+// kernels per row, a look-ahead stream): 8 x 4096 4.8 ms; here 528 tiles per matrix keep every CU busy from the first row on.
+// The error word of a hand-off time-out goes to `ierr` [B] in the caller's scratch (the inverse has no info argument).
+// Returns 1 when enqueued, 0 when the shape is not this schedule's, a HIP error otherwise.
+size_t volt_internal_batch64_trtri_bytes(int B, int n) {
+    const Tunables& tn = tunables();
+    if (tn.batch64 <= 0 || B < 1 || n < 2 || B > 65535) return 0;
+    if (tn.batch64 < 2 && (int64_t)B * (n + 1) > tn.batch64_max) return 0;
+    return ((((size_t)B * batch64_pstride(n) + BATCH_QWORDS) * sizeof(int) + 255) & ~(size_t)255) + (((size_t)B * sizeof(int) + 255) & ~(size_t)255);
+}
+
+int volt_internal_batch64_trtri(const double* A, const double* Winv, double* Y, int B, int Np, void* state, size_t state_bytes,
+                                void* stream) {
+    const int n = Np / TS;
+    const size_t need = volt_internal_batch64_trtri_bytes(B, n);
+    if (!state || !need || state_bytes < need) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    int* prog = reinterpret_cast<int*>(state);
+    const int pstride = batch64_pstride(n), nprog = B * pstride + BATCH_QWORDS;
+    int* ierr = reinterpret_cast<int*>(reinterpret_cast<char*>(state) + ((((size_t)nprog) * sizeof(int) + 255) & ~(size_t)255));
+    int blocks = (std::max(B, nprog) + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks * 256 < B) blocks = (B + 255) / 256;
+    hipLaunchKernelGGL(batch64_begin_kernel, dim3(blocks), dim3(256), 0, s, ierr, B, prog, nprog, n, pstride, B * pstride);
+    const bool local = (B & 7) == 0 && tunables().batch_local != 0 && tunables().xccs == 8;
+    const int64_t npieces = (int64_t)B * n * (n + 1) / 2;
+    if (npieces > 0x7fffffff) return 0;
+    const unsigned grid = (unsigned)std::min<int64_t>(npieces, tunables().batch_pullers > 0 ? (int64_t)tunables().cus * tunables().batch_pullers : npieces);
+    const KSource64 src{nullptr, 0, 0, nullptr, 0.0, Np};
+    const Batch64Args args{const_cast<double*>(A), const_cast<double*>(Winv), Y, ierr, Np, B, prog, pstride, src, g_batch64_stamps, (int)npieces, 1};
     const int xskew = tunables().batch_xskew, xdrop = tunables().batch_xdrop;
     hipError_t e;
     if (local) {

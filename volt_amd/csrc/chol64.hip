@@ -299,6 +299,9 @@ int volt_internal_factor_f64(double* A, double* Winv, int* info, double* Y, int 
 // batch64_step.hip: the one-launch schedule of small batches (state: the progress words, caller scratch)
 bool volt_internal_batch64_applies(int B, int n, int has_y);
 size_t volt_internal_batch64_bytes(int B, int n, int has_y);
+size_t volt_internal_batch64_trtri_bytes(int B, int n);
+int volt_internal_batch64_trtri(const double* A, const double* Winv, double* Y, int B, int Np, void* state, size_t state_bytes,
+                                void* stream);
 int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, int B, int Np, void* state, size_t state_bytes,
                                void* stream, const volt::KSource64* ksrc = nullptr);
 
@@ -373,6 +376,27 @@ int volt_trtri_f64(const double* A, const double* Winv, double* Y, int B, int Np
     }
     VOLT_LAUNCH_CHECK();
     return 0;
+}
+
+size_t volt_trtri_workspace_bytes_f64(int B, int Np) {
+    if (B <= 0 || Np < TS || Np % TS) return 0;
+    return volt_internal_batch64_trtri_bytes(B, Np / TS);
+}
+
+int volt_trtri_ws_f64(const double* A, const double* Winv, double* Y, int B, int Np, void* ws, size_t ws_bytes, void* stream) {
+    if (!A) return -1;
+    if (!Winv) return -2;
+    if (!Y) return -3;
+    if (B < 0) return -4;
+    if (Np < TS || Np % TS) return -5;
+    if (ws && ((uintptr_t)ws & 255)) return -6;
+    if (B == 0) return 0;
+    if (ws) {                                                // the whole inverse in one launch (batch64_step.hip)
+        const int rc = volt_internal_batch64_trtri(A, Winv, Y, B, Np, ws, ws_bytes, stream);
+        if (rc == 1) return 0;
+        if (rc != 0) return rc;
+    }
+    return volt_trtri_f64(A, Winv, Y, B, Np, stream);
 }
 
 int volt_potrf_f64(double* A, double* Winv, int* info, int B, int Np, void* stream) {

@@ -221,8 +221,15 @@ def trtri(f: CholeskyFactor) -> torch.Tensor:
     """Y = L^-T as an upper-triangular [B,N,N] tensor in the factor's dtype (volt_trtri_f32 / volt_trtri_f64)."""
     B, Np = f.A.shape[0], f.A.shape[1]
     Y = torch.empty(B, Np, Np, dtype=f.A.dtype, device=f.A.device)
-    fn = _lib.lib().volt_trtri_f32 if f.A.dtype == torch.float32 else _lib.lib().volt_trtri_f64
-    _lib.check(fn(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()), "volt_trtri")
+    L = _lib.lib()
+    if f.A.dtype == torch.float32:
+        _lib.check(L.volt_trtri_f32(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, _lib.stream_ptr()), "volt_trtri")
+    else:
+        # a few KB of progress words let the whole inverse run as one launch (csrc/batch64_step.hip); 0 bytes: launch per row
+        nbytes = int(L.volt_trtri_workspace_bytes_f64(B, Np))
+        ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=f.A.device) if nbytes else None
+        wp = (ws.data_ptr() + 255) // 256 * 256 if nbytes else None
+        _lib.check(L.volt_trtri_ws_f64(f.A.data_ptr(), f.Winv.data_ptr(), Y.data_ptr(), B, Np, wp, nbytes, _lib.stream_ptr()), "volt_trtri")
     return torch.triu(Y[:, : f.n, : f.n])
 
 
