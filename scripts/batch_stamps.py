@@ -19,7 +19,8 @@ ws = ops.MllWorkspace(B, n, True, K.device)
 nb = ops.padded_n(n) // 128
 lad = int(os.environ.get("VOLT_BATCH_LAD", "0"))
 while lad > 0 and 2 * lad * B > 128: lad -= 1              # batch_step.hip, batch_lad()
-order = int(os.environ.get("VOLT_BATCH_ORDER", "0")) | lad << 1
+order = int(os.environ.get("VOLT_BATCH_ORDER", "-1"))    # -1: the order the step picks for this shape (round 6: windowed for large batches)
+order = -1 if order < 0 else (1000 + order if order >= 2 else order | lad << 1)
 cnt = L.volt_batch_describe(B, nb, 1, order, None, 0)
 buf = (C.c_int * (4 * cnt))()
 assert L.volt_batch_describe(B, nb, 1, order, buf, cnt) == cnt
@@ -88,7 +89,7 @@ print(f"  resident workgroups: time-weighted mean {np.sum(conc * w) / span:.1f},
 print(f"  first piece of the last block column starts at {beg[(kind == 0) & (items[:, 1] == nb - 1)].min():.1f} us; last trtri row starts {beg[(kind == 4) & (items[:, 1] == nb - 1)].min():.1f}")
 print("  xcc of workgroup w (first 16):", xcc[:16].tolist(), " distinct (se,sh,cu):", len(set(zip(xcc.tolist(), se.tolist(), sh_.tolist(), cu.tolist()))))
 mism = (xcc != (np.arange(cnt) % 8)).sum()
-print(f"  workgroups NOT on XCD w % 8: {mism}")
+print(f"  pieces run on an XCD other than (piece % 8) -- queues adopted by another XCD, or the one queue of a batch that is not a multiple of 8: {mism}")
 # dispatch order: is entry time monotone in w per XCD?
 for xq in range(1):
     m = xcc == xq

@@ -20,10 +20,12 @@
 //     T(i,j)    S = Y[j, j..i) L[i, j..i)^T (chasing tcol[j] and rowp[i]), Y[j,i] = -S W_i^T; publishes tcol[j] = i - j + 1
 // What a block column costs on the latency chain is then the diagonal block's pivots (~40 us) plus ONE 32-column step and one
 // rank-32 update (~7 us): the inverse W_k, the write-out and every hand-off of a whole tile are off it.
-// The list needs no table: D(0), then per block column k: LA(k+1), D(k+1) -- resident, its sums under way, while D(k) is
-// still at its pivots --, US(k+2 .. n-1, k), then row k-1 of the inverse (TD, T longest first); every position for all B
-// matrices with the matrix innermost, and a workgroup finds its piece from blockIdx alone.  Workgroups are dispatched in grid order and every piece waits only for pieces listed before it, so whatever a
-// resident workgroup waits for is resident or finished.  The diagonal block's image takes 133 KB of LDS: ONE workgroup per CU,
+// The list needs no table: D(0), then per block column k: LA(k+1), D(k+1) -- its sums under way while D(k) is still at its
+// pivots --, US(k+2 .. n-1, k), then row k-1 of the inverse (TD, T longest first); every position for all B matrices with the
+// matrix innermost, and a piece is a closed-form function of its index.  The pieces are pulled BY TICKET by a grid of resident
+// workgroups (round 6; common.h, "who runs which piece"): every piece waits only for pieces listed before it and a ticket is
+// taken by a running workgroup, so whatever is waited for is running or finished -- wherever and in whatever order workgroups
+// start.  The diagonal block's image takes 133 KB of LDS: ONE workgroup per CU,
 // which is also what the latency chain wants (batch_step.hip: a pivot chain that shares its CU runs 2.5 x slower) -- and why
 // this is the schedule of small batches only; from batch64_max tiles per block column on, chol64.hip's bulk kernels (two per
 // CU) win.

@@ -2,10 +2,11 @@
 //
 // One MLL + gradient step of B matrices of n block columns is B * (n (n + 3) / 2 + ...) tiles with a fixed dependency
 // graph.  The launch-per-column schedules (chol.hip) cut that graph at every block column: 32 launches, each as long as
-// its longest tile plus a tail.  Here the whole step is ONE grid whose workgroup w runs piece w of this list.  The list is
-// in TOPOLOGICAL order and workgroups are dispatched in grid order, so whatever a resident workgroup waits for is
-// resident or finished (the protocol of trsv.hip, small_step_kernel and the W_k hand-off); tiles do not wait for their
-// inputs before they start but chase them K block by K block (common.h, Chase).
+// its longest tile plus a tail.  Here the whole step is ONE launch whose workgroups pull the pieces of this list by ticket
+// (common.h, "who runs which piece").  The list is in TOPOLOGICAL order: a piece only waits for pieces listed before it, a
+// ticket is taken by a running workgroup, so whatever is waited for is running or finished -- in whatever order the
+// dispatcher starts workgroups; tiles do not wait for their inputs before they start but chase them K block by K block
+// (common.h, Chase).
 //
 // Order: for k = 0 .. n-1 the pieces of block column k --
 //     D(k)        diagonal tile (k,k): last K block, factor, invert -> W_k
@@ -14,10 +15,10 @@
 //     TD(k-1), T(k-1,j), j = 0 .. k-2     row k-1 of the triangular inverse (if wanted), longest tile first
 //     AL(k-2)     block k-2 of z = Y'r (the sum of row k-2's z-partials) and alpha's partial sums from block column k-2
 //                 of Y: an HBM / L2 stream that rides beside the MFMA tiles (mll.hip's sum_zpart / y_times_z launches)
-// and finally row n-1 of the inverse with AL(n-2), AL(n-1).  Every position is emitted for all B matrices, matrix innermost: with B a multiple
-// of 8 piece w belongs to matrix w % 8 (mod 8), the dispatcher places workgroup w on XCD w % 8, so a matrix lives on ONE
-// XCD -- its shared block rows in one L2, its hand-offs through it -- exactly what decode_tile_batch arranges for the
-// launch-per-column grids.
+// and finally row n-1 of the inverse with AL(n-2), AL(n-1).  Every position is emitted for all B matrices in groups of 8 that
+// alternate: with B a multiple of 8 piece w belongs to a matrix = w (mod 8), and ticket t of queue q is piece 8 t + q -- queue q is
+// the matrices = q (mod 8), claimed and run by ONE XCD (the pullers read their XCC id), so a matrix lives under one L2: its
+// shared block rows in it, its hand-offs through it.
 #pragma once
 #include <cstdint>
 #include <vector>

@@ -3,10 +3,11 @@
 //
 // The launch-per-column schedules of chol.hip give a step of B matrices of n block columns n + 1 launches, each as long as
 // its longest tile and ended by a tail in which most CUs idle; two stream groups hide part of that, a hipGraph capture
-// cannot (one group), and 8 .. 16 matrices at N = 4096 or 64 at N = 2048 are bounded by exactly these boundaries.  Here
-// workgroup w runs piece w of the host's topologically ordered list (batch_sched.h): diagonal tiles, look-ahead tiles,
-// two-phase panel tiles, rows of the triangular inverse -- the tile bodies are the ones every other schedule runs
-// (tiles.h), so the arithmetic, and with it every bit of the result, is the launch-per-column path's.  What is new:
+// cannot (one group), and 8 .. 16 matrices at N = 4096 or 64 at N = 2048 are bounded by exactly these boundaries.  Here the
+// pieces of the host's topologically ordered list (batch_sched.h) -- diagonal tiles, look-ahead tiles, two-phase panel tiles,
+// rows of the triangular inverse -- are pulled BY TICKET by a grid of resident workgroups (round 6, common.h "who runs which
+// piece": nothing is assumed about where or in what order workgroups start); the tile bodies are the ones every other
+// schedule runs (tiles.h), so the arithmetic, and with it every bit of the result, is the launch-per-column path's.  What is new:
 //   * hand-offs by PROGRESS WORDS per matrix in the caller's scratch (cleared by batch_begin_kernel ahead of the launch):
 //       rowp[i]  = block columns of block row i of L that are complete (P(i,k) stores k + 1 behind its tile)
 //       tcol[j]  = tiles of block column j of X = L^-1 that are complete (TD(j) stores 1, T(i,j) stores i - j + 1)

@@ -491,9 +491,15 @@ class _ExactMLL(torch.autograd.Function):
         ctx.has_scale = scale is not None
         ctx.want_dk = want_dk
         if need_grad:
-            extra = (out[:, 2:6].clone(), noise.detach().clone(), scale.detach().clone()) if scale is not None else ()
+            # the step's outputs live in the workspace, which the next forward overwrites: ONE packed copy of what backward
+            # needs ([B, 8 + N]: the scalars and alpha) instead of a clone per tensor -- the iteration of a short series is
+            # launch-bound (profiles/r06/pipeline_kernel_stats.csv: ~45 tiny kernels beside a 0.13 ms step), every copy is one
+            pk = torch.cat((out, alpha), dim=1)
+            keep = lambda t: t.detach().clone() if t.is_leaf else t.detach()     # (computed tensors are fresh already)
+            extra = (pk[:, 2:6], keep(noise), keep(scale)) if scale is not None else ()
             gk = (ops.mll_grad_k(ws),) if want_dk else ()       # 1/2 (a a' - K_s^-1) / N from the step's own Y = L^-T
-            ctx.save_for_backward(out[:, 1].clone(), alpha.clone(), *gk, *extra)
+            ctx.save_for_backward(pk[:, 1], pk[:, 8:], *gk, *extra)
+            return pk[:, 0]
         return out[:, 0].clone()
 
     @staticmethod
