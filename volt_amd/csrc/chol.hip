@@ -467,6 +467,7 @@ static Tunables read_env(Tunables t) {                       // VOLT_TUNE=1 proc
         geti("VOLT_BATCH_LAD", t.batch_lad);
         geti("VOLT_BATCH_PULLERS", t.batch_pullers);
         geti("VOLT_ROLLOUT_LANE", t.rollout_lane);
+        geti("VOLT_LONG_PULLERS", t.long_pullers);
         geti("VOLT_BATCH_XSKEW", t.batch_xskew);
         geti("VOLT_BATCH_XDROP", t.batch_xdrop);
         geti("VOLT_BATCH64", t.batch64);

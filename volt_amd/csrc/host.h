@@ -35,6 +35,7 @@ struct Tunables {
     int batch64_max_step = 2500;
     int batch_local = 1;                       // ... batches that are a multiple of 8 hand their tiles on through the XCD's L2 (0: the agent-scope protocol everywhere)
     int batch_pullers = 1;                     // ... its grid: this many times the workgroups the chip holds at once, pulling pieces by ticket (0: one workgroup per piece -- they pull all the same)
+    int long_pullers = 1;                      // one long series: this many times the resident workgroups pull its pieces by ticket (0: a workgroup per piece -- they take tickets all the same)
     int rollout_lane = 1;                      // rollouts: one lane per path where the mean's window fits the LDS ring (0: a wave per path everywhere -- the tests compare the two)
     int batch_xskew = 0, batch_xdrop = 0;      // ... tests only: the queues of the XCDs shifted by this many (the map is nobody's assumption); bit x set = the pullers on XCD x leave at once (an XCD a CU mask emptied: its queue is adopted)
 };

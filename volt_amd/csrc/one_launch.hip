@@ -63,6 +63,7 @@ struct SmallState {
     long long* stamps;                         // tuning only (volt_tune_small_stamps): 16 per workgroup, else nullptr
 };
 __host__ __device__ inline int small_stride(int n) { return (4 + 7 * n + 2 * n * n + 31) & ~31; }
+#define LONG_STAMP(i) do { if (st.stamps && threadIdx.x == 0) st.stamps[(int64_t)pw * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define SMALL_STAMP(i) do { if (st.stamps && threadIdx.x == 0) st.stamps[(int64_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 struct SmallTail {
     const float* resid;                        // [B,N]
@@ -557,7 +558,7 @@ __device__ __forceinline__ void small_tail_scalars(const float* __restrict__ A, 
 
 __global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
                                                            float* __restrict__ Y, int* __restrict__ info, int Np, int B,
-                                                           KSource src, TriReduce red, SmallState st, SmallTail tl) {
+                                                           KSource src, TriReduce red, SmallState st, SmallTail tl, int tickets) {
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
     __shared__ int s_last;
     const int n = Np / TS, tid = threadIdx.x;
@@ -568,7 +569,18 @@ __global__ __launch_bounds__(256, 2) void small_step_kernel(float* __restrict__ 
     const int want = __hip_atomic_load(st.hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
     // ---- which piece.  Group k: D(0) | S(k), the panel pieces P(k+2.., k), U(k+1) -- piece-major, series-minor -- and then
     // the k tiles of row k-1 of the inverse, series-major (the pieces of a row next to each other: they wait for each other).
-    int w = blockIdx.x, b = 0, k = 0, i = 0, j = 0, kind = -1;          // kind 0: D(0) / S(k)  1: P(i,k)  2: T(i,j)  3: U(k)
+    // Which piece this workgroup runs: its grid index while the whole grid is resident at once (nothing then depends on the
+    // order workgroups start in), a TICKET otherwise (round 6): a piece only waits for pieces listed before it, and a ticket is
+    // taken by a running workgroup -- the step does not lean on workgroups being dispatched in grid order.  The ticket word
+    // (hdr[32]) is never cleared: step number `want` starts at (want - 1) * gridDim.x.
+    int w = blockIdx.x;
+    if (tickets) {
+        if (tid == 0) s_last = (int)((unsigned)__hip_atomic_fetch_add(st.hdr + 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                                     (unsigned)(want - 1) * gridDim.x);
+        __syncthreads();
+        w = __builtin_amdgcn_readfirstlane(s_last);
+    }
+    int b = 0, k = 0, i = 0, j = 0, kind = -1;                          // kind 0: D(0) / S(k)  1: P(i,k)  2: T(i,j)  3: U(k)
     for (int kk = 0; kk <= n && kind < 0; ++kk) {
         const int np = kk < n && n - kk - 2 > 0 ? n - kk - 2 : 0;
         const int nu = (kk >= 1 && kk + 1 <= n - 1) ? 1 : 0;
@@ -789,18 +801,24 @@ __device__ __forceinline__ void rank32_update(f32x16 (&X)[4], const float* sL, i
     }
 }
 
-__global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
-                                                          float* __restrict__ Y, int* __restrict__ info, int Np,
-                                                          KSource src, TriReduce red, LongState st, SmallTail tl) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE_FLOATS];
-    __shared__ int s_last;
+// LDS of the long-series step (namespace scope: the piece body below is a function of its own)
+static __shared__ __attribute__((aligned(16))) float g_long_smem[2 * STAGE_FLOATS];
+static __shared__ int g_long_last;
+static __shared__ int g_long_piece;
+
+// One piece of the long-series list.  pw: its index in the list (a TICKET since round 6: long_step_kernel below), want: the
+// number of this step (the flags carry it), npieces: pieces of the list.
+__device__ __forceinline__ void long_piece(float* __restrict__ A, float* __restrict__ Winv, float* __restrict__ Y,
+                                           int* __restrict__ info, const int Np, const KSource src, const TriReduce red,
+                                           const LongState st, const SmallTail tl, const int pw, const int want, const int npieces) {
+    float* const smem = g_long_smem;
+    int& s_last = g_long_last;
     const int n = Np / TS, tid = threadIdx.x;
-    if (st.hdr[0] != SMALL_MAGIC || st.hdr[1] != 1 || st.hdr[2] != n) {          // not (or no longer) what init wrote
-        if (tid == 0 && blockIdx.x == 0) info[0] = (int)0x80000001;
-        return;
-    }
-    const int want = __hip_atomic_load(st.hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    const int4 item = st.items[blockIdx.x];
+    int4 item = st.items[pw];
+    item.x = __builtin_amdgcn_readfirstlane(item.x);               // (uniform, said so here: batch_step.hip, batch_piece)
+    item.y = __builtin_amdgcn_readfirstlane(item.y);
+    item.z = __builtin_amdgcn_readfirstlane(item.z);
+    item.w = __builtin_amdgcn_readfirstlane(item.w);
     const int pk = item.x & 255, pa = (item.x >> 8) & 255, pb = (item.x >> 16) & 255;
     const bool isE = pk >= LG_E_PANEL && pk <= LG_E_U;
     const int nslices = isE ? 0 : item.y;                           // base pieces: slices their early part came in
@@ -816,7 +834,7 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
     int* ecnt = hf + 4 * n;
     int* info_b = info;
     float* Ab = A;
-    SMALL_STAMP(0);
+    LONG_STAMP(0);
     auto wait_slices = [&]() {
         if (tid == 0 && !wait_flag_backoff(ecnt + item.w, (int)((unsigned)want * (unsigned)nslices))) atomicCAS(info_b, 0, (int)0x80000000);
         __syncthreads();
@@ -893,7 +911,7 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
                 slab_add_sc1(X, st.eslab + (int64_t)ui.z * TS * TS, 1);
             }
         }
-        SMALL_STAMP(1);
+        LONG_STAMP(1);
         const float* Lt = Ab + (int64_t)k * TS * Np + (int64_t)(k - 1) * TS;
         const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)Lt, 0, 0x7fffffff, 0x00020000);
         float* sL = smem;
@@ -902,7 +920,7 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
         for (int j = 0; j < 4; ++j) {
             if (tid == 0 && !wait_flag(hf + 4 * k + j, 4 * want, 2)) atomicCAS(info_b, 0, (int)0x80000000);
             __syncthreads();
-            if (st.stamps && tid == 0) st.stamps[(int64_t)blockIdx.x * 16 + 6 + j] = __builtin_amdgcn_s_memrealtime();
+            if (st.stamps && tid == 0) st.stamps[(int64_t)pw * 16 + 6 + j] = __builtin_amdgcn_s_memrealtime();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -926,9 +944,9 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
                         sL[r * DT + c] = (c <= r) ? -X[tm * 2 + tn][q] : 0.f;
                     }
         }
-        SMALL_STAMP(3);
+        LONG_STAMP(3);
         diag_body<false, true>(A, Winv, info, Np, k, 0, smem, nullptr, true, wf + k, want, sf + 4 * k);
-        SMALL_STAMP(4);
+        LONG_STAMP(4);
     } else if (pk == LG_TDIAG) {
         small_wait(wf + pa, nullptr, want, info_b);
         small_diag_tile(Winv, Y, Np, pa, 0, red, tl, rowc + pa, want, info_b, smem);
@@ -971,7 +989,7 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
             wait_slices();
             slab_add_sc1(T, eslabs, nslices);
         }
-        SMALL_STAMP(2);
+        LONG_STAMP(2);
         if (isE) {
             slice_out(T, st.eslab + (int64_t)item.z * TS * TS, ecnt + item.w);
         } else if (!isT) {
@@ -982,7 +1000,7 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
             if (pk == LG_SPINE && st.split) {
                 // split spine: the tile by substitution, handed on slab by slab to R(k); its flag goes up here
                 ok = substitute_tile<0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
-                                        st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr, NoOp(), hf + 4 * pa);
+                                        st.stamps ? st.stamps + (int64_t)pw * 16 : nullptr, NoOp(), hf + 4 * pa);
                 if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
                 // every word of the tile went out written through and has been waited for (hand_on): the flag needs no
                 // release fence -- an L2-wide write-back that would sit on the chain
@@ -1009,12 +1027,12 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
                 // written through it a moment ago -- and plain loads spare the trip through the fabric that sc1 loads make
                 if (st.xcd_from > 0 && kd >= st.xcd_from)
                     ok = substitute_tile<1, NoOp, 0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
-                                                     st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
+                                                     st.stamps ? st.stamps + (int64_t)pw * 16 : nullptr);
                 else
                     ok = substitute_tile<1>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X,
-                                            st.stamps ? st.stamps + (int64_t)blockIdx.x * 16 : nullptr);
+                                            st.stamps ? st.stamps + (int64_t)pw * 16 : nullptr);
                 if ((tid & 63) == 0 && !ok) atomicCAS(info_b, 0, (int)0x80000000);
-                SMALL_STAMP(4);
+                LONG_STAMP(4);
                 diag_body<false, true>(A, Winv, info, Np, k, 0, smem, nullptr, true, wf + k, want, sf + 4 * k, lf + k * n + kd);
             } else {
                 ok = substitute_tile<0>(T, Lkk, Np, Wk, sf + 4 * kd, want, jb.out, smem, X);
@@ -1072,14 +1090,52 @@ __global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A
         if (s_last) small_tail_scalars(A, Np, 0, red, tl, reinterpret_cast<double*>(smem + SMALL_SPARE));
         if (pk == LG_TDIAG) small_diag_tile_out(Y, Np, pa, 0, yf + pa * n + pa, want, smem);
     }
-    SMALL_STAMP(5);
+    LONG_STAMP(5);
     if (tid == 0) {                                                // the last workgroup out closes the step
         const int f = __hip_atomic_fetch_add(st.hdr + 4, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (f == (int)gridDim.x - 1) {
+        if (f == npieces - 1) {
             __hip_atomic_store(st.hdr + 4, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st.hdr + 3, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+
+// The pieces are pulled BY TICKET by a grid of resident workgroups (round 6; the scheme of batch_step.hip / common.h, one queue):
+// a piece only waits for pieces listed before it and a ticket is taken by a running workgroup, so the step no longer leans on
+// workgroups being dispatched in grid order.  The ticket word (hdr[32], a line of its own) is never cleared: a step of G
+// pullers takes exactly npieces + G tickets (every puller one too many), so step number `want` starts at
+// (want - 1) * (npieces + G) -- like the flags, a replayed hipGraph needs no host-side argument to change.
+// The loop is an irreducible cycle for the optimiser's sake (batch_step.hip).
+__global__ __launch_bounds__(256, 1) void long_step_kernel(float* __restrict__ A, float* __restrict__ Winv,
+                                                          float* __restrict__ Y, int* __restrict__ info, int Np,
+                                                          KSource src, TriReduce red, LongState st, SmallTail tl, int npieces,
+                                                          int never) {
+    const int n = Np / TS, tid = threadIdx.x;
+    if (st.hdr[0] != SMALL_MAGIC || st.hdr[1] != 1 || st.hdr[2] != n) {          // not (or no longer) what init wrote
+        if (tid == 0 && blockIdx.x == 0) info[0] = (int)0x80000001;
+        return;
+    }
+    const int want = __hip_atomic_load(st.hdr + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const unsigned base = (unsigned)(want - 1) * ((unsigned)npieces + gridDim.x);
+    int pw;
+    if (never) {
+        pw = never | (int)0x80000000;
+        goto piece;
+    }
+pull_next:
+    __syncthreads();                                               // the last piece's LDS traffic is over
+    if (tid == 0) {
+        const unsigned t = (unsigned)__hip_atomic_fetch_add(st.hdr + 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+        g_long_piece = t < (unsigned)npieces ? (int)t : -1;
+    }
+    __syncthreads();
+    pw = g_long_piece;
+piece:
+    pw = __builtin_amdgcn_readfirstlane(pw);
+    if (pw < 0) return;
+    long_piece(A, Winv, Y, info, Np, src, red, st, tl, pw, want, npieces);
+    goto pull_next;
 }
 
 }  // namespace volt
@@ -1126,8 +1182,10 @@ int volt_internal_small_step(const float* K, int64_t ldk, int64_t bsk, const flo
     // 71 us per diagonal block against 22): while every series can still have ~8 pieces resident, a workgroup gets a CU
     // to itself (16 KB of dynamic LDS on top of the 72 KB: one workgroup per 160 KB CU)
     const unsigned pad = B <= tunables().small_pad_maxb ? 16 * 1024 : 0;
-    hipLaunchKernelGGL(small_step_kernel, dim3(B * small_pieces(n)), dim3(256), pad, (hipStream_t)stream, A, Winv, Y, info, Np,
-                       B, src, red, st, tl);
+    const int grid = B * small_pieces(n);
+    const int tickets = grid > tunables().cus * (pad ? 1 : 2);     // more workgroups than the chip holds at once: pieces by ticket
+    hipLaunchKernelGGL(small_step_kernel, dim3(grid), dim3(256), pad, (hipStream_t)stream, A, Winv, Y, info, Np,
+                       B, src, red, st, tl, tickets);
     VOLT_LAUNCH_CHECK();
     return 1;
 }
@@ -1235,10 +1293,14 @@ int volt_internal_long_step(const float* K, int64_t ldk, int64_t bsk, const floa
     const TriReduce red{rpad, zpart, frob, N};
     const SmallTail tl{resid, rpad, z, apad, apart, sigma2, jitter, out, alpha, N};
     const int4* tab = reinterpret_cast<const int4*>(reinterpret_cast<char*>(state) + flag_bytes);
-    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps, pd->xcd_from, tunables().long_split};
+    // (xcd_from: the spines-on-XCD-0 variant assumed the grid index -> XCD map; pieces are pulled by ticket now, so it is off)
+    const LongState st{base, base + SMALL_HDR, tab, tab + pd->nitems, eslab, g_small_stamps, 0, tunables().long_split};
     // one workgroup per CU (16 KB of LDS padding): a pivot chain that shares its CU runs 1.5 - 3x slower
     const unsigned pad = tunables().long_pad ? 16 * 1024 : 0;
-    hipLaunchKernelGGL(long_step_kernel, dim3(pd->nitems), dim3(256), pad, s, A, Winv, Y, info, Np, src, red, st, tl);
+    // as many pullers as the chip holds at once (nothing depends on the number: the kernel derives its ticket base from it)
+    const int pullers = std::min(pd->nitems, tunables().cus * (pad ? 1 : 2) * std::max(1, tunables().long_pullers));
+    const int grid = tunables().long_pullers > 0 ? pullers : pd->nitems;
+    hipLaunchKernelGGL(long_step_kernel, dim3(grid), dim3(256), pad, s, A, Winv, Y, info, Np, src, red, st, tl, pd->nitems, 0);
     VOLT_LAUNCH_CHECK();
     return 1;
 }
