@@ -75,4 +75,6 @@ if DS:
     for i in (1, nb // 2, nb - 1):
         v = ds[i]
         idx = [j for j in sorted(lab) if v[j] > 0]
-        print(f"diagonal block {i} (us since its entry): " + "  ".join(f"{lab[j]} {(v[j] - v[0]) / 100.0:.1f}" for j in idx))
+        print(f"diagonal block {i} (us since its entry): " + "  ".join(f"{lab[j]} {(v[j] - v[0]) / 100.0:.1f}" for j in idx)
+              + (f"  [phase 1, us after trail0: waves 0, 1 (pivots) {(v[21] - v[5]) / 100.0:.1f} {(v[22] - v[5]) / 100.0:.1f}, wave 2 (idle) {(v[23] - v[5]) / 100.0:.1f}, wave 3 (inverse) {(v[24] - v[5]) / 100.0:.1f}]" if v[21] > 0 else "")
+              + (f"  [s_memtime ran at {(v[31] - v[30]) / ((v[20] - v[0]) / 100.0):.0f} MHz]" if v[31] > v[30] > 0 else ""))

@@ -28,3 +28,7 @@ for i in sorted(names):
     if s[i] == 0: continue
     print(f"{names[i]:26s} {(s[i] - prev) * 0.01:8.2f} us   (t = {(s[i] - s[0]) * 0.01:7.2f})")
     prev = s[i]
+if s[31] > s[30] > 0:
+    print(f"s_memtime ran at {(s[31] - s[30]) / ((s[20] - s[0]) * 0.01):.0f} MHz over the block")
+if s[21] > 0:
+    print("phase 1, us after trailing[0]: waves 0, 1 (pivots) %.2f %.2f, wave 2 (idle) %.2f, wave 3 (inverse of sub-block 0) %.2f" % tuple((s[21 + w] - s[5]) * 0.01 for w in range(4)))

@@ -279,76 +279,92 @@ __device__ __forceinline__ double rl64(double v, int src) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// c_i = fma(-l, broadcast(l, lane_i), c_i): the SGPR broadcasts (two v_readlane_b32 per double, into FIXED SGPR pairs
-// s[90:95], declared clobbered) and their FMAs pinned together in one asm block.  Left to the compiler every broadcast
-// of a pivot is hoisted to the top and spilled lane by lane through v_writelane (the fp32 block has the same story,
-// chol.hip rl_fma3); a VALU may read a readlane's SGPR two wait states after it -- groups of three cover each other,
-// shorter ones pad with s_nop.
-__device__ __forceinline__ void rl_fma64_3(double& c0, double& c1, double& c2, double l, int lo, int hi, int l0, int l1, int l2) {
-    asm volatile("v_readlane_b32 s90, %4, %6\n\tv_readlane_b32 s91, %5, %6\n\t"
-                 "v_readlane_b32 s92, %4, %7\n\tv_readlane_b32 s93, %5, %7\n\t"
-                 "v_readlane_b32 s94, %4, %8\n\tv_readlane_b32 s95, %5, %8\n\t"
-                 "v_fma_f64 %0, -%3, s[90:91], %0\n\tv_fma_f64 %1, -%3, s[92:93], %1\n\tv_fma_f64 %2, -%3, s[94:95], %2"
-                 : "+v"(c0), "+v"(c1), "+v"(c2)
-                 : "v"(l), "v"(lo), "v"(hi), "i"(l0), "i"(l1), "i"(l2)
-                 : "s90", "s91", "s92", "s93", "s94", "s95");
-}
-__device__ __forceinline__ void rl_fma64_2(double& c0, double& c1, double l, int lo, int hi, int l0, int l1) {
-    asm volatile("v_readlane_b32 s90, %3, %5\n\tv_readlane_b32 s91, %4, %5\n\t"
-                 "v_readlane_b32 s92, %3, %6\n\tv_readlane_b32 s93, %4, %6\n\t"
-                 "v_fma_f64 %0, -%2, s[90:91], %0\n\ts_nop 0\n\tv_fma_f64 %1, -%2, s[92:93], %1"
-                 : "+v"(c0), "+v"(c1)
-                 : "v"(l), "v"(lo), "v"(hi), "i"(l0), "i"(l1)
-                 : "s90", "s91", "s92", "s93");
-}
+// c = fma(-l, broadcast(l, lane l0), c): the SGPR broadcast (two v_readlane_b32 into the FIXED pair s[90:91], declared clobbered)
+// and its FMA pinned together in one asm block.  A VALU result needs a wait state before v_readlane reads it, and a VALU may read
+// a readlane's SGPR two wait states after it: the s_nops.
 __device__ __forceinline__ void rl_fma64_1(double& c0, double l, int lo, int hi, int l0) {
-    asm volatile("v_readlane_b32 s90, %2, %4\n\tv_readlane_b32 s91, %3, %4\n\ts_nop 1\n\t"
+    asm volatile("s_nop 0\n\tv_readlane_b32 s90, %2, %4\n\tv_readlane_b32 s91, %3, %4\n\ts_nop 1\n\t"
                  "v_fma_f64 %0, -%1, s[90:91], %0"
                  : "+v"(c0)
                  : "v"(l), "v"(lo), "v"(hi), "i"(l0)
                  : "s90", "s91");
 }
 
+// a[c] += rep[16 R + n] * m in every row R of 16 lanes: the multiplicand comes through the DPP row_newbcast path (the only DPP
+// control the 64-bit VALU has), one 8-byte instruction where the SGPR broadcast needs two v_readlane_b32 and a v_fma_f64
+__device__ __forceinline__ void fmac64_row(double& c, double rep, double m, int n) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(c) : "v"(rep), "v"(m), "i"(n));
+}
+// lanes src0 + (lane & 15) of v, repeated in all four rows of 16 lanes
+__device__ __forceinline__ double rows_of64(int lo, int hi, int src0) {
+    const int at = 4 * (src0 + (threadIdx.x & 15));
+    const unsigned r0 = (unsigned)__builtin_amdgcn_ds_bpermute(at, lo), r1 = (unsigned)__builtin_amdgcn_ds_bpermute(at, hi);
+    return __builtin_bit_cast(double, ((unsigned long long)r1 << 32) | r0);
+}
+
 // One WAVE factors the 32x32 diagonal sub-block (kb,kb) with one matrix row per lane in registers -- the idiom of the
-// fp32 diagonal block (chol.hip): per pivot the pivot and the column entries travel by v_readlane (SGPR broadcast),
-// so the 32 dependent pivots cost no barrier and no LDS round trip.  (Round 5 tried the broadcast through LDS instead -- every
-// lane leaves its l in a per-wave buffer, all lanes read entries j+1 .. 31 back 16 bytes at a time: a quarter of the
-// instructions -- and measured 6.4 us per 32 pivots against 6.9 alone, but 9.5 against 6.3 while another wave inverts the
-// previous sub-block from the same LDS: not kept.)  Lanes 0..31 hold the rows of the diagonal
-// sub-block; lanes 32..63 the rows of the panel block (prow,kb) below it, which the very same instructions turn into
-// L[prow,kb] = A[prow,kb] L_kk^-T -- no inverse is needed on the way down.  Several waves run this side by side, each
+// fp32 diagonal block (chol.hip): the 32 dependent pivots cost no barrier and no LDS round trip.  Lanes 0..31 hold the rows of
+// the diagonal sub-block; lanes 32..63 the rows of the panel block (prow,kb) below it, which the very same instructions turn
+// into L[prow,kb] = A[prow,kb] L_kk^-T -- no inverse is needed on the way down.  Several waves run this side by side, each
 // with its own copy of the (tiny) diagonal factorisation and its own panel block; the one with `own` writes L_kk and
-// the reciprocal pivots back.  (The first version -- 256 threads, 2x2 cyclic elements each, one barrier per pivot --
-// took 19.7 us per sub-block, 79 of the kernel's 139 us: scripts/tune_diag64.py.)
+// the reciprocal pivots back.
+//
+// What the phase costs is the NUMBER of instructions: a lone wave issues one 4-byte VALU instruction per 4 clocks and one
+// 8-byte instruction per 5 (scripts/ubench/issue_rate.hip), and the pivot chain itself hides under the updates
+// (scripts/ubench/phase64.hip takes the phase apart).  Through round 5 every update a[c] -= l_r l_c was two v_readlane_b32
+// (l_c into an SGPR pair) and one v_fma_f64, and every pivot carried a wave-uniform branch (d > 0 ?) and an exec-masked LDS
+// store of the reciprocal pivot: 5.9 us per 32 pivots, of which the two branches 1.4.  Now:
+//   * lane j KEEPS 1 / L[j][j] (two v_cndmask); it is stored, and tested, once after the loop -- a pivot that is not > 0 (or NaN)
+//     leaves a NaN there (rsq(0) = inf times 0 in the Newton step, rsq(d < 0) = NaN) and only LATER pivots inherit it, so the
+//     first lane with !(rs > 0) is the pivot LAPACK reports;
+//   * the l column of a pivot is repeated in all four rows of 16 lanes by ds_bpermute (lanes 0..15's and lanes 16..31's: two
+//     copies), and the updates read it through DPP row_newbcast: ONE v_fmac_f64 per element.  Only the next pivot's own column
+//     still takes the SGPR path, straight away; the others run one pivot LATE, under the flight of the next bpermute pair, so
+//     the LDS crossbar's latency is never waited for;
+//   * the products are the same and so is their order per element: the factor is bit-identical to round 5's.
+// 3.6 us per 32 pivots alone, 3.8 with a second wave beside it (ubench); in the kernel: scripts/tune_diag64.py.
+// (Round 5 tried the broadcast through LDS memory instead -- every lane leaves its l in a per-wave buffer, all lanes read entries
+// j+1 .. 31 back 16 bytes at a time -- and measured 6.4 us against 6.9 alone, but 9.5 against 6.3 while another wave inverts the
+// previous sub-block from the same LDS.  The first version -- 256 threads, 2x2 cyclic elements each, one barrier per pivot --
+// took 19.7 us per sub-block, 79 of the kernel's 139 us.)
 __device__ __forceinline__ void pivot_phase64(double* __restrict__ sT, double* __restrict__ rdiag, int kb, int prow, bool own,
                                               int& bad) {
     const int lane = threadIdx.x & 63, l31 = lane & 31;
     const bool up = lane >= 32;
     double* rowp = up ? sT + (32 * (prow < 0 ? kb : prow) + l31) * DT64 + 32 * kb : sT + (32 * kb + l31) * DT64 + 32 * kb;
     const bool live = !up || prow >= 0;
-    double a[32];
+    double a[32], rsv = 1.0;
 #pragma unroll
     for (int c = 0; c < 32; ++c) a[c] = live ? rowp[c] : 0.0;
+    double rep0p = 0.0, rep1p = 0.0, lp = 0.0;                      // pivot j-1: -l of lanes 0..15 / 16..31 in every row, and l
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
         const double d = rl64(a[j], j);                             // pivot: row j of the diagonal half
-        if (!(d > 0.0) && bad == 0) bad = 32 * kb + j + 1;          // wave-uniform
         double rs = __builtin_amdgcn_rsq(d);                        // 1/sqrt(d): v_rsq_f64 + two Newton steps
         rs = rs * (1.5 - 0.5 * d * rs * rs);
         rs = rs * (1.5 - 0.5 * d * rs * rs);
         const double l = a[j] * rs;                                 // lane r: L[r][j]  (lane j: d rs = sqrt d)
         a[j] = l;
-        if (own && lane == 0) rdiag[32 * kb + j] = rs;              // 1 / L[j][j] for the inverse
-        // a[r][c] -= L[r][j] L[c][j] for c > j, L[c][j] broadcast from lane c of the diagonal half
-        double lv = l;
-        asm volatile("s_nop 0" : "+v"(lv));                         // a VALU result needs a wait state before v_readlane reads it
-        const unsigned long long lu = __builtin_bit_cast(unsigned long long, lv);
+        rsv = (lane == j) ? rs : rsv;                               // 1 / L[j][j] for the inverse, and the test below
+        const unsigned long long lu = __builtin_bit_cast(unsigned long long, l);
         const int llo = (int)(unsigned)lu, lhi = (int)(unsigned)(lu >> 32);
-        int c = j + 1;
+        double rep0 = 0.0, rep1 = 0.0;                              // -l: the sign goes in with the high word
+        if (j + 2 < 16) rep0 = rows_of64(llo, lhi ^ (int)0x80000000u, 0);
+        if (j + 2 < 32) rep1 = rows_of64(llo, lhi ^ (int)0x80000000u, 16);
+        // the next pivot's column: what pivot j-1 still owes it, then pivot j's own term by the SGPR path
+        if (j >= 1 && j + 1 < 32) fmac64_row(a[j + 1], j + 1 < 16 ? rep0p : rep1p, lp, (j + 1) & 15);
+        if (j + 1 < 32) rl_fma64_1(a[j + 1], l, llo, lhi, j + 1);
+        // pivot j-1's other columns: its bpermutes landed a whole pivot ago
+        if (j >= 1) {
 #pragma unroll
-        for (; c + 2 < 32; c += 3) rl_fma64_3(a[c], a[c + 1], a[c + 2], lv, llo, lhi, c, c + 1, c + 2);
-        if (c + 1 < 32) rl_fma64_2(a[c], a[c + 1], lv, llo, lhi, c, c + 1);
-        else if (c < 32) rl_fma64_1(a[c], lv, llo, lhi, c);
+            for (int c = j + 2; c < 32; ++c) fmac64_row(a[c], c < 16 ? rep0p : rep1p, lp, c & 15);
+        }
+        rep0p = rep0; rep1p = rep1; lp = l;
+    }
+    {
+        const unsigned nb = (unsigned)__builtin_amdgcn_ballot_w64(!(rsv > 0.0));     // lanes 0..31: the pivots
+        if (nb != 0 && bad == 0) bad = 32 * kb + __builtin_ctz(nb) + 1;              // wave-uniform
+        if (own && !up) rdiag[32 * kb + l31] = rsv;
     }
     if (up) {
         if (prow >= 0) {
@@ -361,27 +377,34 @@ __device__ __forceinline__ void pivot_phase64(double* __restrict__ sT, double* _
     }
 }
 
-// X = L^-1 for the 32x32 lower block at (32 kb, 32 kb), by lanes 0..31 of ONE wave (one column each, registers);
-// X replaces L in the image.  rdiag holds the reciprocal pivots.  Call with the block complete in LDS; ends WITHOUT a barrier.
+// X = L^-1 for the 32x32 lower block at (32 kb, 32 kb) by ONE wave; X replaces L in the image.  rdiag holds the reciprocal
+// pivots.  Call with the block complete in LDS; ends WITHOUT a barrier.
+// Lane c (and its twin c + 32) solves L x = e_c column-oriented: x[m] = acc[m] / L[m][m], then acc[r] -= L[r][m] x[m] for every
+// r > m -- independent FMAs.  L[r][m] has to reach every lane: the wave keeps -L in registers, rows 0..15 and rows 16..31 each
+// repeated in all four rows of 16 lanes (lane l holds rows l & 15 and 16 + (l & 15)), and the FMA reads row r's register through
+// DPP row_newbcast -- one instruction per term, no LDS access inside the solve.  (Through round 5 every term was an LDS broadcast
+// read and an FMA, row by row; the compiler waited for each read in turn -- 4.6 us in the launch-per-column kernel, 9.1 us in the
+// one-launch step where it had become what the pivot phases waited for: scripts/batch64_stamps.py.)
 __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double* __restrict__ rdiag, int kb) {
     double* D = sT + (32 * kb) * DT64 + 32 * kb;
-    const int c = threadIdx.x & 63;
-    if (c < 32) {
-        double x[32];
+    const int lane = threadIdx.x & 63, i = lane & 15, c = lane & 31;
+    double a0[16], a1[32], x[32];
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            // two partial sums: the 31 dependent FMAs of the last rows were half of the block's 3.5 us
-            double acc = (r == c) ? 1.0 : 0.0, acc1 = 0.0;
+    for (int m = 0; m < 16; ++m) a0[m] = -D[i * DT64 + m];
 #pragma unroll
-            for (int m = 0; m + 1 < r; m += 2) {
-                acc -= D[r * DT64 + m] * x[m];                              // x[m] == 0 for m < c
-                acc1 -= D[r * DT64 + m + 1] * x[m + 1];
-            }
-            if (r & 1) acc -= D[r * DT64 + r - 1] * x[r - 1];
-            x[r] = (acc + acc1) * rdiag[32 * kb + r];
-        }
-        // every lane has read all of L it needs (its own column's rows >= c only use L, never X): write after a wave barrier
-        __builtin_amdgcn_wave_barrier();
+    for (int m = 0; m < 32; ++m) a1[m] = -D[(16 + i) * DT64 + m];
+    const double r0 = rdiag[32 * kb + i], r1 = rdiag[32 * kb + 16 + i];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = 0; m < 32; ++m) {
+        double xm = 0.0;
+        fmac64_row(xm, m < 16 ? r0 : r1, x[m], m & 15);                  // x[m] / L[m][m]
+        x[m] = xm;
+#pragma unroll
+        for (int r = m + 1; r < 32; ++r) fmac64_row(x[r], r < 16 ? a0[m & 15] : a1[m], xm, r & 15);
+    }
+    if (lane < 32) {                       // (one exec change, after the last DPP instruction)
 #pragma unroll
         for (int r = 0; r < 32; ++r) D[r * DT64 + c] = x[r];
     }
@@ -498,6 +521,7 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
                                             int k, int b, double* __restrict__ sT, long long* stamps, bool image_ready,
                                             int* sub = nullptr) {
     VOLT_STAMP64(0);
+    if (STAMP && stamps && threadIdx.x == 0) stamps[32 * b + 30] = __builtin_amdgcn_s_memtime();     // shader clocks, against [0] .. [20]'s 100 MHz
     double* colbuf = sT + TS * DT64;       // 128 doubles: the reciprocal pivots
     const int n = Np / TS, tid = threadIdx.x, wave = tid >> 6;
     double* D = A + (int64_t)b * Np * Np + (int64_t)k * TS * Np + (int64_t)k * TS;
@@ -534,6 +558,7 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
         } else if (kb >= 1 && wave == 3) {
             inv32_f64(sT, rdiag, kb - 1);
         }
+        if (STAMP && stamps && kb == 1 && (threadIdx.x & 63) == 0) stamps[32 * b + 21 + wave] = __builtin_amdgcn_s_memrealtime();   // who the barrier waits for
         __syncthreads();
         VOLT_STAMP64(2 + 4 * kb);
         // L_kk out (zeros above the diagonal); progressive: with the blocks below it, which rode along and are final too
@@ -645,6 +670,7 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
     }
     if (tid == 0 && bad) atomicCAS(info + b, 0, k * TS + bad);
     VOLT_STAMP64(20);
+    if (STAMP && stamps && threadIdx.x == 0) stamps[32 * b + 31] = __builtin_amdgcn_s_memtime();
 }
 
 // Y[i,i] = W_i^T (upper triangular), through a 64 x 129-double LDS image at a time (66 KB of smem)
