@@ -37,7 +37,7 @@ s = sall[:cnt * 8].reshape(cnt, 8)
 assert (s[:, 0] > 0).all(), "the shape did not run as one launch"
 t0 = s[:, 0].min()
 T = lambda col: (s[:, col] - t0) / 100.0
-beg, end, t3, t4, t5 = T(0), T(1), T(3), T(4), T(5)
+beg, end, t3, t4, t5, t6, t7 = T(0), T(1), T(3), T(4), T(5), T(6), T(7)
 kind, row, col, mat = items.T
 dur = end - beg
 span = end.max()
@@ -64,17 +64,17 @@ for i in range(nb):
     if i == 0:
         print(f"  i  0  in {beg[d]:8.1f}                                        out {end[d]:8.1f}")
         continue
-    line = f"  i {i:2d}  in {beg[d]:8.1f} sum {t3[d]:8.1f} seen {t4[d]:8.1f} done {t5[d]:8.1f} (+{t5[d] - t4[d]:4.1f}) out {end[d]:8.1f}"
+    line = f"  i {i:2d}  in {beg[d]:8.1f} sum {t3[d]:8.1f} sub-blocks 0, 1 seen {t6[d]:8.1f} {t7[d]:8.1f} seen {t4[d]:8.1f} done {t5[d]:8.1f} (+{t5[d] - t4[d]:4.1f}) out {end[d]:8.1f}"
     if prev is not None: line += f" | column {t4[d] - prev:6.1f}"
     prev = t4[d]
     print(line)
 if DS:
     ds = sall[cnt * 8:].reshape(nb, B, 32)[:, 0, :]        # matrix 0
-    lab = {0: "entry", 1: "image", 2: "piv0", 3: "out0", 5: "trail0+pub", 6: "piv1", 7: "out1", 9: "trail1+pub", 10: "piv2", 11: "out2",
-           13: "trail2+pub", 14: "piv3", 15: "out3", 18: "pub3+inv3+pub4(+Lout)", 19: "Wcomp", 20: "Wout"}
+    lab = {0: "entry", 1: "image", 2: "piv0", 3: "trail0", 5: "inv0+pub1", 6: "piv1", 7: "trail1", 9: "inv1+pub2", 10: "piv2", 11: "trail2",
+           13: "inv2+pub3", 14: "piv3", 15: "-", 17: "inv3+pub4", 18: "(Lout)", 19: "Wcomp", 20: "Wout"}
     for i in (1, nb // 2, nb - 1):
         v = ds[i]
         idx = [j for j in sorted(lab) if v[j] > 0]
         print(f"diagonal block {i} (us since its entry): " + "  ".join(f"{lab[j]} {(v[j] - v[0]) / 100.0:.1f}" for j in idx)
-              + (f"  [phase 1, us after trail0: waves 0, 1 (pivots) {(v[21] - v[5]) / 100.0:.1f} {(v[22] - v[5]) / 100.0:.1f}, wave 2 (idle) {(v[23] - v[5]) / 100.0:.1f}, wave 3 (inverse) {(v[24] - v[5]) / 100.0:.1f}]" if v[21] > 0 else "")
+              + (f"  [phase 1, us after pub1: waves 0, 1 (pivots) {(v[21] - v[5]) / 100.0:.1f} {(v[22] - v[5]) / 100.0:.1f}, waves 2, 3 (idle) {(v[23] - v[5]) / 100.0:.1f} {(v[24] - v[5]) / 100.0:.1f}]" if v[21] > 0 else "")
               + (f"  [s_memtime ran at {(v[31] - v[30]) / ((v[20] - v[0]) / 100.0):.0f} MHz]" if v[31] > v[30] > 0 else ""))

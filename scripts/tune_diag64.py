@@ -21,7 +21,7 @@ for rep in range(3):
 s = st[0].cpu().numpy().astype(np.float64)
 names = {1: "load", 18: "L out", 19: "W compute", 20: "W out"}
 for kb in range(4):
-    names.update({2 + 4 * kb: f"chol32[{kb}]", 3 + 4 * kb: f"Lkk out + inv32[{kb}]", 4 + 4 * kb: f"panel[{kb}]", 5 + 4 * kb: f"trailing[{kb}]"})
+    names.update({2 + 4 * kb: f"chol32[{kb}]", 3 + 4 * kb: f"wave 0: out, trailing[{kb}]", 5 + 4 * kb: f"barrier (inv32[{kb}] on wave 3)"})
 prev = s[0]
 print("s_memrealtime (100 MHz): microseconds")
 for i in sorted(names):
@@ -31,4 +31,4 @@ for i in sorted(names):
 if s[31] > s[30] > 0:
     print(f"s_memtime ran at {(s[31] - s[30]) / ((s[20] - s[0]) * 0.01):.0f} MHz over the block")
 if s[21] > 0:
-    print("phase 1, us after trailing[0]: waves 0, 1 (pivots) %.2f %.2f, wave 2 (idle) %.2f, wave 3 (inverse of sub-block 0) %.2f" % tuple((s[21 + w] - s[5]) * 0.01 for w in range(4)))
+    print("phase 1, us after the barrier behind trailing[0]: waves 0, 1 (pivots) %.2f %.2f, waves 2, 3 (idle) %.2f %.2f" % tuple((s[21 + w] - s[5]) * 0.01 for w in range(4)))

@@ -283,6 +283,8 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
             if (KB == 0) batch_wait<false>(sub + k, KB + 1, nullptr, 0, info_b);  \
             else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);        \
             if (KB == 3) VOLT_B64_STAMP(4);                                     \
+            if (KB == 0) VOLT_B64_STAMP(6);                                     \
+            if (KB == 1) VOLT_B64_STAMP(7);                                     \
             trsm64_step<KB>(sT, Lkk, Np, Wk, P, Np);                            \
             if (dg) {                                                           \
                 /* the last slice: rowp[i] = k + 1 goes out HERE -- the next diagonal tile's sum waits for it.  Its barrier is */ \

@@ -410,15 +410,6 @@ __device__ __forceinline__ void inv32_f64(double* __restrict__ sT, const double*
     }
 }
 
-// X_kb (the 32x32 inverse of diagonal sub-block kb, in the image) into the diagonal block of W: 16-byte stores, 2 per thread
-__device__ __forceinline__ void x64_out(const double* __restrict__ sT, double* __restrict__ W, int kb) {
-    for (int e = threadIdx.x; e < 32 * 16; e += NT) {
-        const int r = e >> 4, c = (e & 15) * 2;
-        const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
-        *reinterpret_cast<f64x2*>(W + (int64_t)(32 * kb + r) * TS + 32 * kb + c) = f64x2{s[0], s[1]};
-    }
-}
-
 // ---- the blocked solve  tile <- tile L_kk^-T  in an LDS image, 32 columns at a time (batch64_step.hip) ---------------------
 // B operand of a 32x32x32 product straight from memory into registers: element [c][p] of a row-major block (ld doubles)
 // (Fetching these blocks with agent-scope (sc1) loads, so that the wait in front of them needs no acquire fence, was measured:
@@ -549,50 +540,59 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
     VOLT_STAMP64(1);
     int bad = 0;
     double* rdiag = colbuf;                // 128 reciprocal pivots
-    // Sub-block column kb: pivot waves w < max(1, 3 - kb) factor (kb,kb) with the panel block (kb+1+w, kb) riding along;
-    // a wave that has no panel block left inverts the previous diagonal sub-block meanwhile (X_kb is only needed for W).
+    // Sub-block column kb: pivot waves w < max(1, 3 - kb) factor (kb,kb) with the panel block (kb+1+w, kb) riding along.  Then
+    // wave 3 inverts the sub-block (1.8 us) WHILE waves 0..2 do the trailing updates of the blocks to its right (6, 3, 1, 0 block
+    // products), so that X_kb goes out -- and, progressive, sub is raised -- one whole pivot phase earlier than through round 5,
+    // where the inverse rode along with the NEXT pivot phase: the tile below starts its solve 6 us sooner.
     for (int kb = 0; kb < 4; ++kb) {
         const int npw = kb < 3 ? 3 - kb : 1;
-        if (wave < npw) {
-            pivot_phase64(sT, rdiag, kb, kb + 1 + wave <= 3 ? kb + 1 + wave : -1, wave == 0, bad);
-        } else if (kb >= 1 && wave == 3) {
-            inv32_f64(sT, rdiag, kb - 1);
-        }
+        if (wave < npw) pivot_phase64(sT, rdiag, kb, kb + 1 + wave <= 3 ? kb + 1 + wave : -1, wave == 0, bad);
         if (STAMP && stamps && kb == 1 && (threadIdx.x & 63) == 0) stamps[32 * b + 21 + wave] = __builtin_amdgcn_s_memrealtime();   // who the barrier waits for
         __syncthreads();
         VOLT_STAMP64(2 + 4 * kb);
-        // L_kk out (zeros above the diagonal); progressive: with the blocks below it, which rode along and are final too
-        for (int e = tid; e < (sub ? TS - 32 * kb : 32) * 16; e += NT) {
-            const int r = e >> 4, c = (e & 15) * 2;
-            const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
-            *reinterpret_cast<f64x2*>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c) = f64x2{s[0], s[1]};
-        }
-        if (sub && kb >= 1) x64_out(sT, W, kb - 1);          // X_{kb-1}: wave 3 inverted it during this pivot phase
-        VOLT_STAMP64(3 + 4 * kb);
-        if (kb == 3) break;
-        // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to the 4 waves
-        int cnt = 0;
-        for (int i = kb + 1; i <= 3; ++i)
-            for (int j = kb + 1; j <= i; ++j) {
-                if (wave == (cnt++ & 3)) {
-                    double* C = sT + (32 * i) * DT64 + 32 * j;
-                    f64x4 acc[4];
-                    acc64_load(acc, C);
-                    mm64_nt<true>(acc, sT + (32 * i) * DT64 + 32 * kb, sT + (32 * j) * DT64 + 32 * kb);
-                    acc64_store(acc, C, 1.0);
+        if (wave == 3) {
+            // L_kk out (zeros above the diagonal) by the wave that is about to overwrite it, then X_kb in its place and out
+            const int lane = tid & 63;
+            for (int e = lane; e < 32 * 16; e += 64) {
+                const int r = e >> 4, c = (e & 15) * 2;
+                const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
+                *reinterpret_cast<f64x2*>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c) = f64x2{s[0], s[1]};
+            }
+            inv32_f64(sT, rdiag, kb);
+            if (sub) {                                        // (the wave's own LDS writes: in order, no barrier)
+                for (int e = lane; e < 32 * 16; e += 64) {
+                    const int r = e >> 4, c = (e & 15) * 2;
+                    const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
+                    *reinterpret_cast<f64x2*>(W + (int64_t)(32 * kb + r) * TS + 32 * kb + c) = f64x2{s[0], s[1]};
                 }
             }
-        if (sub && kb >= 1) batch_publish_release<LOCALPUB>(sub, kb, 64);   // (drain, barrier; release + word by wave 1, idle from here on)
+        } else {
+            // progressive: the blocks below L_kk, which rode along and are final too
+            if (sub) {
+                for (int e = tid; e < (TS - 32 * kb - 32) * 16; e += NT - 64) {
+                    const int r = 32 + (e >> 4), c = (e & 15) * 2;
+                    const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
+                    *reinterpret_cast<f64x2*>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c) = f64x2{s[0], s[1]};
+                }
+            }
+            // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to waves 0..2
+            int cnt = 0;
+            for (int i = kb + 1; i <= 3; ++i)
+                for (int j = kb + 1; j <= i; ++j) {
+                    if (wave == (cnt++ % 3)) {
+                        double* C = sT + (32 * i) * DT64 + 32 * j;
+                        f64x4 acc[4];
+                        acc64_load(acc, C);
+                        mm64_nt<true>(acc, sT + (32 * i) * DT64 + 32 * kb, sT + (32 * j) * DT64 + 32 * kb);
+                        acc64_store(acc, C, 1.0);
+                    }
+                }
+        }
+        VOLT_STAMP64(3 + 4 * kb);
+        // (drain, barrier; release + word by wave 3, which has nothing to do in the next pivot phase)
+        if (sub) batch_publish_release<LOCALPUB>(sub, kb + 1, 192);
         else __syncthreads();
         VOLT_STAMP64(5 + 4 * kb);
-    }
-    if (sub) batch_publish_release<LOCALPUB>(sub, 3, 64);
-    else __syncthreads();                  // the L_33 store above reads the image
-    if (wave == 3) inv32_f64(sT, rdiag, 3);
-    __syncthreads();
-    if (sub) {
-        x64_out(sT, W, 3);
-        batch_publish_release<LOCALPUB>(sub, 4, 64);
     }
     // off-diagonal L blocks out (the diagonal sub-blocks went out above), zeros above the diagonal: 16-byte stores, the
     // LDS reads of 8 of them in flight at a time
