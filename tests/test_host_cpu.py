@@ -58,7 +58,7 @@ def test_argument_validation_without_a_device():
     assert L.volt_potrf_k_f64(1, 4, 64, None, 0.0, 1, 1, 1, 1, 8, None, 0, None) == -2    # row stride shorter than N
     assert L.volt_potrf_k_f64(1, 8, 64, None, 0.0, None, 1, 1, 1, 8, None, 0, None) == -6
     assert L.volt_potrf_workspace_bytes_f64(1, 100) == 0 and L.volt_potrf_workspace_bytes_f64(1, 128) == 0   # one block column: nothing to hand on
-    words = lambda B, n: ((B * ((4 * n + 1 + 31) // 32 * 32) + 8 * 32) * 4 + 255) // 256 * 256   # progress words + the pullers' queue words (round 6)
+    words = lambda B, n: ((B * ((5 * n + 1 + 31) // 32 * 32) + 8 * 32) * 4 + 255) // 256 * 256   # progress words + the pullers' queue words (round 6)
     assert L.volt_potrf_workspace_bytes_f64(1, 4096) == words(1, 32) and L.volt_potrf_workspace_bytes_f64(8, 1024) == words(8, 8)
     assert L.volt_potrf_workspace_bytes_f64(512, 4096) == 0                           # beyond the measured range: launch per block column
     assert (L.volt_mll_workspace_bytes_f64(8, 4096, 1) - L.volt_mll_workspace_bytes_f64(8, 4096, 0)

@@ -39,8 +39,8 @@
 
 namespace volt {
 
-// progress words per matrix (ints): rowp[n] | tcol[n] | sub[n] | la[n] | wdone, padded to a multiple of 32
-static inline int batch64_pstride(int n) { return (4 * n + 1 + 31) & ~31; }
+// progress words per matrix (ints): rowp[n] | tcol[n] | sub[n] | la[n] | wdone | tsl[n], padded to a multiple of 32
+static inline int batch64_pstride(int n) { return (5 * n + 1 + 31) & ~31; }
 static inline int64_t batch64_count(int B, int n, bool has_y) {
     const int64_t per = n + (n >= 3 ? n - 2 : 0) + (int64_t)(n - 1) * (n - 2) / 2 + (has_y ? (int64_t)n * (n + 1) / 2 : 0);
     return (int64_t)B * per;
@@ -55,7 +55,7 @@ __global__ void batch64_begin_kernel(int* __restrict__ info, int ninfo, int* __r
     for (int c = i; c < nprog; c += gridDim.x * blockDim.x) {
         int v = 0;
         if (inv_n > 0 && c < nwords) {
-            const int o = c % pstride;                        // rowp[n] | tcol[n] | sub[n] | la[n] | wdone
+            const int o = c % pstride;                        // rowp[n] | tcol[n] | sub[n] | la[n] | wdone | tsl[n]
             if (o < inv_n || o == 4 * inv_n) v = inv_n;
         }
         prog[c] = v;
@@ -142,6 +142,23 @@ __device__ __forceinline__ void tile64_input_neg(f64x4 (&v)[16], const KSource64
                 v[mt * 4 + nt][q] = -input64(src, Kb, add, ti * TS + r, tj * TS + c);
             }
 }
+// the same for the diagonal tile's owners (tiles64.h diag_tile)
+__device__ __forceinline__ void diag_input_neg(f64x4 (&v)[DIAG_OWN], const KSource64& src, int b, const double* __restrict__ Ab, int Np, int ti) {
+    if (!src.K) {
+        diag_load_neg(v, Ab + (int64_t)ti * TS * Np + (int64_t)ti * TS, Np);
+        return;
+    }
+    const int lane = threadIdx.x & 63, g = diag_group();
+    const double add = (src.sigma2 ? src.sigma2[b] : 0.0) + src.jitter;
+    const double* Kb = src.K + (int64_t)b * src.bsk;
+#pragma unroll
+    for (int t = 0; t < DIAG_OWN; ++t) {
+        int tr, tc;
+        diag_tile(g, t, tr, tc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[t][q] = -input64(src, Kb, add, ti * TS + 16 * tr + (lane >> 4) + 4 * q, ti * TS + 16 * tc + (lane & 15));
+    }
+}
 template <bool WT>
 __device__ __forceinline__ void tile64_store(const f64x4 (&v)[16], double* __restrict__ C, int64_t ld, double sign) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -206,11 +223,17 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
     const Piece64 pc = a.inverse_only ? batch64_trtri_piece(w / B, n) : batch64_piece(w / B, n, Y != nullptr);
 #define VOLT_B64_STAMP(i) \
     do { if (stamps && threadIdx.x == 0) stamps[(int64_t)w * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifdef VOLT_B64_SLICE_STAMPS
+#define VOLT_B64_STAMP67(KB)
+#else
+#define VOLT_B64_STAMP67(KB) if (KB == 0) VOLT_B64_STAMP(6); if (KB == 1) VOLT_B64_STAMP(7);
+#endif
     int* rowp = prog + (int64_t)b * pstride;
     int* tcol = rowp + n;
     int* sub = tcol + n;
     int* la = sub + n;
     int* wdone = la + n;
+    int* tsl = wdone + 1;                // tsl[i]: 32-column slices of tile (i,i-1) that are final in memory (D(i) raises it 1 .. 4)
     int* info_b = info + b;
     double* Ab = A + (int64_t)b * Np * Np;
     double* Wb = Winv + (int64_t)b * n * TS * TS;
@@ -257,56 +280,90 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
                     const int early = dg ? k - 1 : k;
                     gemm64_nt_128<true, LOCAL, 2>(X, Np, Z, Np, early * CPB, acc, smem, &ch, &ok);
                     if (dg) {
+                        // X's block: tile (i,k-1), whole.  Z's: D(k)'s own tile, which it hands on SLICE BY SLICE (tsl[k]) -- the
+                        // product follows D(k)'s solve 32 columns of K behind instead of starting when the whole tile is out
+                        // (14 us of MFMA work on this one CU, all of it on the chain through round 5)
+                        ch.p1 = ch.p0;
                         ch.base0 = ch.base1 = k - 1;
-                        gemm64_nt_128<true, LOCAL, 2>(X + (int64_t)(k - 1) * TS, Np, Z + (int64_t)(k - 1) * TS, Np, CPB, acc, smem, &ch, &ok);
+                        chase_wait<LOCAL>(ch, 1, ok);
+#ifdef VOLT_B64_SLICE_STAMPS
+                        VOLT_B64_STAMP(6);
+#endif
+                        ch.p0 = ch.p1 = tsl + k;
+                        // one short loop per slice: the chunk pipeline asks for data four chunks AHEAD of the one it multiplies, so
+                        // a single loop over the block would hold slice 0's product back until slice 2 is there
+                        for (int sl = 0; sl < 4; ++sl) {
+                            ch.base0 = ch.base1 = sl;
+#ifdef VOLT_B64_SLICE_STAMPS
+                            if (sl == 3) { chase_wait<LOCAL>(ch, 1, ok); VOLT_B64_STAMP(7); }
+#endif
+                            gemm64_nt_128<true, LOCAL, 2>(X + (int64_t)(k - 1) * TS + 32 * sl, Np, Z + (int64_t)(k - 1) * TS + 32 * sl, Np, CPB / 4, acc, smem, &ch, &ok);
+                        }
                     }
                 }
                 tile64_to_image<false>(acc, sT);          // (the staging buffers are free: the loop ends with a barrier)
             }
             VOLT_B64_STAMP(3);
-            f64x4 accT[16];
-            if (dg) {                                    // the diagonal tile's sum so far: the look-ahead's, or the input itself
-                if (i >= 2) {
-                    batch_wait<LOCAL>(la + i, 1, nullptr, 0, info_b);
-                    tile64_load_neg(accT, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np);
-                } else {
-                    tile64_input_neg(accT, src, b, Ab, Np, i, i);
-                }
-            }
             const double* Lkk = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
             const double* Wk = Wb + (int64_t)k * TS * TS;
+            // KB = 0: a REAL acquire even under LOCAL -- A[k,k] is the one address written twice per launch (LA(k) parks its sum
+            // there, from a prepared copy it also READ the input there; D(k) then stores L_kk): a CU that ran LA(k) could hit its
+            // old L1 lines when it reads the L_kk sub-blocks below.  One buffer_inv per piece.
+            f64x4 accT[DIAG_OWN];
+            if (!dg) {
 #define VOLT_B64_STEP(KB)                                                       \
-            /* KB = 0: a REAL acquire even under LOCAL -- A[k,k] is the one address written twice per launch (LA(k) parks its sum */ \
-            /* there, from a prepared copy it also READ the input there; D(k) then stores L_kk): a CU that ran LA(k) could hit */ \
-            /* its old L1 lines when it reads the L_kk sub-blocks below.  One buffer_inv per piece, off the chain */ \
-            /* for every US tile */ \
-            if (KB == 0) batch_wait<false>(sub + k, KB + 1, nullptr, 0, info_b);  \
-            else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);        \
-            if (KB == 3) VOLT_B64_STAMP(4);                                     \
-            if (KB == 0) VOLT_B64_STAMP(6);                                     \
-            if (KB == 1) VOLT_B64_STAMP(7);                                     \
-            trsm64_step<KB>(sT, Lkk, Np, Wk, P, Np);                            \
-            if (dg) {                                                           \
-                /* the last slice: rowp[i] = k + 1 goes out HERE -- the next diagonal tile's sum waits for it.  Its barrier is */ \
-                /* the one the rank-32 update needs anyway, and the release + word are wave 1's: the quadrant above the */ \
-                /* diagonal needs no update, so nothing on the chain waits for that wave */ \
-                if (KB == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    \
-                __syncthreads();                                                \
-                if (KB == 3 && threadIdx.x == 64) {                             \
-                    if constexpr (LOCAL) {                                      \
-                        *reinterpret_cast<volatile int*>(rowp + i) = k + 1;     \
-                    } else {                                                    \
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      \
-                        __hip_atomic_store(rowp + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-                    }                                                           \
-                }                                                               \
-                if ((threadIdx.x >> 6) != 1) syrk64_slice<KB>(accT, sT);        \
-            }
-            VOLT_B64_STEP(0)
-            VOLT_B64_STEP(1)
-            VOLT_B64_STEP(2)
-            VOLT_B64_STEP(3)
+                if (KB == 0) batch_wait<false>(sub + k, KB + 1, nullptr, 0, info_b);  \
+                else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);    \
+                if (KB == 3) VOLT_B64_STAMP(4);                                 \
+                trsm64_step<KB, true>(sT, Lkk, Np, Wk, P, Np);
+                VOLT_B64_STEP(0)
+                VOLT_B64_STEP(1)
+                VOLT_B64_STEP(2)
+                VOLT_B64_STEP(3)
 #undef VOLT_B64_STEP
+            } else {
+                // The tile next to the diagonal.  Per step: the slice stays in the image; after the barrier the rank-32 update
+                // needs anyway, wave 1 -- the quadrant above the diagonal needs no update -- writes it out (written through
+                // unless LOCAL), drains, and raises tsl[i] (and, with the last slice, rowp[i] = k + 1): nothing on the chain
+                // waits for stores or for a release.
+                // (Measured and not kept: the NEXT step's operands requested before the rank-32 update when block k's next
+                // sub-block was already announced, and the diagonal tile's sum fetched behind step 0's operands instead of in
+                // front of its wait -- steps 1 .. 3 each 1 us shorter, step 0 5.7 us longer, 1 x 4096 1.80 ms against 1.765.)
+                const int wv = threadIdx.x >> 6;
+                if (i >= 2) {                                // the diagonal tile's sum so far: the look-ahead's, or the input itself
+                    batch_wait<LOCAL>(la + i, 1, nullptr, 0, info_b);
+                    if (wv != 1) diag_load_neg(accT, Ab + (int64_t)i * TS * Np + (int64_t)i * TS, Np);
+                } else if (wv != 1) {
+                    diag_input_neg(accT, src, b, Ab, Np, i);
+                }
+#define VOLT_B64_DSTEP(KB)                                                      \
+                if (KB == 0) batch_wait<false>(sub + k, 1, nullptr, 0, info_b); \
+                else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);    \
+                if (KB == 3) VOLT_B64_STAMP(4);                                 \
+                VOLT_B64_STAMP67(KB)                                            \
+                trsm64_step<KB, false>(sT, Lkk, Np, Wk, P, Np);                 \
+                __syncthreads();                                                \
+                if (wv == 1) {                                                  \
+                    slice64_out<KB, !LOCAL>(sT, P, Np);                         \
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
+                    if (lane == 0) {                                            \
+                        if constexpr (LOCAL) {                                  \
+                            *reinterpret_cast<volatile int*>(tsl + i) = KB + 1; \
+                            if (KB == 3) *reinterpret_cast<volatile int*>(rowp + i) = k + 1; \
+                        } else {                                                \
+                            __hip_atomic_store(tsl + i, KB + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                            if (KB == 3) __hip_atomic_store(rowp + i, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+                        }                                                       \
+                    }                                                           \
+                } else {                                                        \
+                    diag_syrk_slice<KB>(accT, sT);                              \
+                }
+                VOLT_B64_DSTEP(0)
+                VOLT_B64_DSTEP(1)
+                VOLT_B64_DSTEP(2)
+                VOLT_B64_DSTEP(3)
+#undef VOLT_B64_DSTEP
+            }
             if (!ok && lane == 0) atomicCAS(info_b, 0, (int)0x80000000);
             if (!dg) {
                 batch_publish_release<LOCAL>(rowp + i, k + 1);
@@ -315,7 +372,7 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
             }
             __syncthreads();                                     // (the last rank-32 update has read the image)
             VOLT_B64_STAMP(5);
-            tile64_to_image<true>(accT, sT);
+            diag_to_image(accT, sT);
         }
         bool image = k >= 0;
         if (!image && src.K) {                           // block 0 straight from K into the image

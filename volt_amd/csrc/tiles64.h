@@ -7,6 +7,7 @@ namespace volt {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_64 __attribute__((ext_vector_type(4)));
 
 // Where the one-launch step reads a tile of its input from (batch64_step.hip): K == nullptr -- the prepared copy A; else the
 // caller's K (+ sigma2[b] + jitter on the diagonal, identity in the padding): no copy-in pass ahead of the factorisation.
@@ -444,36 +445,139 @@ __device__ __forceinline__ void mm64_nt_rb(f64x4 (&acc)[4], const double* __rest
 // Step KB on the 128x128 tile P in the image: column slice KB becomes final, Lt = P[:,KB] X_KB^T, and is taken out of the
 // slices to its right, P[:,j] -= Lt L[j,KB]^T.  Wave w owns rows 32 w .. 32 w + 31 (no barrier inside, none needed between
 // steps).  Lkk: the diagonal block of L in memory (ld doubles), Wk: W_k, whose diagonal 32-blocks are the X_kb.  Then the
-// final slice goes out to `out` (ldo doubles): 16-byte stores.
+// final slice goes out to `out` (ldo doubles): 16-byte stores -- unless the caller has one wave do that for all rows (slice64_out).
+struct Trsm64Ops { Blk64 bx, bl[3]; };          // X_KB and the blocks L[j,KB], j > KB, of one step (what a step does not use is dead)
 template <int KB>
-__device__ __forceinline__ void trsm64_step(double* __restrict__ sT, const double* __restrict__ Lkk, int64_t ld,
-                                            const double* __restrict__ Wk, double* __restrict__ out, int64_t ldo) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    Blk64 bx, bl[KB < 3 ? 3 - KB : 1];
-    blk64_load(bx, Wk + (int64_t)(32 * KB) * TS + 32 * KB, TS);
+__device__ __forceinline__ void trsm64_load(Trsm64Ops& o, const double* __restrict__ Lkk, int64_t ld, const double* __restrict__ Wk) {
+    blk64_load(o.bx, Wk + (int64_t)(32 * KB) * TS + 32 * KB, TS);
 #pragma unroll
-    for (int j = KB + 1; j <= 3; ++j) blk64_load(bl[j - KB - 1], Lkk + (int64_t)(32 * j) * ld + 32 * KB, ld);
+    for (int j = KB + 1; j <= 3; ++j) blk64_load(o.bl[j - KB - 1], Lkk + (int64_t)(32 * j) * ld + 32 * KB, ld);
+}
+template <int KB, bool STORE = true>
+__device__ __forceinline__ void trsm64_apply(double* __restrict__ sT, const Trsm64Ops& o, double* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double* rows = sT + (32 * wave) * DT64;
     f64x4 acc[4];
     acc64_zero(acc);
-    mm64_nt_rb<false>(acc, rows + 32 * KB, bx);
+    mm64_nt_rb<false>(acc, rows + 32 * KB, o.bx);
     acc64_store(acc, rows + 32 * KB, 1.0);
 #pragma unroll
     for (int j = KB + 1; j <= 3; ++j) {
         f64x4 c[4];
         acc64_load(c, rows + 32 * j);
-        mm64_nt_rb<true>(c, rows + 32 * KB, bl[j - KB - 1]);
+        mm64_nt_rb<true>(c, rows + 32 * KB, o.bl[j - KB - 1]);
         acc64_store(c, rows + 32 * j, 1.0);
     }
+    if constexpr (STORE) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int r = it * 4 + (lane >> 4), c = (lane & 15) * 2;
-        f64x2 v;
-        v[0] = rows[r * DT64 + 32 * KB + c];
-        v[1] = rows[r * DT64 + 32 * KB + c + 1];
-        *reinterpret_cast<f64x2*>(out + (int64_t)(32 * wave + r) * ldo + 32 * KB + c) = v;
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 4 + (lane >> 4), c = (lane & 15) * 2;
+            f64x2 v;
+            v[0] = rows[r * DT64 + 32 * KB + c];
+            v[1] = rows[r * DT64 + 32 * KB + c + 1];
+            *reinterpret_cast<f64x2*>(out + (int64_t)(32 * wave + r) * ldo + 32 * KB + c) = v;
+        }
     }
 }
+template <int KB, bool STORE = true>
+__device__ __forceinline__ void trsm64_step(double* __restrict__ sT, const double* __restrict__ Lkk, int64_t ld,
+                                            const double* __restrict__ Wk, double* __restrict__ out, int64_t ldo) {
+    Trsm64Ops o;
+    trsm64_load<KB>(o, Lkk, ld, Wk);
+    trsm64_apply<KB, STORE>(sT, o, out, ldo);
+}
+// slice KB of the whole 128-row tile out of the image, by ONE wave: 32 x 16-byte stores per lane, the LDS reads of FL in flight
+// (FL = 8 raised the one-launch kernel's register count from 418 to 444, and the compiler then broke its main K loop into
+// pieces -- 17.8 us per K block instead of 14.8 on every tile of the launch)
+// WT: written through (sc1) -- the word that announces the slice then needs the wave's own drain only, no L2-wide write-back (which
+// took ~6 us here, with every other CU of the XCD storing tiles)
+template <int KB, bool WT, int FL = 4>
+__device__ __forceinline__ void slice64_out(const double* __restrict__ sT, double* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63, c = (lane & 15) * 2;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, 0x7fffffff, 0x00020000);
+#pragma unroll 1
+    for (int it0 = 0; it0 < 32; it0 += FL) {
+        f64x2 v[FL];
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int r = (it0 + u) * 4 + (lane >> 4);
+            v[u][0] = sT[r * DT64 + 32 * KB + c];
+            v[u][1] = sT[r * DT64 + 32 * KB + c + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int r = (it0 + u) * 4 + (lane >> 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_64, v[u]), rs, (int)((r * ldo + 32 * KB + c) * 8), 0, WT ? 16 : 0);
+        }
+    }
+}
+// ---- the diagonal tile's sum while the tile beside it is solved (batch64_step.hip, D pieces) ------------------------------------
+// Only the lower triangle of A[i,i] -= Lt Lt^T is needed: 36 of the 64 16x16 tiles.  Waves 0, 2, 3 own 12 each (wave 1 writes
+// the finished slices out meanwhile): rows of tiles 0..3 and (4,0), (4,1) | (4,2) .. (4,4), row 5, (6,0) .. (6,2) | (6,3) ..
+// (6,6), row 7.  Through round 5 three waves owned a 64x64 quadrant each -- 16 tiles, and the update was 3.4 of a step's 6.4 us
+// at the fp64 MFMA rate (one v_mfma_f64_16x16x4 per 64 clocks and SIMD).
+constexpr int DIAG_OWN = 12;
+__device__ __forceinline__ int diag_group() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) == 0 ? 0 : (int)(threadIdx.x >> 6) - 1); }
+__device__ __forceinline__ void diag_tile(int g, int t, int& tr, int& tc) {      // t: compile-time after unrolling, g: wave-uniform
+    constexpr int R[3][DIAG_OWN] = {{0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4}, {4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6}, {6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7}};
+    constexpr int C[3][DIAG_OWN] = {{0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1}, {2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2}, {3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7}};
+    tr = g == 0 ? R[0][t] : (g == 1 ? R[1][t] : R[2][t]);
+    tc = g == 0 ? C[0][t] : (g == 1 ? C[1][t] : C[2][t]);
+}
+// -(the tile at C, ld doubles) into the owners' accumulators
+__device__ __forceinline__ void diag_load_neg(f64x4 (&v)[DIAG_OWN], const double* __restrict__ C, int64_t ld) {
+    const int lane = threadIdx.x & 63, g = diag_group();
+#pragma unroll
+    for (int t = 0; t < DIAG_OWN; ++t) {
+        int tr, tc;
+        diag_tile(g, t, tr, tc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[t][q] = -C[(int64_t)(16 * tr + (lane >> 4) + 4 * q) * ld + 16 * tc + (lane & 15)];
+    }
+}
+// += Lt[:, slice KB] Lt[:, slice KB]^T from the image (call on waves 0, 2, 3)
+template <int KB>
+__device__ __forceinline__ void diag_syrk_slice(f64x4 (&acc)[DIAG_OWN], const double* __restrict__ sT) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4, g = diag_group();
+    const double* base = sT + l15 * DT64 + 32 * KB + lk;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+        double a[DIAG_OWN], bb[DIAG_OWN];
+#pragma unroll
+        for (int t = 0; t < DIAG_OWN; ++t) {
+            int tr, tc;
+            diag_tile(g, t, tr, tc);
+            a[t] = base[(16 * tr) * DT64 + 4 * st];
+            bb[t] = base[(16 * tc) * DT64 + 4 * st];
+        }
+#pragma unroll
+        for (int t = 0; t < DIAG_OWN; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bb[t], acc[t], 0, 0, 0);
+    }
+}
+// -acc into the LDS image, the lower triangle; zeros above the diagonal inside the four 32x32 diagonal sub-blocks (what the
+// pivot phases read) -- the rest of the upper triangle is never read
+__device__ __forceinline__ void diag_to_image(const f64x4 (&v)[DIAG_OWN], double* __restrict__ sT) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sT[(32 * u + (lane >> 4) + 4 * q) * DT64 + 32 * u + 16 + (lane & 15)] = 0.0;
+        return;
+    }
+    const int g = diag_group();
+#pragma unroll
+    for (int t = 0; t < DIAG_OWN; ++t) {
+        int tr, tc;
+        diag_tile(g, t, tr, tc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * tr + (lane >> 4) + 4 * q, c = 16 * tc + (lane & 15);
+            sT[r * DT64 + c] = (c <= r) ? -v[t][q] : 0.0;
+        }
+    }
+}
+
 // acc (the wave's 64x64 of a 128x128 tile, gemm64 layout) += Lt[:, slice KB] Lt[:, slice KB]^T from the image
 template <int KB>
 __device__ __forceinline__ void syrk64_slice(f64x4 (&acc)[16], const double* __restrict__ sT) {
@@ -496,6 +600,16 @@ __device__ __forceinline__ void syrk64_slice(f64x4 (&acc)[16], const double* __r
     }
 }
 
+// 16 bytes out; WT: written through (two sc1 stores) -- what a hand-off word announces then needs the storing waves' drain only
+template <bool WT>
+__device__ __forceinline__ void store64x2(double* __restrict__ p, double a, double b) {
+    if constexpr (WT) {
+        __hip_atomic_store(p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<f64x2*>(p) = f64x2{a, b};
+    }
+}
 #define VOLT_STAMP64(i)                                                                \
     do {                                                                               \
         if (STAMP && stamps && threadIdx.x == 0) stamps[32 * b + (i)] = __builtin_amdgcn_s_memrealtime();   \
@@ -511,6 +625,9 @@ template <bool STAMP, bool LOCALPUB = false>
 __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __restrict__ Winv, int* __restrict__ info, int Np,
                                             int k, int b, double* __restrict__ sT, long long* stamps, bool image_ready,
                                             int* sub = nullptr) {
+    // (the progressive hand-off's stores written through, and the word without a release, were measured for readers outside the
+    // XCD: the drain of sc1 stores costs what the L2 write-back did -- sub-block 0 is seen 7 us after its barrier either way)
+    constexpr bool WTP = false;
     VOLT_STAMP64(0);
     if (STAMP && stamps && threadIdx.x == 0) stamps[32 * b + 30] = __builtin_amdgcn_s_memtime();     // shader clocks, against [0] .. [20]'s 100 MHz
     double* colbuf = sT + TS * DT64;       // 128 doubles: the reciprocal pivots
@@ -556,14 +673,14 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
             for (int e = lane; e < 32 * 16; e += 64) {
                 const int r = e >> 4, c = (e & 15) * 2;
                 const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
-                *reinterpret_cast<f64x2*>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c) = f64x2{s[0], s[1]};
+                store64x2<WTP>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c, s[0], s[1]);
             }
             inv32_f64(sT, rdiag, kb);
             if (sub) {                                        // (the wave's own LDS writes: in order, no barrier)
                 for (int e = lane; e < 32 * 16; e += 64) {
                     const int r = e >> 4, c = (e & 15) * 2;
                     const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
-                    *reinterpret_cast<f64x2*>(W + (int64_t)(32 * kb + r) * TS + 32 * kb + c) = f64x2{s[0], s[1]};
+                    store64x2<WTP>(W + (int64_t)(32 * kb + r) * TS + 32 * kb + c, s[0], s[1]);
                 }
             }
         } else {
@@ -572,7 +689,7 @@ __device__ __forceinline__ void diag64_body(double* __restrict__ A, double* __re
                 for (int e = tid; e < (TS - 32 * kb - 32) * 16; e += NT - 64) {
                     const int r = 32 + (e >> 4), c = (e & 15) * 2;
                     const double* s = sT + (32 * kb + r) * DT64 + 32 * kb + c;
-                    *reinterpret_cast<f64x2*>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c) = f64x2{s[0], s[1]};
+                    store64x2<WTP>(D + (int64_t)(32 * kb + r) * Np + 32 * kb + c, s[0], s[1]);
                 }
             }
             // trailing updates A[i,j] -= L[i,kb] L[j,kb]^T, kb < j <= i <= 3, dealt round-robin to waves 0..2
