@@ -40,4 +40,4 @@ def check(src):
     return bad
 
 if __name__ == "__main__":
-    sys.exit(1 if sum(check(s) for s in ("chol64.hip", "batch64_step.hip")) else 0)
+    sys.exit(1 if sum(check(s) for s in ("chol64.hip", "batch64_step.hip", "mll64.hip")) else 0)

@@ -88,6 +88,42 @@ def test_one_launch_fp64_reports_a_matrix_that_is_not_pd(ops):
     assert float((f.L[[0, 1, 3]] - Lr).abs().amax() / Lr.abs().amax()) < 1e-10
 
 
+@pytest.mark.parametrize("kind", ["negative", "zero", "nan"])
+@pytest.mark.parametrize("at", [0, 31, 32, 63, 127, 128, 300])
+def test_fp64_first_bad_pivot_is_lapacks_at_every_lane_of_the_pivot_wave(ops, kind, at):
+    """Round 6: the pivot phase no longer tests d > 0 pivot by pivot -- lane j keeps 1/sqrt(d_j) and the first lane whose value is
+    not > 0 names the pivot (csrc/tiles64.h pivot_phase64).  A pivot that is <= 0 or NaN must be reported at LAPACK's index
+    (torch.linalg.cholesky_ex) wherever it sits in a 32-pivot phase, with later pivots' NaNs not taking its place; both the
+    one launch and the launch-per-column path."""
+    from volt_amd import _lib
+    L = _lib.lib()
+    B, n = 2, 384
+    K, r, s2 = _problem(ops, B, n)
+    K = K.clone()
+    M = K[1] + torch.diag(s2[1].expand(n))
+    if kind == "nan":
+        M[at, at] = float("nan")
+        want = at + 1
+    elif kind == "zero":
+        if at != 0: pytest.skip("an exactly zero pivot can only be placed at index 0 (elsewhere its sign is a matter of summation order)")
+        M[0, 0] = 0.0
+        want = 1
+    else:
+        Lr = torch.linalg.cholesky(M)
+        M[at, at] -= 1.5 * Lr[at, at] ** 2                        # the Schur complement's pivot `at` becomes -0.5 d
+        want = int(torch.linalg.cholesky_ex(M).info)
+        assert want == at + 1
+    K[1] = M - torch.diag(s2[1].expand(n))
+    f = ops.potrf(K, s2)
+    info = f.info.cpu().tolist()
+    assert info[0] == 0 and info[1] == want, (info, want)
+    A = torch.empty_like(f.A)
+    _lib.check(L.volt_prepare_f64(K.data_ptr(), n, n * n, s2.data_ptr(), 0.0, A.data_ptr(), B, n, _lib.stream_ptr()), "prep")
+    W, info2 = torch.empty_like(f.Winv), torch.empty_like(f.info)
+    _lib.check(L.volt_potrf_ws_f64(A.data_ptr(), W.data_ptr(), info2.data_ptr(), B, n, None, 0, _lib.stream_ptr()), "potrf")
+    assert info2.cpu().tolist() == [0, want]
+
+
 def test_null_workspace_is_the_launch_per_column_path(ops):
     """ws == NULL is volt_potrf_f64: same factor to fp64 round-off (the K-sliced path sums with atomics)."""
     from volt_amd import _lib

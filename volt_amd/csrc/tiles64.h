@@ -578,28 +578,6 @@ __device__ __forceinline__ void diag_to_image(const f64x4 (&v)[DIAG_OWN], double
     }
 }
 
-// acc (the wave's 64x64 of a 128x128 tile, gemm64 layout) += Lt[:, slice KB] Lt[:, slice KB]^T from the image
-template <int KB>
-__device__ __forceinline__ void syrk64_slice(f64x4 (&acc)[16], const double* __restrict__ sT) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lk = lane >> 4;
-    const double* ra = sT + ((wave >> 1) * 64 + l15) * DT64 + 32 * KB + lk;
-    const double* rb = sT + ((wave & 1) * 64 + l15) * DT64 + 32 * KB + lk;
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-        double a[4], bb[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a[t] = ra[(16 * t) * DT64 + 4 * st];
-            bb[t] = rb[(16 * t) * DT64 + 4 * st];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[mt * 4 + nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt], bb[nt], acc[mt * 4 + nt], 0, 0, 0);
-    }
-}
-
 // 16 bytes out; WT: written through (two sc1 stores) -- what a hand-off word announces then needs the storing waves' drain only
 template <bool WT>
 __device__ __forceinline__ void store64x2(double* __restrict__ p, double a, double b) {
