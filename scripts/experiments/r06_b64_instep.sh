@@ -1,14 +1,19 @@
 # step 1 of the D piece taken apart (thread 0 = wave 0): wait over | products done | barrier passed | rank-32 update done
 # (needs scripts/experiments/r06_b64_instep_stamps.diff applied: a tuning-only macro, kept out of the sources so that their hash stays the evidence's)
-# measured: 1 x 4096 / 8 x 2048, us: wait over -> products done 5.4 - 6.0 (2.6 of MFMA) | barrier 0.1 | rank-32 update 3.5 (2.6 of MFMA) -- the same with XCD-local and with agent-scope hand-offs
+# (the diff also holds -DVOLT_B64_PREFETCH: the next step's operands requested before the rank-32 update)
+# measured at 1 x 4096, us: wait over -> products done | barrier | -> rank-32 update done (wave 0)
+#   as shipped   step 0: 7.4 | 0.04 | 4.1     step 1: 5.6 | 0.04 | 3.6         (MFMA alone: 3.4 / 2.6 and 2.6)
+#   prefetch     step 0: 4.9 | 0.04 | 7.5     step 1: 3.2 | 0.2 - 1.2 | 5.5     step 2: 2.2 | 0.1 - 0.6 | 3.9 - 5.4
+#   -> operands in registers take 2.4 us off the products; the acquire + the 48 scattered loads per wave issued in front of the
+#      update put 2 back, and sub-block 0 is seen 5 us later: a wash (1.775 vs 1.75 ms).  8 x 2048 (XCD-local hand-offs): the same steps.
 cd $GRAFT_REPO_ROOT
-VOLT_EXTRA_FLAGS="-DVOLT_B64_INSTEP_STAMPS -DVOLT_B64_SLICE_STAMPS" python - <<'PY'
+for FL in "-DVOLT_B64_INSTEP_KB=0" "-DVOLT_B64_INSTEP_KB=1" "-DVOLT_B64_INSTEP_KB=0 -DVOLT_B64_PREFETCH" "-DVOLT_B64_INSTEP_KB=1 -DVOLT_B64_PREFETCH" "-DVOLT_B64_INSTEP_KB=2 -DVOLT_B64_PREFETCH"; do echo "== $FL"; VOLT_EXTRA_FLAGS="-DVOLT_B64_INSTEP_STAMPS -DVOLT_B64_SLICE_STAMPS $FL" python - <<'PY'
 import os, sys, ctypes as C
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from volt_amd import ops, _lib
 from volt_amd.synthetic import sde_batch
-for B, n in ((1, 4096), (8, 2048)):
+for B, n in ((1, 4096),):
     L = _lib.lib()
     x, F, vol = sde_batch(min(B, 4), n)
     vol = np.tile(vol, (B // min(B, 4) + 1, 1))[:B]
@@ -28,3 +33,4 @@ for B, n in ((1, 4096), (8, 2048)):
     print(f"{B}x{n}: step 1 of D(i), us: wait over -> products done (loads + MFMA + LDS) | -> barrier passed | -> rank-32 update done (wave 0)")
     for r in v: print("   ", " ".join(f"{x:6.2f}" for x in np.diff(r)))
 PY
+done
