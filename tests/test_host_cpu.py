@@ -394,3 +394,21 @@ def test_reference_driver_imports_resolve():
         _out_of_scope._stand_in("TrainBasicModel")(None, None)
     with pytest.raises(NotImplementedError):
         _out_of_scope._stand_in("MaternGP")(None)
+
+
+def test_fp64_device_assembly_dpp_hazards_and_kernel_shape():
+    """Round 6 (csrc/tiles64.h): the fp64 pivot phase and sub-block inverse use v_fmac_f64_dpp row_newbcast from inline asm, where
+    the compiler's hazard recogniser cannot see the DPP operand -- every such instruction in the cross-compiled assembly must have
+    its operand's last VALU write >= 2 and any EXEC write >= 5 wait states ahead; and the one-launch kernel must keep the shape its
+    speed depends on (<= 420 registers, the steady K loop one basic block of 128 MFMAs: DESIGN 4.7).  hipcc only, no GPU."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(os.path.dirname(__file__), "..", "scripts", "check_dpp_hazards.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for src in ("chol64.hip", "batch64_step.hip"):
+        bad, n, text = m.check(src)
+        assert n > 1000 and bad == 0, (src, n, bad)
+    shapes = m.kernel_shape(text, "_ZN4volt19batch64_step_kernel")
+    assert len(shapes) == 2
+    for name, (regs, mfma) in shapes.items():
+        assert regs <= 420 and mfma == 128, (name, regs, mfma)
