@@ -205,6 +205,7 @@ struct Batch64Args {
     int inverse_only;        // 1: the factor is there, the launch runs the rows of the inverse alone (volt_trtri_ws_f64)
 };
 extern __shared__ __attribute__((aligned(16))) double g_sT64[];     // the diagonal block's image / the staging buffers
+constexpr int BATCH64_LDS_BYTES = DIAG64_LDS_BYTES + TRSM64_STAGE_BYTES;   // 159 488 of the CU's 163 840
 static __shared__ int g_piece64;                                     // the piece thread 0 pulled
 
 // One piece of the list.  LOCAL: the batch is a multiple of 8 -- every piece of a matrix runs under ONE XCD's L2 (the pullers read
@@ -306,6 +307,7 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
             VOLT_B64_STAMP(3);
             const double* Lkk = Ab + (int64_t)k * TS * Np + (int64_t)k * TS;
             const double* Wk = Wb + (int64_t)k * TS * TS;
+            double* stage = sT + TS * DT64 + 160;            // three operand blocks of a solve step, behind the image and its pivots
             // KB = 0: a REAL acquire even under LOCAL -- A[k,k] is the one address written twice per launch (LA(k) parks its sum
             // there, from a prepared copy it also READ the input there; D(k) then stores L_kk): a CU that ran LA(k) could hit its
             // old L1 lines when it reads the L_kk sub-blocks below.  One buffer_inv per piece.
@@ -315,7 +317,7 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
                 if (KB == 0) batch_wait<false>(sub + k, KB + 1, nullptr, 0, info_b);  \
                 else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);    \
                 if (KB == 3) VOLT_B64_STAMP(4);                                 \
-                trsm64_step<KB, true>(sT, Lkk, Np, Wk, P, Np);
+                trsm64_step_staged<KB, true>(sT, stage, Lkk, Np, Wk, P, Np);
                 VOLT_B64_STEP(0)
                 VOLT_B64_STEP(1)
                 VOLT_B64_STEP(2)
@@ -341,7 +343,7 @@ __device__ __forceinline__ void batch64_piece(const Batch64Args a, const int w) 
                 else batch_wait<LOCAL>(sub + k, KB + 1, nullptr, 0, info_b);    \
                 if (KB == 3) VOLT_B64_STAMP(4);                                 \
                 VOLT_B64_STAMP67(KB)                                            \
-                trsm64_step<KB, false>(sT, Lkk, Np, Wk, P, Np);                 \
+                trsm64_step_staged<KB, false>(sT, stage, Lkk, Np, Wk, P, Np);                 \
                 __syncthreads();                                                \
                 if (wv == 1) {                                                  \
                     slice64_out<KB, !LOCAL>(sT, P, Np);                         \
@@ -520,14 +522,14 @@ int volt_internal_batch64_step(double* A, double* Winv, int* info, double* Y, in
     hipError_t e;
     if (local) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BATCH64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
+        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), BATCH64_LDS_BYTES, s, args, xskew, xdrop);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BATCH64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
+        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), BATCH64_LDS_BYTES, s, args, xskew, xdrop);
     }
     e = hipGetLastError();
     return e != hipSuccess ? (int)e : 1;
@@ -569,14 +571,14 @@ int volt_internal_batch64_trtri(const double* A, const double* Winv, double* Y, 
     hipError_t e;
     if (local) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BATCH64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
+        hipLaunchKernelGGL(batch64_step_kernel<true>, dim3(grid), dim3(256), BATCH64_LDS_BYTES, s, args, xskew, xdrop);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(batch64_step_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, DIAG64_LDS_BYTES);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BATCH64_LDS_BYTES);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), DIAG64_LDS_BYTES, s, args, xskew, xdrop);
+        hipLaunchKernelGGL(batch64_step_kernel<false>, dim3(grid), dim3(256), BATCH64_LDS_BYTES, s, args, xskew, xdrop);
     }
     e = hipGetLastError();
     return e != hipSuccess ? (int)e : 1;

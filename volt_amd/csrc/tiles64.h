@@ -486,6 +486,53 @@ __device__ __forceinline__ void trsm64_step(double* __restrict__ sT, const doubl
     trsm64_load<KB>(o, Lkk, ld, Wk);
     trsm64_apply<KB, STORE>(sT, o, out, ldo);
 }
+// The same step with its operand blocks fetched ONCE per workgroup (batch64_step.hip): the four waves need the same <= 4 blocks
+// of 8 KB, and blk64_load has every wave pull them with 16 scattered 8-byte loads per lane and block (2.4 us from the wait to
+// the first product, stamped).  Here the 256 threads fetch X_KB and the first two L[j,KB] with 16-byte loads (two per thread and
+// block) into a stage behind the image (row stride 34 doubles: the fragment reads of a half-wave touch 64 different banks), one
+// barrier, and each wave takes its fragments from LDS.  Step 0's fourth block -- the one its products need last -- still
+// comes the old way, under the first two products.
+constexpr int OPS_LD = 34;
+constexpr int OPS_BLOCK = 32 * OPS_LD;                        // doubles per staged block
+constexpr int TRSM64_STAGE_BYTES = 3 * OPS_BLOCK * 8;
+__device__ __forceinline__ void blk64_from_stage(Blk64& b, const double* __restrict__ st) {
+    const int lane = threadIdx.x & 63, l15 = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) b.v[s8][t] = st[(t * 16 + l15) * OPS_LD + 4 * s8 + lk];
+}
+template <int KB, bool STORE = true>
+__device__ __forceinline__ void trsm64_step_staged(double* __restrict__ sT, double* __restrict__ stage, const double* __restrict__ Lkk,
+                                                   int64_t ld, const double* __restrict__ Wk, double* __restrict__ out, int64_t ldo) {
+    constexpr int NB = KB < 3 ? (KB == 0 ? 3 : 4 - KB) : 1;        // staged blocks: X_KB, then L[KB+1,KB] (, L[KB+2,KB])
+    const int tid = threadIdx.x;
+    f64x2 v[NB][2];
+#pragma unroll
+    for (int bq = 0; bq < NB; ++bq) {
+        const double* src = bq == 0 ? Wk + (int64_t)(32 * KB) * TS + 32 * KB : Lkk + (int64_t)(32 * (KB + bq)) * ld + 32 * KB;
+        const int64_t sld = bq == 0 ? TS : ld;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * NT, r = e >> 4, c = (e & 15) * 2;
+            v[bq][u] = *reinterpret_cast<const f64x2*>(src + (int64_t)r * sld + c);
+        }
+    }
+    Trsm64Ops o;
+    if constexpr (KB == 0) blk64_load(o.bl[2], Lkk + (int64_t)(32 * 3) * ld, ld);
+#pragma unroll
+    for (int bq = 0; bq < NB; ++bq)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * NT, r = e >> 4, c = (e & 15) * 2;
+            *reinterpret_cast<f64x2*>(stage + bq * OPS_BLOCK + r * OPS_LD + c) = v[bq][u];
+        }
+    __syncthreads();
+    blk64_from_stage(o.bx, stage);
+#pragma unroll
+    for (int bq = 1; bq < NB; ++bq) blk64_from_stage(o.bl[bq - 1], stage + bq * OPS_BLOCK);
+    trsm64_apply<KB, STORE>(sT, o, out, ldo);
+}
 // slice KB of the whole 128-row tile out of the image, by ONE wave: 32 x 16-byte stores per lane, the LDS reads of FL in flight
 // (FL = 8 raised the one-launch kernel's register count from 418 to 444, and the compiler then broke its main K loop into
 // pieces -- 17.8 us per K block instead of 14.8 on every tile of the launch)
