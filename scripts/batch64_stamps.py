@@ -64,8 +64,11 @@ for i in range(nb):
     if i == 0:
         print(f"  i  0  in {beg[d]:8.1f}                                        out {end[d]:8.1f}")
         continue
+    xs = np.where((kind == 1) & (row == i) & (col == i - 2) & (mat == 0))[0]
+    xt = f" | X tile ({i},{i - 2}): in {beg[xs[0]]:7.1f} sum {t3[xs[0]]:7.1f} last sub seen {t4[xs[0]]:7.1f} out {end[xs[0]]:7.1f}" if len(xs) else ""
     line = f"  i {i:2d}  in {beg[d]:8.1f} sum {t3[d]:8.1f} sub-blocks 0, 1 seen {t6[d]:8.1f} {t7[d]:8.1f} seen {t4[d]:8.1f} done {t5[d]:8.1f} (+{t5[d] - t4[d]:4.1f}) out {end[d]:8.1f}"
     if prev is not None: line += f" | column {t4[d] - prev:6.1f}"
+    line += xt
     prev = t4[d]
     print(line)
 if DS:
