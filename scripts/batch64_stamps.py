@@ -80,4 +80,5 @@ if DS:
         idx = [j for j in sorted(lab) if v[j] > 0]
         print(f"diagonal block {i} (us since its entry): " + "  ".join(f"{lab[j]} {(v[j] - v[0]) / 100.0:.1f}" for j in idx)
               + (f"  [phase 1, us after pub1: waves 0, 1 (pivots) {(v[21] - v[5]) / 100.0:.1f} {(v[22] - v[5]) / 100.0:.1f}, waves 2, 3 (idle) {(v[23] - v[5]) / 100.0:.1f} {(v[24] - v[5]) / 100.0:.1f}]" if v[21] > 0 else "")
+              + (f"  [publication of sub-block 0 by wave 3: enters at {(v[25] - v[0]) / 100.0:.1f}, word stored and acknowledged at {(v[26] - v[0]) / 100.0:.1f}]" if v[26] > 0 else "")
               + (f"  [s_memtime ran at {(v[31] - v[30]) / ((v[20] - v[0]) / 100.0):.0f} MHz]" if v[31] > v[30] > 0 else ""))
